@@ -1,0 +1,221 @@
+"""CPU oracle (test infrastructure only, see oracle/__init__.py): PyramidBox forward
+restated with `torch.nn.functional` on the CPU backend -- the same ATen routines the
+reference's nn.Modules dispatch to, so outputs are bit-identical to the reference on
+the same machine.  Weights come in as a plain {name: array} dict with the reference's
+state-dict keys.
+
+Res50:  reference pyramid.py:218-351 (+ :41-48 SSHContext, :61-69 ContextTexture,
+        :97-103 Bottleneck)
+try3:   reference pyramid_mb2_try3.py:218-340 (+ :130-134 InvertedResidual)
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import postproc
+
+
+def _t(sd):
+    return {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v)))
+            for k, v in sd.items()}
+
+
+def _conv(sd, name, x, stride=1, padding=0, dilation=1, groups=1):
+    return F.conv2d(x, sd[name + ".weight"], sd.get(name + ".bias"), stride, padding,
+                    dilation, groups)
+
+
+def _bn(sd, name, x):
+    return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"],
+                        sd[name + ".weight"], sd[name + ".bias"], False, 0.0, 1e-5)
+
+
+def _ssh(sd, name, x):
+    # pyramid.py:41-48
+    x1 = F.relu(_conv(sd, name + ".conv1", x, 1, 1))
+    x2 = F.relu(_conv(sd, name + ".conv2", x, 1, 2, 2))
+    x2_1 = F.relu(_conv(sd, name + ".conv2_1", x2, 1, 1))
+    x2_2 = F.relu(_conv(sd, name + ".conv2_2", x2, 1, 2, 2))
+    x2_2 = F.relu(_conv(sd, name + ".conv2_2_1", x2_2, 1, 1))
+    return torch.cat([x1, x2_1, x2_2], 1)
+
+
+def _ct(sd, name, up, main):
+    # pyramid.py:61-69
+    up = _conv(sd, name + ".up_conv", up)
+    main = _conv(sd, name + ".main_conv", main)
+    H, W = main.shape[2], main.shape[3]
+    res = F.interpolate(up, scale_factor=2, mode='bilinear', align_corners=False)
+    if res.shape[2] != H or res.shape[3] != W:
+        res = res[:, :, 0:H, 0:W]
+    return res + main
+
+
+def _bottleneck(sd, p, x, stride):
+    # pyramid.py:97-103
+    out = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x)))
+    out = F.relu(_bn(sd, p + ".bn2", _conv(sd, p + ".conv2", out, stride, 1)))
+    out = _bn(sd, p + ".bn3", _conv(sd, p + ".conv3", out))
+    if (p + ".downsample.0.weight") in sd:
+        sc = _bn(sd, p + ".downsample.1", _conv(sd, p + ".downsample.0", x, stride))
+    else:
+        sc = x
+    return F.relu(out + sc)
+
+
+def _heads(sd, sources):
+    # pyramid.py:291-309 max-in-out + NHWC flatten + level concat
+    loc, conf = [], []
+    for idx, x in enumerate(sources):
+        tmp = _conv(sd, "face_conf.%d" % idx, x, 1, 1)
+        if idx == 0:
+            neg = tmp[:, 0:3].max(1, keepdim=True)[0]
+            c2 = torch.cat([neg, tmp[:, 3:4]], 1)
+        else:
+            pos = tmp[:, 1:4].max(1, keepdim=True)[0]
+            c2 = torch.cat([tmp[:, 0:1], pos], 1)
+        conf.append(c2.permute(0, 2, 3, 1).contiguous())
+        loc.append(_conv(sd, "face_loc.%d" % idx, x, 1, 1).permute(0, 2, 3, 1).contiguous())
+    loc = torch.cat([o.reshape(o.size(0), -1) for o in loc], 1)
+    conf = torch.cat([o.reshape(o.size(0), -1) for o in conf], 1)
+    return loc.view(loc.size(0), -1, 4), conf.view(conf.size(0), -1, 2)
+
+
+@torch.no_grad()
+def res50_forward(sd, x, want=()):
+    """x: [B,3,H,W] f32 (already mean-subtracted BGR).  Returns dict with `loc`
+    [B,P,4], `conf` [B,P,2] (softmaxed) and any intermediates named in `want`."""
+    sd = _t(sd)
+    x = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.asarray(x, dtype=np.float32))
+    t = {}
+    c1 = F.relu(_bn(sd, "bn1", _conv(sd, "conv1", x, 2, 3)))          # :229
+    t["stem"] = c1
+    c1 = F.max_pool2d(c1, kernel_size=3, stride=2, padding=1)         # :230
+    t["pool"] = c1
+    h = c1
+    feats = []
+    for li, (nblk, stride) in enumerate([(3, 1), (4, 2), (6, 2), (3, 2)], start=1):
+        for b in range(nblk):
+            h = _bottleneck(sd, "layer%d.%d" % (li, b), h, stride if b == 0 else 1)
+        feats.append(h)
+    c2, c3, c4, c5 = feats                                            # :231-234
+    c6 = F.relu(_bn(sd, "layer5.1", _conv(sd, "layer5.0", c5)))
+    c6 = F.relu(_bn(sd, "layer5.4", _conv(sd, "layer5.3", c6, 2, 1)))  # :235
+    c7 = F.relu(_bn(sd, "layer6.1", _conv(sd, "layer6.0", c6)))
+    c7 = F.relu(_bn(sd, "layer6.4", _conv(sd, "layer6.3", c7, 2, 1)))  # :236
+    t.update(c2=c2, c3=c3, c4=c4, c5=c5, c6=c6, c7=c7)
+    c5_lat = _conv(sd, "latlayer_fc", c5)                             # :239-241
+    c6_lat = _conv(sd, "latlayer_c6", c6)
+    c7_lat = _conv(sd, "latlayer_c7", c7)
+    c4_fuse = _ct(sd, "conv5_ct_py", c5_lat, c4)                      # :243-245
+    c3_fuse = _ct(sd, "conv4_ct_py", c4_fuse, c3)
+    c2_fuse = _ct(sd, "conv3_ct_py", c3_fuse, c2)
+    t.update(c4_ct=c4_fuse, c3_ct=c3_fuse, c2_ct=c2_fuse)
+    c2_fuse = _conv(sd, "smooth_c3", c2_fuse, 1, 1)                   # :247-249
+    c3_fuse = _conv(sd, "smooth_c4", c3_fuse, 1, 1)
+    c4_fuse = _conv(sd, "smooth_c5", c4_fuse, 1, 1)
+    t.update(c2_smooth=c2_fuse, c3_smooth=c3_fuse, c4_smooth=c4_fuse)
+    sources = [_ssh(sd, "conv2_SSH", c2_fuse), _ssh(sd, "conv3_SSH", c3_fuse),
+               _ssh(sd, "conv4_SSH", c4_fuse), _ssh(sd, "conv5_SSH", c5_lat),
+               _ssh(sd, "conv6_SSH", c6_lat), _ssh(sd, "conv7_SSH", c7_lat)]   # :255-266
+    for i, s in enumerate(sources):
+        t["src%d" % i] = s
+    loc, conf_logits = _heads(sd, sources)
+    t["conf_logits"] = conf_logits
+    out = {"loc": loc.numpy(), "conf": torch.softmax(conf_logits, -1).numpy()}    # :332
+    for k in want:
+        out[k] = t[k].numpy()
+    return out
+
+
+def _ir(sd, p, x, inp, oup, stride, t):
+    # pyramid_mb2_try3.py:73-134
+    h = x
+    i = 0
+    hid = int(round(inp * t))
+    if t != 1:
+        h = F.relu6(_bn(sd, "%s.conv.%d" % (p, i + 1), _conv(sd, "%s.conv.%d" % (p, i), h)))
+        i += 3
+    h = F.relu6(_bn(sd, "%s.conv.%d" % (p, i + 1),
+                    _conv(sd, "%s.conv.%d" % (p, i), h, stride, 1, 1, hid)))
+    i += 3
+    h = _bn(sd, "%s.conv.%d" % (p, i + 1), _conv(sd, "%s.conv.%d" % (p, i), h))
+    if stride == 1 and inp == oup:
+        return x + h
+    return h
+
+
+def _try3_blocks():
+    # (feature index, inp, oup, stride, t): pyramid_mb2_try3.py:148-168
+    cfgs = [(1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2),
+            (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1)]
+    blocks, inp, idx = [], 32, 1
+    for t, c, n, st in cfgs:
+        for i in range(n):
+            blocks.append((idx, inp, c, st if i == 0 else 1, t))
+            inp = c
+            idx += 1
+    return blocks
+
+
+@torch.no_grad()
+def try3_forward(sd, x, want=()):
+    """PyramidBox-MobileNetV2 "try3" forward, reference pyramid_mb2_try3.py:218-340."""
+    sd = _t(sd)
+    x = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.asarray(x, dtype=np.float32))
+    blocks = _try3_blocks()
+    t = {}
+    h = F.relu6(_bn(sd, "features.0.1", _conv(sd, "features.0.0", x, 2, 1)))
+    t["stem"] = h
+    taps = {}
+    for idx, inp, oup, st, tt in blocks:
+        h = _ir(sd, "features.%d" % idx, h, inp, oup, st, tt)
+        taps[idx] = h
+    c2, c3, c4, c5 = taps[3], taps[6], taps[13], taps[17]             # :229-236
+    c6 = _ir(sd, "layer6", c5, 320, 160, 2, 6)                        # :238
+    t.update(c2=c2, c3=c3, c4=c4, c5=c5, c6=c6)
+    c6 = _conv(sd, "smooth_c6", c6, 1, 1)                             # :242-243
+    c5 = _conv(sd, "smooth_c5", c5, 1, 1)
+    c4 = _ct(sd, "conv4_ct_py", c5, c4)                               # :245-247
+    c3 = _ct(sd, "conv3_ct_py", c4, c3)
+    c2 = _ct(sd, "conv2_ct_py", c3, c2)
+    c2 = _conv(sd, "smooth_c2", c2, 1, 1)                             # :249-251
+    c3 = _conv(sd, "smooth_c3", c3, 1, 1)
+    c4 = _conv(sd, "smooth_c4", c4, 1, 1)
+    t.update(c2_smooth=c2, c3_smooth=c3, c4_smooth=c4, c5_smooth=c5, c6_smooth=c6)
+    sources = [_ssh(sd, "conv2_SSH", c2), _ssh(sd, "conv3_SSH", c3), _ssh(sd, "conv4_SSH", c4),
+               _ssh(sd, "conv5_SSH", c5), _ssh(sd, "conv6_SSH", c6)]  # :257-266
+    for i, s in enumerate(sources):
+        t["src%d" % i] = s
+    loc, conf_logits = _heads(sd, sources)     # zip() truncates to 5 sources (:288)
+    t["conf_logits"] = conf_logits
+    out = {"loc": loc.numpy(), "conf": torch.softmax(conf_logits, -1).numpy()}
+    for k in want:
+        out[k] = t[k].numpy()
+    return out
+
+
+def preprocess(frame_bgr_u8):
+    """u8 BGR HWC -> f32 NCHW minus (104,117,123): reference iouTracke_cal.py:40-46."""
+    x = np.asarray(frame_bgr_u8).astype(np.float32)
+    x -= np.array([104, 117, 123], dtype=np.float32)
+    return np.ascontiguousarray(x.transpose(2, 0, 1)[None])
+
+
+def detect_frame(sd, frame_bgr_u8, arch="res50", detect=None, priorbox=None):
+    """Full per-frame path: preprocess -> net -> Detect.  Returns [1,2,top_k,5]."""
+    x = preprocess(frame_bgr_u8)
+    H, W = x.shape[2], x.shape[3]
+    fwd = res50_forward if arch == "res50" else try3_forward
+    o = fwd(sd, x)
+    if priorbox is None:
+        if arch == "res50":
+            priorbox = postproc.PriorBoxLayer(W, H)
+        else:
+            priorbox = postproc.PriorBoxLayer(W, H, stride=[4, 8, 16, 32, 64],
+                                              box=(16, 32, 64, 128, 256))
+    priors = postproc.build_priors(priorbox, H, W, arch)
+    if detect is None:
+        detect = (postproc.Detect(2, 0, 750, 0.3, 0.5) if arch == "res50"
+                  else postproc.Detect(2, 0, 750, 0.2, 0.35))
+    return detect(o["loc"], o["conf"], priors)
