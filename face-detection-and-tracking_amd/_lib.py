@@ -1,0 +1,126 @@
+"""ctypes binding of libfdt_hip.so (the C ABI declared in include/fdt.h).
+
+There is NO fallback: if the shared library is missing or a call fails, this raises.
+Build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C face-detection-and-tracking_amd/csrc -j8`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfdt_hip.so")
+
+FDT_OK = 0
+FDT_ERR_ARG, FDT_ERR_HIP, FDT_ERR_STATE, FDT_ERR_NAME = -1, -2, -3, -4
+ARCH_RES50, ARCH_TRY3, ARCH_FACEBOX = 0, 1, 2
+FRAME_U8_HWC_BGR, FRAME_F32_NCHW = 0, 1
+F32, F64 = 0, 1
+
+
+class FdtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libfdt_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_c_int_p = C.POINTER(C.c_int)
+_c_f32_p = C.POINTER(C.c_float)
+_c_f64_p = C.POINTER(C.c_double)
+_c_i64_p = C.POINTER(C.c_longlong)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes): every symbol include/fdt.h declares
+SIGNATURES = {
+    "fdt_last_error": (C.c_char_p, []),
+    "fdt_version": (C.c_int, []),
+    "fdt_device_count": (C.c_int, [_c_int_p]),
+    "fdt_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "fdt_set_device": (C.c_int, [C.c_int]),
+    "fdt_device_synchronize": (C.c_int, []),
+    "fdt_priorbox": (C.c_int, [C.c_int] * 5 + [_vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "fdt_decode": (C.c_int, [_vp, _vp, C.c_int, C.c_float, C.c_float, _vp]),
+    "fdt_nms": (C.c_int, [_vp, _vp, C.c_int, C.c_float, C.c_int, _vp, _c_int_p]),
+    "fdt_detect": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                             C.c_float, C.c_int, C.c_float, C.c_float, _vp, _vp]),
+    "fdt_detect_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                 C.c_float, C.c_int, C.c_float, C.c_float, _vp, _vp, _vp,
+                                 C.c_longlong, _vp]),
+    "fdt_detect_workspace_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "fdt_pairwise_iou": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp]),
+    "fdt_tracker_create": (_vp, [C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]),
+    "fdt_tracker_destroy": (None, [_vp]),
+    "fdt_tracker_reset": (C.c_int, [_vp]),
+    "fdt_tracker_step": (C.c_int, [_vp, _vp, C.c_int]),
+    "fdt_tracker_step_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
+    "fdt_tracker_finish": (C.c_int, [_vp]),
+    "fdt_tracker_num_tracks": (C.c_int, [_vp, _c_int_p]),
+    "fdt_tracker_track_info": (C.c_int, [_vp, C.c_int, _c_int_p, _c_f64_p, _c_int_p]),
+    "fdt_tracker_track_boxes": (C.c_int, [_vp, C.c_int, _vp]),
+    "fdt_model_create": (_vp, [C.c_int, C.c_int]),
+    "fdt_model_destroy": (None, [_vp]),
+    "fdt_model_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int, _c_i64_p]),
+    "fdt_model_missing": (C.c_int, [_vp, _c_int_p]),
+    "fdt_model_missing_name": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int]),
+    "fdt_model_finalize": (C.c_int, [_vp]),
+    "fdt_model_set_priorbox": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _c_int_p, _c_int_p]),
+    "fdt_model_set_detect": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float, C.c_int]),
+    "fdt_model_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "fdt_model_forward_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "fdt_model_forward_raw": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "fdt_model_num_priors": (C.c_int, [_vp, _c_int_p]),
+    "fdt_model_get_tensor": (C.c_int, [_vp, C.c_char_p, _vp, C.c_longlong, _c_i64_p]),
+    "fdt_model_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "fdt_model_profile_read": (C.c_int, [_vp, C.c_int, C.c_char_p, _vp, _vp, _c_int_p]),
+    "fdt_model_flops": (C.c_int, [_vp, _c_f64_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded CDLL (loads on first use; raises if the library was not built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FdtError(FDT_ERR_STATE,
+                           "%s not found -- build it first (make -C %s); there is no CPU fallback"
+                           % (LIB_PATH, os.path.dirname(LIB_PATH)))
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)        # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != FDT_OK:
+        raise FdtError(rc, (lib().fdt_last_error() or b"").decode(errors="replace"))
+    return rc
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_vp)
+
+
+def as_c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().fdt_device_count(C.byref(n)))
+    return n.value
+
+
+def device_name(dev=0):
+    buf = C.create_string_buffer(256)
+    check(lib().fdt_device_name(dev, buf, 256))
+    return buf.value.decode()

@@ -1,0 +1,210 @@
+"""Shared host-side detector object behind `pyramid.SFD` / `pyramid_mb2_try3.SFD_mobile`.
+
+Mirrors what callers of the reference modules rely on: `load_state_dict`,
+`load_weights`, mutable `.priorbox` / `.firstTime` / `.detect` attributes, `.priors` after a
+forward, `.cuda()` / `.eval()` no-ops, and `net(x) -> Tensor[B,2,top_k,5]`.  All compute happens
+in libfdt_hip.so; torch is only the container for weights in and detections out.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .layers import Detect, PriorBoxLayer
+
+
+class DetectorNet:
+    _arch = None
+    _default_priorbox = None     # () -> PriorBoxLayer
+    _default_detect = None       # () -> Detect
+
+    def __init__(self, phase, num_classes, size, device=0):
+        if phase != 'test':
+            raise NotImplementedError("only phase='test' (inference) is implemented on this path")
+        self.phase = phase
+        self.num_classes = num_classes
+        self.size = size
+        self.firstTime = True
+        self.priorbox = type(self)._default_priorbox(size)
+        self.priors = None
+        self.detect = type(self)._default_detect(num_classes)
+        self.training = False
+        self._device = device
+        self._h = _lib.lib().fdt_model_create(self._arch, device)
+        if not self._h:
+            raise _lib.FdtError(_lib.FDT_ERR_HIP, (_lib.lib().fdt_last_error() or b"").decode())
+        self._loaded = False
+        self._sd_cache = None
+        self._prior_shape = None
+
+    # ---- nn.Module surface the reference's callers touch ------------------------------------
+    def cuda(self, device=None):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().fdt_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def state_dict(self):
+        return self._sd_cache
+
+    def load_state_dict(self, state_dict, strict=True):
+        L = _lib.lib()
+        unexpected = []
+        for k, v in state_dict.items():
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            dims = (C.c_longlong * max(a.ndim, 1))(*a.shape)
+            rc = L.fdt_model_set_tensor(self._h, k.encode(), _lib.ptr(a), a.ndim, dims)
+            if rc == _lib.FDT_ERR_NAME:
+                unexpected.append(k)
+            else:
+                _lib.check(rc)
+        n = C.c_int(0)
+        _lib.check(L.fdt_model_missing(self._h, C.byref(n)))
+        missing = []
+        for i in range(n.value):
+            buf = C.create_string_buffer(256)
+            _lib.check(L.fdt_model_missing_name(self._h, i, buf, 256))
+            missing.append(buf.value.decode())
+        if missing or (strict and unexpected):
+            msg = []
+            if missing:
+                msg.append("Missing key(s) in state_dict: " + ", ".join('"%s"' % k for k in missing))
+            if strict and unexpected:
+                msg.append("Unexpected key(s) in state_dict: " + ", ".join('"%s"' % k for k in unexpected))
+            raise RuntimeError("Error(s) in loading state_dict for %s:\n\t%s"
+                               % (type(self).__name__, "\n\t".join(msg)))
+        _lib.check(L.fdt_model_finalize(self._h))
+        self._sd_cache = state_dict
+        self._loaded = True
+        return self
+
+    def load_weights(self, base_file):
+        """reference pyramid.py:353-364: keep only the keys the model knows."""
+        print('Loading weights into state dict...')
+        sd = torch.load(base_file, map_location='cpu', weights_only=True)
+        self.load_state_dict(sd, strict=False)
+        print('Finished!')
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def _sync_attributes(self, H, W):
+        L = _lib.lib()
+        if self.firstTime:
+            pb = self.priorbox
+            nlev = len(pb.stride)
+            if any(int(s) != 1 for s in pb.scales[:nlev]) or any(len(a) for a in pb.aspect_ratios[:nlev]):
+                raise NotImplementedError("the fused path supports scale=1 / no aspect ratios "
+                                          "(every configuration the reference uses)")
+            st = (C.c_int * nlev)(*[int(s) for s in pb.stride])
+            bx = (C.c_int * nlev)(*[int(b) for b in pb.box[:nlev]])
+            _lib.check(L.fdt_model_set_priorbox(self._h, int(pb.width), int(pb.height), nlev, st, bx))
+            self.firstTime = False
+            self._prior_shape = (H, W)
+        elif self._prior_shape != (H, W):
+            raise RuntimeError("priors were generated for input %s, got %s; set net.firstTime = True "
+                               "(the reference fails with a size mismatch here)" % (self._prior_shape, (H, W)))
+        d = self.detect
+        _lib.check(L.fdt_model_set_detect(self._h, int(d.top_k), float(d.conf_thresh),
+                                          float(d.nms_thresh), int(d.nms_top_k)))
+
+    def _prepare(self, x):
+        if isinstance(x, torch.Tensor):
+            x = x.detach().cpu().numpy()
+        x = np.asarray(x)
+        if x.dtype == np.uint8:
+            if x.ndim == 3:
+                x = x[None]
+            B, H, W, _ = x.shape
+            return np.ascontiguousarray(x), _lib.FRAME_U8_HWC_BGR, B, H, W
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        B, _, H, W = x.shape
+        return x, _lib.FRAME_F32_NCHW, B, H, W
+
+    def __call__(self, x):
+        """x: [B,3,H,W] f32 (mean-subtracted BGR, what the reference passes) or uint8 [B,H,W,3]
+        raw BGR frames (mean subtraction then happens on the GPU)."""
+        if not self._loaded:
+            raise RuntimeError("weights not loaded: call load_state_dict / load_weights first")
+        x, fmt, B, H, W = self._prepare(x)
+        self._sync_attributes(H, W)
+        out = np.empty((B, 2, self.detect.top_k, 5), dtype=np.float32)
+        counts = np.zeros((B, 2), dtype=np.int32)
+        _lib.check(_lib.lib().fdt_model_forward(self._h, _lib.ptr(x), fmt, B, H, W, _lib.ptr(out),
+                                                _lib.ptr(counts)))
+        self.last_counts = counts
+        self.priors = torch.from_numpy(self.get_tensor("priors")[0])
+        return torch.from_numpy(out)
+
+    forward = __call__
+
+    # ---- debugging / parity helpers ------------------------------------------------------------
+    def forward_raw(self, x):
+        """(loc [B,P,4], softmaxed conf [B,P,2]) without Detect."""
+        x, fmt, B, H, W = self._prepare(x)
+        self._sync_attributes(H, W)
+        # a first call is needed to know P: run once with small outputs via get_tensor
+        L = _lib.lib()
+        P = self._num_priors_for(x, fmt, B, H, W)
+        loc = np.empty((B, P, 4), np.float32)
+        conf = np.empty((B, P, 2), np.float32)
+        _lib.check(L.fdt_model_forward_raw(self._h, _lib.ptr(x), fmt, B, H, W, _lib.ptr(loc), _lib.ptr(conf)))
+        return loc, conf
+
+    def _num_priors_for(self, x, fmt, B, H, W):
+        def half(n):
+            return (n - 1) // 2 + 1
+        h, w = half(half(H)), half(half(W))
+        P = 0
+        for _ in range(self._n_sources):
+            P += h * w
+            h, w = half(h), half(w)
+        return P
+
+    def get_tensor(self, name):
+        L = _lib.lib()
+        dims = (C.c_longlong * 4)()
+        _lib.check(L.fdt_model_get_tensor(self._h, name.encode(), None, 0, dims))
+        shape = tuple(int(d) for d in dims)
+        out = np.empty(shape, np.float32)
+        _lib.check(L.fdt_model_get_tensor(self._h, name.encode(), _lib.ptr(out), out.size, dims))
+        if name in ("loc", "conf", "conf_logits", "priors"):
+            out = out.reshape(shape[:3])
+        return out
+
+    def flops_per_frame(self):
+        f = C.c_double(0)
+        _lib.check(_lib.lib().fdt_model_flops(self._h, C.byref(f)))
+        return f.value
+
+    def profile(self, on=True):
+        _lib.check(_lib.lib().fdt_model_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        L = _lib.lib()
+        n = C.c_int(0)
+        cap = 512
+        names = C.create_string_buffer(cap * 48)
+        ms = np.zeros(cap, np.float32)
+        fl = np.zeros(cap, np.float64)
+        _lib.check(L.fdt_model_profile_read(self._h, cap, names, _lib.ptr(ms), _lib.ptr(fl), C.byref(n)))
+        out = []
+        for i in range(min(n.value, cap)):
+            nm = names.raw[i * 48:(i + 1) * 48].split(b"\0")[0].decode()
+            out.append((nm, float(ms[i]), float(fl[i])))
+        return out

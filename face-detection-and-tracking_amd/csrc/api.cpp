@@ -1,0 +1,41 @@
+// Library-level entry points: error string, device queries.
+#include "common.h"
+
+namespace fdt {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* get_error() { return g_err; }
+}  // namespace fdt
+
+extern "C" const char* fdt_last_error(void) { return fdt::get_error(); }
+extern "C" int fdt_version(void) { return 100; }
+
+extern "C" int fdt_device_count(int* n) {
+  FDT_REQUIRE(n, FDT_ERR_ARG, "fdt_device_count: null pointer");
+  *n = 0;
+  FDT_HIP(hipGetDeviceCount(n));
+  return FDT_OK;
+}
+
+extern "C" int fdt_device_name(int dev, char* buf, int buflen) {
+  FDT_REQUIRE(buf && buflen > 0, FDT_ERR_ARG, "fdt_device_name: bad buffer");
+  hipDeviceProp_t p;
+  FDT_HIP(hipGetDeviceProperties(&p, dev));
+  snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+  return FDT_OK;
+}
+
+extern "C" int fdt_set_device(int dev) {
+  FDT_HIP(hipSetDevice(dev));
+  return FDT_OK;
+}
+
+extern "C" int fdt_device_synchronize(void) {
+  FDT_HIP(hipDeviceSynchronize());
+  return FDT_OK;
+}

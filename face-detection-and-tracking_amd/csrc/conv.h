@@ -1,0 +1,67 @@
+// Implicit-GEMM convolution on the f32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32): launch
+// interface.  See conv.hip for the kernel design.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+namespace fdt {
+
+// Convolution classes the three nets instantiate.
+enum ConvKind {
+  CONV_1x1_S1 = 0,
+  CONV_1x1_S2,
+  CONV_3x3_S1,      // pad 1
+  CONV_3x3_S1_D2,   // pad 2, dilation 2
+  CONV_3x3_S2,      // pad 1
+  CONV_7x7_S2,      // pad 3 (Res50 stem)
+  CONV_7x7_S4,      // pad 3 (FaceBox conv1)
+  CONV_5x5_S2,      // pad 2 (FaceBox conv2)
+  CONV_KIND_COUNT
+};
+
+// Output-tile shapes.  BM = output pixels (TH x TW patch), BN = output channels per workgroup.
+enum ConvTile {
+  TILE_128x128 = 0,  // 8x16 px, 128 ch : the workhorse
+  TILE_128x64,       // 8x16 px,  64 ch
+  TILE_128x32,       // 8x16 px,  32 ch : narrow heads (Cout = 8) and thin MobileNet layers
+  TILE_64x64,        // 8x8  px,  64 ch : small maps
+  TILE_64x128,       // 8x8  px, 128 ch : small maps, wide layers
+  CONV_TILE_COUNT
+};
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2 };
+
+struct ConvGeom {   // static description of one kernel class
+  int kh, kw, stride, dil, pad, kc;   // kc = input channels per LDS stage
+};
+ConvGeom conv_geom(ConvKind k);
+int tile_bm(ConvTile t);
+int tile_bn(ConvTile t);
+int tile_th(ConvTile t);
+int tile_tw(ConvTile t);
+
+struct ConvArgs {
+  const float* in;        // [B][Cin][Hin][Win]
+  const float* w;         // tiled weights, see tile_weights()
+  const float* bias;      // [Cout] (BN folded in) or nullptr
+  float* out;             // [B][out_ctot][Hout][Wout]; channels [out_coff, out_coff+Cout) are written
+  const float* res;       // residual [B][res_ctot][Hout][Wout] added before the activation, or nullptr
+  const float* up;        // [B][Cout][up_h][up_w]: bilinear x2 (align_corners=False) upsample added, or nullptr
+  int B, Cin, Hin, Win, Cout, Hout, Wout;
+  int out_ctot, out_coff, res_ctot, res_coff, up_h, up_w;
+  int act;
+};
+
+// Re-tile OIHW weights for (kind, tile): [Cout_pad/BN][ceil(Cin/KC)][KC][taps][BN], zero padded.
+// `scale` (per output channel, may be null) is the folded BN factor.
+void tile_weights(const float* w_oihw, const float* scale, int Cout, int Cin, ConvKind kind,
+                  ConvTile tile, std::vector<float>& out);
+
+// FLOPs (2*MAC) of one launch, algorithmic (no padding).
+double conv_flops(const ConvArgs& a, ConvKind kind);
+
+int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a, hipStream_t st);
+bool conv_supported(ConvKind kind, ConvTile tile);
+
+}  // namespace fdt

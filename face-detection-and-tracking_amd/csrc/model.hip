@@ -1,0 +1,1059 @@
+// Detector model handle: weight store (reference state-dict keys), eval-BN folding, per-shape execution
+// plan, and the forward pass as a flat list of HIP launches on one stream.
+//
+// Forward graphs restated from:
+//   Res50   pyramid.py:218-351  (Bottleneck :97-103, ContextTexture :61-69, SSHContext :41-48)
+//   try3    pyramid_mb2_try3.py:218-340 (InvertedResidual :73-134)
+//   FaceBox FACEBOX/networks.py:87-116 (Inception :43-57), FACEBOX/multibox_layer.py:28-50
+// Dead work the reference computes and throws away in test phase (head_loc/head_conf,
+// pyramid.py:312-317) is skipped; its weights are still accepted by set_tensor.
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "conv.h"
+#include "ops.h"
+#include "postproc.h"
+
+using namespace fdt;
+
+namespace {
+
+struct HostT {
+  std::vector<float> v;
+  std::vector<long long> dims;
+};
+
+struct Tensor {
+  std::string name;
+  int C = 0, H = 0, W = 0;
+  float* d = nullptr;
+};
+
+enum OpType { OP_CONV, OP_POOL, OP_DW, OP_HEADFIN, OP_MBOXFIN };
+
+struct Op {
+  OpType type;
+  std::string name;
+  double flops = 0;
+  // conv
+  ConvKind kind;
+  ConvTile tile;
+  ConvArgs ca;
+  // pool / dw / finalize
+  int in_t = -1, in2_t = -1, out_t = -1, stride = 1, crelu = 0, act = 0;
+  const float* w = nullptr;
+  const float* bias = nullptr;
+  int level0 = 0, p_off = 0, anchors = 1;
+};
+
+struct DevW {
+  float* w = nullptr;
+  float* bias = nullptr;
+};
+
+}  // namespace
+
+struct fdt_model {
+  int arch = 0, device = 0;
+  hipStream_t stream = nullptr;
+  std::map<std::string, HostT> sd;
+  std::set<std::string> expected;      // keys the forward graph reads
+  bool finalized = false;
+
+  // detect / priorbox configuration (mutable attributes of the reference module)
+  int top_k = 750, nms_top_k = 5000;
+  float conf_t = 0.3f, nms_t = 0.5f;
+  bool pb_set = false, priors_dirty = true;
+  int pb_w = 0, pb_h = 0;
+  std::vector<int> pb_stride, pb_box;
+
+  // plan
+  int pB = 0, pH = 0, pW = 0;
+  bool dry = false;
+  std::vector<Tensor> tensors;
+  std::vector<Op> ops;
+  std::map<std::string, DevW> wcache;  // key: layer|tile
+  std::vector<void*> plan_allocs;
+  std::vector<std::pair<int, int>> levels;  // (H, W) of each detection source
+  int P = 0;
+  float *d_loc = nullptr, *d_conf = nullptr, *d_logits = nullptr, *d_priors = nullptr, *d_out = nullptr;
+  int* d_counts = nullptr;
+  void* d_ws = nullptr;
+  DetectPlan dplan;
+  unsigned char* d_frames_u8 = nullptr;
+  double flops_per_frame = 0;
+
+  // profiling
+  bool profile = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<float> prof_ms;
+  int prof_runs = 0;
+
+  ~fdt_model() {
+    free_plan();
+    for (auto& kv : wcache) {
+      if (kv.second.w) (void)hipFree(kv.second.w);
+      if (kv.second.bias) (void)hipFree(kv.second.bias);
+    }
+    for (auto e : ev) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  void free_plan() {
+    for (void* p : plan_allocs) (void)hipFree(p);
+    plan_allocs.clear();
+    tensors.clear();
+    ops.clear();
+    levels.clear();
+    d_loc = d_conf = d_logits = d_priors = d_out = nullptr;
+    d_counts = nullptr;
+    d_ws = nullptr;
+    d_frames_u8 = nullptr;
+    pB = pH = pW = 0;
+  }
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ builder
+struct Builder {
+  fdt_model* m;
+  int B;
+  int rc = FDT_OK;
+
+  int fail(int code) {
+    if (rc == FDT_OK) rc = code;
+    return -1;
+  }
+
+  int new_tensor(const std::string& name, int C, int H, int W) {
+    Tensor t;
+    t.name = name;
+    t.C = C;
+    t.H = H;
+    t.W = W;
+    if (!m->dry) {
+      size_t bytes = (size_t)B * C * H * W * sizeof(float);
+      if (hipMalloc((void**)&t.d, bytes) != hipSuccess) {
+        set_error("hipMalloc(%zu) failed for tensor %s", bytes, name.c_str());
+        return fail(FDT_ERR_HIP);
+      }
+      m->plan_allocs.push_back(t.d);
+    }
+    m->tensors.push_back(t);
+    return (int)m->tensors.size() - 1;
+  }
+
+  const HostT* get(const std::string& key) {
+    m->expected.insert(key);
+    if (m->dry) return nullptr;
+    auto it = m->sd.find(key);
+    if (it == m->sd.end()) {
+      set_error("missing weight tensor '%s'", key.c_str());
+      fail(FDT_ERR_STATE);
+      return nullptr;
+    }
+    return &it->second;
+  }
+
+  // Fold eval BatchNorm (eps 1e-5) into per-channel scale / bias.  bias_out = (conv_bias - mean) *
+  // scale + beta, scale = gamma / sqrt(var + eps).
+  void fold(const std::string& bn, const HostT* conv_bias, int Cout, std::vector<float>& scale,
+            std::vector<float>& bias) {
+    scale.assign(Cout, 1.0f);
+    bias.assign(Cout, 0.0f);
+    if (conv_bias)
+      for (int c = 0; c < Cout; ++c) bias[c] = conv_bias->v[c];
+    if (bn.empty()) return;
+    const HostT* g = get(bn + ".weight");
+    const HostT* be = get(bn + ".bias");
+    const HostT* mu = get(bn + ".running_mean");
+    const HostT* var = get(bn + ".running_var");
+    if (!g || !be || !mu || !var) return;
+    for (int c = 0; c < Cout; ++c) {
+      double s = (double)g->v[c] / std::sqrt((double)var->v[c] + 1e-5);
+      scale[c] = (float)s;
+      bias[c] = (float)(((double)bias[c] - (double)mu->v[c]) * s + (double)be->v[c]);
+    }
+  }
+
+  static ConvTile choose_tile(ConvKind kind, int Cout, int Ho, int Wo, int B) {
+    ConvTile best = TILE_128x128;
+    double best_cost = 1e300;
+    for (int t = 0; t < CONV_TILE_COUNT; ++t) {
+      if (!conv_supported(kind, (ConvTile)t)) continue;
+      const int bm = tile_bm((ConvTile)t), bn = tile_bn((ConvTile)t);
+      const long long tiles_m = (long long)ceil_div(Ho, tile_th((ConvTile)t)) * ceil_div(Wo, tile_tw((ConvTile)t));
+      const long long blocks = tiles_m * ceil_div(Cout, bn) * B;
+      // rounds over 256 CUs x 2 resident workgroups, times the work of one workgroup; small
+      // wave tiles pay ~15% for their lower MFMA:LDS-read ratio
+      const double rounds = std::ceil((double)blocks / 512.0);
+      double cost = rounds * bm * bn;
+      if (bm * bn <= 64 * 64) cost *= 1.15;
+      if (cost < best_cost - 1e-9) {
+        best_cost = cost;
+        best = (ConvTile)t;
+      }
+    }
+    return best;
+  }
+
+  // Upload (cached) tiled weights + bias for a conv given concatenated OIHW weights.
+  int device_weights(const std::string& key, const std::vector<float>& w_oihw,
+                     const std::vector<float>& scale, const std::vector<float>& bias, int Cout, int Cin,
+                     ConvKind kind, ConvTile tile, DevW& out) {
+    std::string ck = key + "|" + std::to_string((int)kind) + "|" + std::to_string((int)tile);
+    auto it = m->wcache.find(ck);
+    if (it != m->wcache.end()) {
+      out = it->second;
+      return FDT_OK;
+    }
+    std::vector<float> tiled;
+    tile_weights(w_oihw.data(), scale.data(), Cout, Cin, kind, tile, tiled);
+    DevW d;
+    FDT_HIP(hipMalloc((void**)&d.w, tiled.size() * 4));
+    FDT_HIP(hipMemcpy(d.w, tiled.data(), tiled.size() * 4, hipMemcpyHostToDevice));
+    FDT_HIP(hipMalloc((void**)&d.bias, (size_t)Cout * 4));
+    FDT_HIP(hipMemcpy(d.bias, bias.data(), (size_t)Cout * 4, hipMemcpyHostToDevice));
+    m->wcache[ck] = d;
+    out = d;
+    return FDT_OK;
+  }
+
+  struct ConvOpt {
+    std::string bn;           // BatchNorm module to fold ("" = none)
+    bool bias = true;         // conv has its own bias tensor
+    int act = ACT_NONE;
+    int out_t = -1, out_coff = 0;   // write into a channel slice of an existing tensor
+    int res_t = -1;           // residual tensor (same shape as the output)
+    int up_t = -1;            // coarser map to bilinear-upsample and add
+    std::string name2;        // second conv concatenated along Cout (fused loc+conf heads)
+    int cout2 = 0;
+  };
+
+  int conv(const std::string& name, int in_t, int Cout, ConvKind kind, const ConvOpt& o) {
+    if (rc != FDT_OK) return -1;
+    const Tensor in = m->tensors[in_t];
+    const ConvGeom g = conv_geom(kind);
+    const int Ho = (in.H + 2 * g.pad - g.dil * (g.kh - 1) - 1) / g.stride + 1;
+    const int Wo = (in.W + 2 * g.pad - g.dil * (g.kw - 1) - 1) / g.stride + 1;
+    const int Ctot = Cout + o.cout2;
+    if (Ho < 1 || Wo < 1) {
+      set_error("input too small: layer %s would have a %dx%d output", name.c_str(), Ho, Wo);
+      return fail(FDT_ERR_ARG);
+    }
+    int out_t = o.out_t;
+    if (out_t < 0) out_t = new_tensor(name, Ctot, Ho, Wo);
+    if (out_t < 0) return -1;
+    const HostT* w = get(name + ".weight");
+    const HostT* b = o.bias ? get(name + ".bias") : nullptr;
+    if (!o.bn.empty())
+      for (const char* sfx : {".weight", ".bias", ".running_mean", ".running_var"}) (void)get(o.bn + sfx);
+    const HostT* w2 = o.cout2 ? get(o.name2 + ".weight") : nullptr;
+    const HostT* b2 = o.cout2 ? get(o.name2 + ".bias") : nullptr;
+    Op op;
+    op.type = OP_CONV;
+    op.name = name;
+    op.kind = kind;
+    op.tile = choose_tile(kind, Ctot, Ho, Wo, B);
+    ConvArgs& a = op.ca;
+    memset(&a, 0, sizeof(a));
+    a.B = B;
+    a.Cin = in.C;
+    a.Hin = in.H;
+    a.Win = in.W;
+    a.Cout = Ctot;
+    a.Hout = Ho;
+    a.Wout = Wo;
+    a.out_ctot = m->tensors[out_t].C;
+    a.out_coff = o.out_coff;
+    a.act = o.act;
+    op.flops = conv_flops(a, kind);
+    op.out_t = out_t;
+    if (!m->dry) {
+      if (rc != FDT_OK) return -1;
+      const size_t per = (size_t)in.C * g.kh * g.kw;
+      if (w->v.size() != per * Cout || (b && (int)b->v.size() != Cout) ||
+          (w2 && w2->v.size() != per * o.cout2)) {
+        set_error("weight shape mismatch for layer %s", name.c_str());
+        return fail(FDT_ERR_STATE);
+      }
+      std::vector<float> scale, bias, wcat;
+      fold(o.bn, b, Cout, scale, bias);
+      if (rc != FDT_OK) return -1;
+      const std::vector<float>* wsrc = &w->v;
+      if (o.cout2) {
+        wcat = w->v;
+        wcat.insert(wcat.end(), w2->v.begin(), w2->v.end());
+        scale.resize(Ctot, 1.0f);
+        bias.resize(Ctot, 0.0f);
+        for (int c = 0; c < o.cout2; ++c) bias[Cout + c] = b2->v[c];
+        wsrc = &wcat;
+      }
+      DevW dw;
+      int r = device_weights(name, *wsrc, scale, bias, Ctot, in.C, kind, op.tile, dw);
+      if (r != FDT_OK) return fail(r);
+      a.in = in.d;
+      a.w = dw.w;
+      a.bias = dw.bias;
+      a.out = m->tensors[out_t].d;
+      if (o.res_t >= 0) {
+        const Tensor& rt = m->tensors[o.res_t];
+        if (rt.H != Ho || rt.W != Wo || rt.C != Ctot) {
+          set_error("residual shape mismatch at %s", name.c_str());
+          return fail(FDT_ERR_STATE);
+        }
+        a.res = rt.d;
+        a.res_ctot = rt.C;
+        a.res_coff = 0;
+      }
+      if (o.up_t >= 0) {
+        const Tensor& ut = m->tensors[o.up_t];
+        if (ut.C != Ctot) {
+          set_error("upsample channel mismatch at %s", name.c_str());
+          return fail(FDT_ERR_STATE);
+        }
+        a.up = ut.d;
+        a.up_h = ut.H;
+        a.up_w = ut.W;
+      }
+    }
+    m->ops.push_back(op);
+    m->flops_per_frame += op.flops / B;
+    return out_t;
+  }
+
+  int pool(const std::string& name, int in_t, int stride, int crelu) {
+    if (rc != FDT_OK) return -1;
+    const Tensor in = m->tensors[in_t];
+    const int Ho = (in.H - 1) / stride + 1, Wo = (in.W - 1) / stride + 1;
+    int out_t = new_tensor(name, crelu ? 2 * in.C : in.C, Ho, Wo);
+    if (out_t < 0) return -1;
+    Op op;
+    op.type = OP_POOL;
+    op.name = name;
+    op.in_t = in_t;
+    op.out_t = out_t;
+    op.stride = stride;
+    op.crelu = crelu;
+    memset(&op.ca, 0, sizeof(op.ca));
+    m->ops.push_back(op);
+    return out_t;
+  }
+
+  // depthwise 3x3 + BN + ReLU6
+  int dwconv(const std::string& name, const std::string& bn, int in_t, int stride, int act) {
+    if (rc != FDT_OK) return -1;
+    const Tensor in = m->tensors[in_t];
+    const int Ho = (in.H - 1) / stride + 1, Wo = (in.W - 1) / stride + 1;
+    int out_t = new_tensor(name, in.C, Ho, Wo);
+    if (out_t < 0) return -1;
+    const HostT* w = get(name + ".weight");
+    Op op;
+    op.type = OP_DW;
+    op.name = name;
+    op.in_t = in_t;
+    op.out_t = out_t;
+    op.stride = stride;
+    op.act = act;
+    op.flops = 2.0 * B * (double)Ho * Wo * in.C * 9;
+    memset(&op.ca, 0, sizeof(op.ca));
+    std::vector<float> scale, bias;
+    fold(bn, nullptr, in.C, scale, bias);
+    if (!m->dry) {
+      if (rc != FDT_OK) return -1;
+      if ((int)w->v.size() != in.C * 9) {
+        set_error("depthwise weight shape mismatch for %s", name.c_str());
+        return fail(FDT_ERR_STATE);
+      }
+      std::string ck = name + "|dw";
+      auto it = m->wcache.find(ck);
+      DevW d;
+      if (it == m->wcache.end()) {
+        std::vector<float> ws(w->v);
+        for (int c = 0; c < in.C; ++c)
+          for (int k = 0; k < 9; ++k) ws[c * 9 + k] *= scale[c];
+        if (hipMalloc((void**)&d.w, ws.size() * 4) != hipSuccess ||
+            hipMalloc((void**)&d.bias, bias.size() * 4) != hipSuccess) {
+          set_error("hipMalloc failed for %s", name.c_str());
+          return fail(FDT_ERR_HIP);
+        }
+        (void)hipMemcpy(d.w, ws.data(), ws.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(d.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice);
+        m->wcache[ck] = d;
+      } else {
+        d = it->second;
+      }
+      op.w = d.w;
+      op.bias = d.bias;
+    }
+    m->ops.push_back(op);
+    m->flops_per_frame += op.flops / B;
+    return out_t;
+  }
+
+  void headfin(int head_t, int level0) {
+    if (rc != FDT_OK) return;
+    Op op;
+    op.type = OP_HEADFIN;
+    op.name = "head_finalize";
+    op.in_t = head_t;
+    op.level0 = level0;
+    memset(&op.ca, 0, sizeof(op.ca));
+    m->levels.push_back({m->tensors[head_t].H, m->tensors[head_t].W});
+    m->ops.push_back(op);
+  }
+
+  // ---------------------------------------------------------------- shared PyramidBox blocks
+  int ssh(const std::string& n, int x, int xc) {   // pyramid.py:41-48
+    if (rc != FDT_OK) return -1;
+    const Tensor xin = m->tensors[x];
+    int src = new_tensor(n, 2 * xc, xin.H, xin.W);
+    if (src < 0) return -1;
+    ConvOpt o;
+    o.act = ACT_RELU;
+    o.out_t = src;
+    o.out_coff = 0;
+    conv(n + ".conv1", x, xc, CONV_3x3_S1, o);
+    ConvOpt t;
+    t.act = ACT_RELU;
+    int x2 = conv(n + ".conv2", x, xc / 2, CONV_3x3_S1_D2, t);
+    o.out_coff = xc;
+    conv(n + ".conv2_1", x2, xc / 2, CONV_3x3_S1, o);
+    int x22 = conv(n + ".conv2_2", x2, xc / 2, CONV_3x3_S1_D2, t);
+    o.out_coff = xc + xc / 2;
+    conv(n + ".conv2_2_1", x22, xc / 2, CONV_3x3_S1, o);
+    return src;
+  }
+
+  int ct(const std::string& n, int up, int main, int C) {   // pyramid.py:61-69
+    ConvOpt o;
+    int u = conv(n + ".up_conv", up, C, CONV_1x1_S1, o);
+    ConvOpt mo;
+    mo.up_t = u;
+    return conv(n + ".main_conv", main, C, CONV_1x1_S1, mo);
+  }
+
+  void heads(const std::vector<int>& sources) {   // pyramid.py:291-309
+    for (size_t i = 0; i < sources.size(); ++i) {
+      ConvOpt o;
+      o.name2 = "face_conf." + std::to_string(i);
+      o.cout2 = 4;
+      int hm = conv("face_loc." + std::to_string(i), sources[i], 4, CONV_3x3_S1, o);
+      if (hm < 0) return;
+      m->tensors[hm].name = "head" + std::to_string(i);
+      headfin(hm, i == 0);
+    }
+  }
+
+  // ---------------------------------------------------------------- Res50   pyramid.py:218-351
+  void build_res50(int H, int W) {
+    int x = new_tensor("input", 3, H, W);
+    ConvOpt st;
+    st.bn = "bn1";
+    st.bias = false;
+    st.act = ACT_RELU;
+    int c1 = conv("conv1", x, 64, CONV_7x7_S2, st);
+    if (c1 < 0) return;
+    m->tensors[c1].name = "stem";
+    int h = pool("pool", c1, 2, 0);
+    int in_planes = 64;
+    const int planes_[4] = {64, 128, 256, 512}, nblk[4] = {3, 4, 6, 3}, strd[4] = {1, 2, 2, 2};
+    int feats[4];
+    for (int li = 0; li < 4; ++li) {
+      for (int bi = 0; bi < nblk[li]; ++bi) {
+        const int stv = bi == 0 ? strd[li] : 1;
+        const int planes = planes_[li];
+        std::string p = "layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+        ConvOpt o1;
+        o1.bn = p + ".bn1";
+        o1.bias = false;
+        o1.act = ACT_RELU;
+        int a1 = conv(p + ".conv1", h, planes, CONV_1x1_S1, o1);
+        ConvOpt o2;
+        o2.bn = p + ".bn2";
+        o2.bias = false;
+        o2.act = ACT_RELU;
+        int a2 = conv(p + ".conv2", a1, planes, stv == 2 ? CONV_3x3_S2 : CONV_3x3_S1, o2);
+        int sc = h;
+        if (stv != 1 || in_planes != planes * 4) {
+          ConvOpt od;
+          od.bn = p + ".downsample.1";
+          od.bias = false;
+          sc = conv(p + ".downsample.0", h, planes * 4, stv == 2 ? CONV_1x1_S2 : CONV_1x1_S1, od);
+        }
+        ConvOpt o3;
+        o3.bn = p + ".bn3";
+        o3.bias = false;
+        o3.act = ACT_RELU;
+        o3.res_t = sc;
+        h = conv(p + ".conv3", a2, planes * 4, CONV_1x1_S1, o3);
+        if (rc != FDT_OK) return;
+        in_planes = planes * 4;
+      }
+      feats[li] = h;
+      m->tensors[h].name = "c" + std::to_string(li + 2);
+    }
+    const int c2 = feats[0], c3 = feats[1], c4 = feats[2], c5 = feats[3];
+    ConvOpt a;
+    a.act = ACT_RELU;
+    a.bn = "layer5.1";
+    int c6a = conv("layer5.0", c5, 512, CONV_1x1_S1, a);
+    a.bn = "layer5.4";
+    int c6 = conv("layer5.3", c6a, 512, CONV_3x3_S2, a);
+    a.bn = "layer6.1";
+    int c7a = conv("layer6.0", c6, 128, CONV_1x1_S1, a);
+    a.bn = "layer6.4";
+    int c7 = conv("layer6.3", c7a, 256, CONV_3x3_S2, a);
+    if (rc != FDT_OK) return;
+    m->tensors[c6].name = "c6";
+    m->tensors[c7].name = "c7";
+    ConvOpt lin;
+    int c5_lat = conv("latlayer_fc", c5, 2048, CONV_1x1_S1, lin);
+    int c6_lat = conv("latlayer_c6", c6, 512, CONV_1x1_S1, lin);
+    int c7_lat = conv("latlayer_c7", c7, 256, CONV_1x1_S1, lin);
+    int c4_f = ct("conv5_ct_py", c5_lat, c4, 1024);
+    int c3_f = ct("conv4_ct_py", c4_f, c3, 512);
+    int c2_f = ct("conv3_ct_py", c3_f, c2, 256);
+    if (rc != FDT_OK) return;
+    m->tensors[c4_f].name = "c4_ct";
+    m->tensors[c3_f].name = "c3_ct";
+    m->tensors[c2_f].name = "c2_ct";
+    int c2_s = conv("smooth_c3", c2_f, 256, CONV_3x3_S1, lin);
+    int c3_s = conv("smooth_c4", c3_f, 512, CONV_3x3_S1, lin);
+    int c4_s = conv("smooth_c5", c4_f, 1024, CONV_3x3_S1, lin);
+    if (rc != FDT_OK) return;
+    m->tensors[c2_s].name = "c2_smooth";
+    m->tensors[c3_s].name = "c3_smooth";
+    m->tensors[c4_s].name = "c4_smooth";
+    std::vector<int> src;
+    src.push_back(ssh("conv2_SSH", c2_s, 256));
+    src.push_back(ssh("conv3_SSH", c3_s, 256));
+    src.push_back(ssh("conv4_SSH", c4_s, 256));
+    src.push_back(ssh("conv5_SSH", c5_lat, 256));
+    src.push_back(ssh("conv6_SSH", c6_lat, 256));
+    src.push_back(ssh("conv7_SSH", c7_lat, 256));
+    if (rc != FDT_OK) return;
+    for (size_t i = 0; i < src.size(); ++i) m->tensors[src[i]].name = "src" + std::to_string(i);
+    heads(src);
+  }
+
+  // ---------------------------------------------------------------- try3   pyramid_mb2_try3.py:218-340
+  int inverted_residual(const std::string& p, int x, int inp, int oup, int stride, int t) {
+    int h = x;
+    int i = 0;
+    const int hid = (int)std::lround((double)inp * t);
+    if (t != 1) {
+      ConvOpt o;
+      o.bias = false;
+      o.bn = p + ".conv." + std::to_string(i + 1);
+      o.act = ACT_RELU6;
+      h = conv(p + ".conv." + std::to_string(i), h, hid, CONV_1x1_S1, o);
+      i += 3;
+    }
+    h = dwconv(p + ".conv." + std::to_string(i), p + ".conv." + std::to_string(i + 1), h, stride, ACT_RELU6);
+    i += 3;
+    ConvOpt o;
+    o.bias = false;
+    o.bn = p + ".conv." + std::to_string(i + 1);
+    if (stride == 1 && inp == oup) o.res_t = x;   // :131-134
+    return conv(p + ".conv." + std::to_string(i), h, oup, CONV_1x1_S1, o);
+  }
+
+  void build_try3(int H, int W) {
+    int x = new_tensor("input", 3, H, W);
+    ConvOpt st;
+    st.bn = "features.0.1";
+    st.bias = false;
+    st.act = ACT_RELU6;
+    int h = conv("features.0.0", x, 32, CONV_3x3_S2, st);
+    if (h < 0) return;
+    m->tensors[h].name = "stem";
+    const int cfgs[7][4] = {{1, 16, 1, 1}, {6, 24, 2, 2}, {6, 32, 3, 2}, {6, 64, 4, 2},
+                            {6, 96, 3, 1}, {6, 160, 3, 2}, {6, 320, 1, 1}};
+    int inp = 32, idx = 1;
+    std::map<int, int> taps;
+    for (auto& c : cfgs) {
+      for (int i = 0; i < c[2]; ++i) {
+        h = inverted_residual("features." + std::to_string(idx), h, inp, c[1], i == 0 ? c[3] : 1, c[0]);
+        if (rc != FDT_OK) return;
+        taps[idx] = h;
+        inp = c[1];
+        ++idx;
+      }
+    }
+    int c2 = taps[3], c3 = taps[6], c4 = taps[13], c5 = taps[17];   // :229-236
+    int c6 = inverted_residual("layer6", c5, 320, 160, 2, 6);       // :238
+    if (rc != FDT_OK) return;
+    m->tensors[c2].name = "c2";
+    m->tensors[c3].name = "c3";
+    m->tensors[c4].name = "c4";
+    m->tensors[c5].name = "c5";
+    m->tensors[c6].name = "c6";
+    ConvOpt lin;
+    c6 = conv("smooth_c6", c6, 160, CONV_3x3_S1, lin);   // :242-243
+    c5 = conv("smooth_c5", c5, 320, CONV_3x3_S1, lin);
+    c4 = ct("conv4_ct_py", c5, c4, 96);                  // :245-247
+    c3 = ct("conv3_ct_py", c4, c3, 32);
+    c2 = ct("conv2_ct_py", c3, c2, 24);
+    c2 = conv("smooth_c2", c2, 24, CONV_3x3_S1, lin);    // :249-251
+    c3 = conv("smooth_c3", c3, 32, CONV_3x3_S1, lin);
+    c4 = conv("smooth_c4", c4, 96, CONV_3x3_S1, lin);
+    if (rc != FDT_OK) return;
+    m->tensors[c2].name = "c2_smooth";
+    m->tensors[c3].name = "c3_smooth";
+    m->tensors[c4].name = "c4_smooth";
+    m->tensors[c5].name = "c5_smooth";
+    m->tensors[c6].name = "c6_smooth";
+    std::vector<int> src;
+    src.push_back(ssh("conv2_SSH", c2, 128));
+    src.push_back(ssh("conv3_SSH", c3, 128));
+    src.push_back(ssh("conv4_SSH", c4, 128));
+    src.push_back(ssh("conv5_SSH", c5, 128));
+    src.push_back(ssh("conv6_SSH", c6, 128));
+    if (rc != FDT_OK) return;
+    for (size_t i = 0; i < src.size(); ++i) m->tensors[src[i]].name = "src" + std::to_string(i);
+    heads(src);   // zip() truncates to the 5 sources (:288): face_*.5 are dead weights
+  }
+};
+
+bool ignored_key(const fdt_model* m, const std::string& k) {
+  auto ends_with = [&](const char* s) {
+    size_t n = strlen(s);
+    return k.size() >= n && k.compare(k.size() - n, n, s) == 0;
+  };
+  if (ends_with("num_batches_tracked")) return true;
+  if (m->arch == FDT_ARCH_RES50 || m->arch == FDT_ARCH_TRY3) {
+    if (k.rfind("head_loc.", 0) == 0 || k.rfind("head_conf.", 0) == 0) return true;   // pyramid.py:312-317
+    if (m->arch == FDT_ARCH_TRY3 && (k.rfind("face_loc.5.", 0) == 0 || k.rfind("face_conf.5.", 0) == 0))
+      return true;
+  }
+  return false;
+}
+
+int build_graph(fdt_model* m, int B, int H, int W) {
+  Builder bld{m, B};
+  m->flops_per_frame = 0;
+  if (m->arch == FDT_ARCH_RES50)
+    bld.build_res50(H, W);
+  else if (m->arch == FDT_ARCH_TRY3)
+    bld.build_try3(H, W);
+  else {
+    set_error("arch %d: forward graph not available in this build", m->arch);
+    return FDT_ERR_ARG;
+  }
+  return bld.rc;
+}
+
+// priors (net.priorbox(idx, f_w, f_h) per source, pyramid.py:275-283)
+int make_priors(fdt_model* m, int H, int W) {
+  const int nl = (int)m->levels.size();
+  std::vector<int> stride = m->pb_stride, box = m->pb_box;
+  int pw = m->pb_set ? m->pb_w : W, ph = m->pb_set ? m->pb_h : H;
+  if (!m->pb_set) {
+    // module default: PriorBoxLayer(size=640, size) (pyramid.py:113) -- callers override it with the
+    // frame size; a forward at another size with the default object keeps 640 like the reference.
+    pw = ph = 640;
+    stride.clear();
+    box.clear();
+    for (int i = 0; i < nl; ++i) {
+      stride.push_back(4 << i);
+      box.push_back(16 << i);
+    }
+  }
+  FDT_REQUIRE((int)stride.size() >= nl && (int)box.size() >= nl, FDT_ERR_STATE,
+              "priorbox has %d levels, the net has %d sources", (int)stride.size(), nl);
+  int off = 0;
+  for (int i = 0; i < nl; ++i) {
+    FDT_TRY(launch_priorbox(pw, ph, stride[i], box[i], 1, nullptr, 0, m->levels[i].second,
+                            m->levels[i].first, m->d_priors + (size_t)off * 4, m->stream));
+    off += m->levels[i].first * m->levels[i].second;
+  }
+  m->priors_dirty = false;
+  return FDT_OK;
+}
+
+// (Re)build the execution plan for a batch shape.
+int make_plan(fdt_model* m, int B, int H, int W) {
+  if (m->pB == B && m->pH == H && m->pW == W && !m->ops.empty()) {
+    if (m->priors_dirty) {
+      FDT_HIP(hipDeviceSynchronize());
+      FDT_TRY(make_priors(m, H, W));
+    }
+    return FDT_OK;
+  }
+  FDT_HIP(hipStreamSynchronize(m->stream));
+  m->free_plan();
+  m->dry = false;
+  int rc = build_graph(m, B, H, W);
+  if (rc != FDT_OK) {
+    m->free_plan();
+    return rc;
+  }
+  // detection levels -> prior offsets
+  int P = 0;
+  size_t li = 0;
+  for (auto& op : m->ops)
+    if (op.type == OP_HEADFIN) {
+      op.p_off = P;
+      P += m->levels[li].first * m->levels[li].second;
+      ++li;
+    }
+  m->P = P;
+  auto dalloc = [&](void** p, size_t bytes) -> int {
+    FDT_HIP(hipMalloc(p, bytes));
+    m->plan_allocs.push_back(*p);
+    return FDT_OK;
+  };
+  FDT_TRY(dalloc((void**)&m->d_loc, (size_t)B * P * 16));
+  FDT_TRY(dalloc((void**)&m->d_conf, (size_t)B * P * 8));
+  FDT_TRY(dalloc((void**)&m->d_logits, (size_t)B * P * 8));
+  FDT_TRY(dalloc((void**)&m->d_priors, (size_t)P * 16));
+  FDT_TRY(dalloc((void**)&m->d_out, (size_t)B * 2 * m->top_k * 5 * 4));
+  FDT_TRY(dalloc((void**)&m->d_counts, (size_t)B * 2 * 4));
+  FDT_TRY(dalloc((void**)&m->d_frames_u8, (size_t)B * H * W * 3));
+  m->dplan = make_detect_plan(B, P, m->nms_top_k);
+  FDT_TRY(dalloc(&m->d_ws, m->dplan.bytes));
+  FDT_TRY(make_priors(m, H, W));
+  m->pB = B;
+  m->pH = H;
+  m->pW = W;
+  // profiling events
+  for (auto e : m->ev) (void)hipEventDestroy(e);
+  m->ev.clear();
+  m->prof_ms.assign(m->ops.size() + 1, 0.f);
+  m->prof_runs = 0;
+  return FDT_OK;
+}
+
+int run_ops(fdt_model* m, int B, hipStream_t st) {
+  const bool prof = m->profile;
+  if (prof && m->ev.size() != m->ops.size() + 2) {
+    for (auto e : m->ev) (void)hipEventDestroy(e);
+    m->ev.resize(m->ops.size() + 2);
+    for (auto& e : m->ev) FDT_HIP(hipEventCreate(&e));
+  }
+  for (size_t i = 0; i < m->ops.size(); ++i) {
+    const Op& op = m->ops[i];
+    if (prof) FDT_HIP(hipEventRecord(m->ev[i], st));
+    switch (op.type) {
+      case OP_CONV:
+        FDT_TRY(launch_conv(op.kind, op.tile, op.ca, st));
+        break;
+      case OP_POOL: {
+        const Tensor& in = m->tensors[op.in_t];
+        const Tensor& out = m->tensors[op.out_t];
+        FDT_TRY(launch_maxpool3(in.d, B, in.C, in.H, in.W, op.stride, op.crelu, out.d, out.H, out.W, st));
+        break;
+      }
+      case OP_DW: {
+        const Tensor& in = m->tensors[op.in_t];
+        const Tensor& out = m->tensors[op.out_t];
+        FDT_TRY(launch_dwconv3(in.d, op.w, op.bias, B, in.C, in.H, in.W, op.stride, op.act, out.d, out.H,
+                               out.W, st));
+        break;
+      }
+      case OP_HEADFIN: {
+        const Tensor& in = m->tensors[op.in_t];
+        FDT_TRY(launch_head_finalize(in.d, B, in.H, in.W, op.level0, m->P, op.p_off, m->d_loc, m->d_conf,
+                                     m->d_logits, st));
+        break;
+      }
+      default:
+        break;
+    }
+  }
+  if (prof) FDT_HIP(hipEventRecord(m->ev[m->ops.size()], st));
+  return FDT_OK;
+}
+
+int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int format, int B, int H, int W,
+                 bool run_detect, float* out_dev, int* counts_dev, hipStream_t user_stream) {
+  FDT_REQUIRE(m && frames, FDT_ERR_ARG, "fdt_model_forward: null argument");
+  FDT_REQUIRE(m->finalized, FDT_ERR_STATE, "fdt_model_forward: call fdt_model_finalize first");
+  FDT_REQUIRE(B >= 1 && H >= 1 && W >= 1, FDT_ERR_ARG, "fdt_model_forward: bad shape");
+  FDT_REQUIRE(format == FDT_FRAME_U8_HWC_BGR || format == FDT_FRAME_F32_NCHW, FDT_ERR_ARG,
+              "fdt_model_forward: unknown frame format %d", format);
+  FDT_HIP(hipSetDevice(m->device));
+  const bool fresh = !(m->pB == B && m->pH == H && m->pW == W && !m->ops.empty()) || m->priors_dirty;
+  FDT_TRY(make_plan(m, B, H, W));
+  hipStream_t st = user_stream ? user_stream : m->stream;
+  if (fresh && st != m->stream) FDT_HIP(hipStreamSynchronize(m->stream));   // priors were built there
+  const hipMemcpyKind kind = frames_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  float* x = m->tensors[0].d;
+  if (format == FDT_FRAME_U8_HWC_BGR) {
+    const unsigned char* src = (const unsigned char*)frames;
+    if (!frames_on_device) {
+      FDT_HIP(hipMemcpyAsync(m->d_frames_u8, frames, (size_t)B * H * W * 3, kind, st));
+      src = m->d_frames_u8;
+    }
+    if (m->arch == FDT_ARCH_FACEBOX)
+      FDT_TRY(launch_preprocess(src, B, H, W, 0.f, 0.f, 0.f, 1.0f / 255.0f, x, st));
+    else
+      FDT_TRY(launch_preprocess(src, B, H, W, 104.f, 117.f, 123.f, 1.0f, x, st));
+  } else {
+    FDT_HIP(hipMemcpyAsync(x, frames, (size_t)B * 3 * H * W * 4, kind, st));
+  }
+  FDT_TRY(run_ops(m, B, st));
+  if (run_detect) {
+    FDT_TRY(launch_detect(m->dplan, m->d_ws, m->d_loc, m->d_conf, m->d_priors, 2, m->top_k, m->conf_t,
+                          m->nms_t, 0.1f, 0.2f, out_dev ? out_dev : m->d_out,
+                          counts_dev ? counts_dev : m->d_counts, st));
+    if (m->profile) FDT_HIP(hipEventRecord(m->ev[m->ops.size() + 1], st));
+  }
+  return FDT_OK;
+}
+
+}  // namespace
+
+// ================================================================================== C ABI
+extern "C" fdt_model* fdt_model_create(int arch, int device) {
+  if (arch != FDT_ARCH_RES50 && arch != FDT_ARCH_TRY3) {
+    set_error("fdt_model_create: unknown arch %d", arch);
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    set_error("fdt_model_create: hipSetDevice(%d) failed: %s", device, hipGetErrorString(hipGetLastError()));
+    return nullptr;
+  }
+  std::unique_ptr<fdt_model> m(new fdt_model());
+  m->arch = arch;
+  m->device = device;
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+    set_error("fdt_model_create: stream creation failed");
+    return nullptr;
+  }
+  if (arch == FDT_ARCH_TRY3) {   // pyramid_mb2_try3.py:216
+    m->conf_t = 0.2f;
+    m->nms_t = 0.35f;
+  }
+  // dry build: collect the state-dict keys the forward graph reads
+  m->dry = true;
+  int rc = build_graph(m.get(), 1, 256, 256);
+  m->dry = false;
+  m->tensors.clear();
+  m->ops.clear();
+  m->levels.clear();
+  if (rc != FDT_OK) return nullptr;
+  return m.release();
+}
+
+extern "C" void fdt_model_destroy(fdt_model* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  (void)hipDeviceSynchronize();
+  delete m;
+}
+
+extern "C" int fdt_model_set_tensor(fdt_model* m, const char* name, const float* data, int ndim,
+                                    const long long* dims) {
+  FDT_REQUIRE(m && name && ndim >= 0 && ndim <= 8, FDT_ERR_ARG, "fdt_model_set_tensor: bad argument");
+  std::string k(name);
+  if (ignored_key(m, k)) return FDT_OK;
+  FDT_REQUIRE(m->expected.count(k), FDT_ERR_NAME, "Unexpected key(s) in state_dict: \"%s\"", name);
+  FDT_REQUIRE(data, FDT_ERR_ARG, "fdt_model_set_tensor: null data for %s", name);
+  HostT t;
+  long long n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    FDT_REQUIRE(dims[i] >= 0, FDT_ERR_ARG, "fdt_model_set_tensor: negative dim");
+    t.dims.push_back(dims[i]);
+    n *= dims[i];
+  }
+  t.v.assign(data, data + n);
+  m->sd[k] = std::move(t);
+  m->finalized = false;
+  return FDT_OK;
+}
+
+extern "C" int fdt_model_missing(fdt_model* m, int* n) {
+  FDT_REQUIRE(m && n, FDT_ERR_ARG, "fdt_model_missing: bad argument");
+  int c = 0;
+  for (auto& k : m->expected)
+    if (!m->sd.count(k)) ++c;
+  *n = c;
+  return FDT_OK;
+}
+
+extern "C" int fdt_model_missing_name(fdt_model* m, int i, char* buf, int buflen) {
+  FDT_REQUIRE(m && buf && buflen > 0, FDT_ERR_ARG, "fdt_model_missing_name: bad argument");
+  int c = 0;
+  for (auto& k : m->expected)
+    if (!m->sd.count(k)) {
+      if (c == i) {
+        snprintf(buf, buflen, "%s", k.c_str());
+        return FDT_OK;
+      }
+      ++c;
+    }
+  set_error("fdt_model_missing_name: index %d out of range", i);
+  return FDT_ERR_ARG;
+}
+
+extern "C" int fdt_model_finalize(fdt_model* m) {
+  FDT_REQUIRE(m, FDT_ERR_ARG, "fdt_model_finalize: null handle");
+  for (auto& k : m->expected)
+    FDT_REQUIRE(m->sd.count(k), FDT_ERR_STATE, "Missing key(s) in state_dict: \"%s\"", k.c_str());
+  FDT_HIP(hipSetDevice(m->device));
+  // weights may have changed: drop cached device copies and the plan
+  FDT_HIP(hipStreamSynchronize(m->stream));
+  m->free_plan();
+  for (auto& kv : m->wcache) {
+    if (kv.second.w) (void)hipFree(kv.second.w);
+    if (kv.second.bias) (void)hipFree(kv.second.bias);
+  }
+  m->wcache.clear();
+  m->finalized = true;
+  return FDT_OK;
+}
+
+extern "C" int fdt_model_set_priorbox(fdt_model* m, int width, int height, int n_levels, const int* stride,
+                                      const int* box) {
+  FDT_REQUIRE(m && width > 0 && height > 0 && n_levels >= 1 && stride && box, FDT_ERR_ARG,
+              "fdt_model_set_priorbox: bad argument");
+  m->pb_set = true;
+  m->pb_w = width;
+  m->pb_h = height;
+  m->pb_stride.assign(stride, stride + n_levels);
+  m->pb_box.assign(box, box + n_levels);
+  m->priors_dirty = true;   // net.firstTime = True: priors are regenerated by the next forward
+  return FDT_OK;
+}
+
+extern "C" int fdt_model_set_detect(fdt_model* m, int top_k, float conf_thresh, float nms_thresh,
+                                    int nms_top_k) {
+  FDT_REQUIRE(m && top_k >= 1 && nms_top_k >= 1, FDT_ERR_ARG, "fdt_model_set_detect: bad argument");
+  FDT_REQUIRE(nms_thresh > 0.0f, FDT_ERR_ARG, "nms_threshold must be non negative.");
+  if (top_k != m->top_k || nms_top_k != m->nms_top_k) {
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    m->free_plan();
+  }
+  m->top_k = top_k;
+  m->nms_top_k = nms_top_k;
+  m->conf_t = conf_thresh;
+  m->nms_t = nms_thresh;
+  return FDT_OK;
+}
+
+extern "C" int fdt_model_forward(fdt_model* m, const void* frames, int format, int B, int H, int W,
+                                 float* out, int* counts) {
+  FDT_REQUIRE(out, FDT_ERR_ARG, "fdt_model_forward: null output");
+  FDT_TRY(forward_impl(m, frames, false, format, B, H, W, true, nullptr, nullptr, nullptr));
+  FDT_HIP(hipMemcpyAsync(out, m->d_out, (size_t)B * 2 * m->top_k * 5 * 4, hipMemcpyDeviceToHost, m->stream));
+  if (counts) FDT_HIP(hipMemcpyAsync(counts, m->d_counts, (size_t)B * 2 * 4, hipMemcpyDeviceToHost, m->stream));
+  FDT_HIP(hipStreamSynchronize(m->stream));
+  return FDT_OK;
+}
+
+extern "C" int fdt_model_forward_dev(fdt_model* m, const void* frames_dev, int format, int B, int H, int W,
+                                     float* out_dev, int* counts_dev, void* stream) {
+  FDT_REQUIRE(out_dev, FDT_ERR_ARG, "fdt_model_forward_dev: null output");
+  return forward_impl(m, frames_dev, true, format, B, H, W, true, out_dev, counts_dev, (hipStream_t)stream);
+}
+
+extern "C" int fdt_model_forward_raw(fdt_model* m, const void* frames, int format, int B, int H, int W,
+                                     float* loc, float* conf) {
+  FDT_REQUIRE(loc && conf, FDT_ERR_ARG, "fdt_model_forward_raw: null output");
+  FDT_TRY(forward_impl(m, frames, false, format, B, H, W, false, nullptr, nullptr, nullptr));
+  FDT_HIP(hipMemcpyAsync(loc, m->d_loc, (size_t)B * m->P * 16, hipMemcpyDeviceToHost, m->stream));
+  FDT_HIP(hipMemcpyAsync(conf, m->d_conf, (size_t)B * m->P * 8, hipMemcpyDeviceToHost, m->stream));
+  FDT_HIP(hipStreamSynchronize(m->stream));
+  return FDT_OK;
+}
+
+extern "C" int fdt_model_num_priors(fdt_model* m, int* P) {
+  FDT_REQUIRE(m && P, FDT_ERR_ARG, "fdt_model_num_priors: bad argument");
+  FDT_REQUIRE(m->pB > 0, FDT_ERR_STATE, "fdt_model_num_priors: no forward has run yet");
+  *P = m->P;
+  return FDT_OK;
+}
+
+extern "C" int fdt_model_get_tensor(fdt_model* m, const char* name, float* out, long long max_elems,
+                                    long long* dims4) {
+  FDT_REQUIRE(m && name, FDT_ERR_ARG, "fdt_model_get_tensor: bad argument");
+  FDT_REQUIRE(m->pB > 0, FDT_ERR_STATE, "fdt_model_get_tensor: no forward has run yet");
+  std::string k(name);
+  const float* src = nullptr;
+  long long d[4] = {m->pB, 0, 0, 0};
+  if (k == "loc") {
+    src = m->d_loc;
+    d[1] = m->P;
+    d[2] = 4;
+    d[3] = 1;
+  } else if (k == "conf") {
+    src = m->d_conf;
+    d[1] = m->P;
+    d[2] = 2;
+    d[3] = 1;
+  } else if (k == "conf_logits") {
+    src = m->d_logits;
+    d[1] = m->P;
+    d[2] = 2;
+    d[3] = 1;
+  } else if (k == "priors") {
+    src = m->d_priors;
+    d[0] = 1;
+    d[1] = m->P;
+    d[2] = 4;
+    d[3] = 1;
+  } else {
+    for (auto& t : m->tensors)
+      if (t.name == k) {
+        src = t.d;
+        d[1] = t.C;
+        d[2] = t.H;
+        d[3] = t.W;
+      }
+  }
+  FDT_REQUIRE(src, FDT_ERR_NAME, "fdt_model_get_tensor: no tensor named '%s'", name);
+  if (dims4)
+    for (int i = 0; i < 4; ++i) dims4[i] = d[i];
+  long long n = d[0] * d[1] * d[2] * d[3];
+  if (!out) return FDT_OK;
+  FDT_REQUIRE(max_elems >= n, FDT_ERR_ARG, "fdt_model_get_tensor: buffer too small (%lld < %lld)", max_elems, n);
+  FDT_HIP(hipStreamSynchronize(m->stream));
+  FDT_HIP(hipMemcpy(out, src, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return FDT_OK;
+}
+
+extern "C" int fdt_model_profile_enable(fdt_model* m, int on) {
+  FDT_REQUIRE(m, FDT_ERR_ARG, "fdt_model_profile_enable: null handle");
+  m->profile = on != 0;
+  std::fill(m->prof_ms.begin(), m->prof_ms.end(), 0.f);
+  m->prof_runs = 0;
+  return FDT_OK;
+}
+
+extern "C" int fdt_model_profile_read(fdt_model* m, int max, char* names, float* ms, double* flops, int* n) {
+  FDT_REQUIRE(m && n, FDT_ERR_ARG, "fdt_model_profile_read: bad argument");
+  FDT_REQUIRE(m->profile && m->ev.size() == m->ops.size() + 2, FDT_ERR_STATE,
+              "fdt_model_profile_read: profiling not enabled or no forward since enabling");
+  FDT_HIP(hipStreamSynchronize(m->stream));
+  int cnt = (int)m->ops.size() + 1;   // + the Detect stage
+  *n = cnt;
+  for (int i = 0; i < cnt && i < max; ++i) {
+    float t = 0.f;
+    hipError_t e = hipEventElapsedTime(&t, m->ev[i], m->ev[i + 1]);
+    if (e != hipSuccess) t = 0.f;
+    if (ms) ms[i] = t;
+    if (flops) flops[i] = i < (int)m->ops.size() ? m->ops[i].flops : 0.0;
+    if (names) {
+      std::string nm = i < (int)m->ops.size() ? m->ops[i].name : std::string("detect");
+      if (i < (int)m->ops.size() && m->ops[i].type == OP_CONV)
+        nm += "#k" + std::to_string((int)m->ops[i].kind) + "t" + std::to_string((int)m->ops[i].tile);
+      snprintf(names + (size_t)i * 48, 48, "%s", nm.c_str());
+    }
+  }
+  return FDT_OK;
+}
+
+extern "C" int fdt_model_flops(fdt_model* m, double* flops) {
+  FDT_REQUIRE(m && flops, FDT_ERR_ARG, "fdt_model_flops: bad argument");
+  FDT_REQUIRE(m->pB > 0, FDT_ERR_STATE, "fdt_model_flops: no forward has run yet");
+  *flops = m->flops_per_frame;
+  return FDT_OK;
+}

@@ -1,0 +1,34 @@
+// Small HBM-bound kernels around the convolutions: frame ingest, pooling, depthwise 3x3, head
+// finalisation (max-in-out + 2-way softmax + NHWC flatten).  Device pointers, async on `st`.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fdt {
+
+// u8 BGR HWC -> f32 NCHW, minus per-channel mean (iouTracke_cal.py:41-44) then * scale
+// (FaceBox: mean 0, scale 1/255: FACEBOX/My_test_facebox.py:14-15).
+int launch_preprocess(const unsigned char* frames, int B, int H, int W, float m0, float m1, float m2,
+                      float scale, float* out, hipStream_t st);
+
+// F.max_pool2d(x, 3, stride, 1)  (pyramid.py:230 stride 2; FACEBOX/networks.py:46 stride 1).
+// relu_in: apply ReLU to the input on the fly.  crelu: input has C channels, output 2C =
+// maxpool(relu(cat[x,-x])) (FACEBOX/networks.py:92-98).
+int launch_maxpool3(const float* in, int B, int C, int H, int W, int stride, int crelu, float* out,
+                    int Ho, int Wo, hipStream_t st);
+
+// depthwise 3x3, pad 1, stride 1|2, + bias (folded BN) + ReLU6 (pyramid_mb2_try3.py:89-91,112-114)
+int launch_dwconv3(const float* in, const float* w9, const float* bias, int B, int C, int H, int W,
+                   int stride, int act, float* out, int Ho, int Wo, hipStream_t st);
+
+// One detection level: raw head map [B][8][H][W] (ch 0-3 loc, 4-7 conf) -> loc [B][P][4] and
+// softmaxed conf [B][P][2] rows [p_off, p_off+H*W): max-in-out (pyramid.py:291-305), NHWC flatten
+// (:298,:306), nn.Softmax(dim=-1) (:332).
+int launch_head_finalize(const float* head, int B, int H, int W, int level0, int P, int p_off,
+                         float* loc, float* conf, float* logits, hipStream_t st);
+
+// FaceBox multibox level: loc map [B][A*4][H][W], conf map [B][A*2][H][W] -> rows of A anchors per
+// cell (FACEBOX/multibox_layer.py:34-48) + softmax.
+int launch_multibox_finalize(const float* locmap, const float* confmap, int B, int A, int H, int W,
+                             int P, int p_off, float* loc, float* conf, hipStream_t st);
+
+}  // namespace fdt

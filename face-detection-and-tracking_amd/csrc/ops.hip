@@ -1,0 +1,179 @@
+// HBM-bound helper kernels (see ops.h).  One thread per output element, lanes along the contiguous
+// W axis so every wave reads/writes whole 256-byte row segments of the NCHW maps.
+#include "common.h"
+#include "ops.h"
+
+namespace fdt {
+namespace {
+
+__global__ void preprocess_kernel(const unsigned char* __restrict__ in, int H, int W, float m0, float m1,
+                                  float m2, float scale, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const long long hw = (long long)H * W;
+  long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= hw) return;
+  const unsigned char* px = in + ((long long)b * hw + p) * 3;
+  float* o = out + (long long)b * 3 * hw + p;
+  // x.astype(f32) - mean (exact in f32), optional scale
+  float v0 = (float)px[0] - m0, v1 = (float)px[1] - m1, v2 = (float)px[2] - m2;
+  if (scale != 1.0f) { v0 *= scale; v1 *= scale; v2 *= scale; }
+  o[0] = v0;
+  o[hw] = v1;
+  o[2 * hw] = v2;
+}
+
+__global__ void maxpool3_kernel(const float* __restrict__ in, int C, int H, int W, int stride, int crelu,
+                                float* __restrict__ out, int Ho, int Wo) {
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+  const int oy = blockIdx.y;
+  const int Cout = crelu ? 2 * C : C;
+  const int bc = blockIdx.z;
+  const int b = bc / Cout, co = bc % Cout;
+  if (ox >= Wo) return;
+  const bool neg = crelu && co >= C;
+  const int ci = neg ? co - C : co;
+  const float* src = in + ((long long)b * C + ci) * H * W;
+  float m = -INFINITY;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    int y = oy * stride + dy;
+    if (y < 0 || y >= H) continue;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      int x = ox * stride + dx;
+      if (x < 0 || x >= W) continue;
+      float v = src[(long long)y * W + x];
+      if (crelu) v = fmaxf(neg ? -v : v, 0.0f);
+      m = fmaxf(m, v);
+    }
+  }
+  out[((long long)b * Cout + co) * Ho * Wo + (long long)oy * Wo + ox] = m;
+}
+
+__global__ void dwconv3_kernel(const float* __restrict__ in, const float* __restrict__ w9,
+                               const float* __restrict__ bias, int C, int H, int W, int stride, int act,
+                               float* __restrict__ out, int Ho, int Wo) {
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+  const int oy = blockIdx.y;
+  const int bc = blockIdx.z;
+  const int c = bc % C;
+  if (ox >= Wo) return;
+  const float* src = in + (long long)bc * H * W;
+  const float* k = w9 + c * 9;
+  float acc = 0.0f;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    int y = oy * stride - 1 + dy;
+    if (y < 0 || y >= H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      int x = ox * stride - 1 + dx;
+      if (x < 0 || x >= W) continue;
+      acc = fmaf(src[(long long)y * W + x], k[dy * 3 + dx], acc);
+    }
+  }
+  if (bias) acc += bias[c];
+  if (act == 1) acc = fmaxf(acc, 0.0f);
+  else if (act == 2) acc = fminf(fmaxf(acc, 0.0f), 6.0f);
+  out[(long long)bc * Ho * Wo + (long long)oy * Wo + ox] = acc;
+}
+
+__device__ __forceinline__ void softmax2(float a, float b, float& pa, float& pb) {
+  float m = fmaxf(a, b);
+  float ea = expf(a - m), eb = expf(b - m);
+  float s = ea + eb;
+  pa = ea / s;
+  pb = eb / s;
+}
+
+__global__ void head_finalize_kernel(const float* __restrict__ head, int HW, int level0, int P, int p_off,
+                                     float* __restrict__ loc, float* __restrict__ conf,
+                                     float* __restrict__ logits) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  const float* h = head + (long long)b * 8 * HW + p;
+  float4 l = make_float4(h[0], h[(long long)HW], h[2ll * HW], h[3ll * HW]);
+  float c0 = h[4ll * HW], c1 = h[5ll * HW], c2 = h[6ll * HW], c3 = h[7ll * HW];
+  float neg, pos;
+  if (level0) {   // (a,b,c,pos): neg = max(a,b,c)          pyramid.py:292-298
+    neg = fmaxf(fmaxf(c0, c1), c2);
+    pos = c3;
+  } else {        // (neg,a,b,c): pos = max(a,b,c)          pyramid.py:299-305
+    neg = c0;
+    pos = fmaxf(fmaxf(c1, c2), c3);
+  }
+  const long long row = (long long)b * P + p_off + p;
+  reinterpret_cast<float4*>(loc)[row] = l;
+  float pn, pp;
+  softmax2(neg, pos, pn, pp);
+  reinterpret_cast<float2*>(conf)[row] = make_float2(pn, pp);
+  if (logits) reinterpret_cast<float2*>(logits)[row] = make_float2(neg, pos);
+}
+
+__global__ void multibox_finalize_kernel(const float* __restrict__ locmap, const float* __restrict__ confmap,
+                                         int A, int HW, int P, int p_off, float* __restrict__ loc,
+                                         float* __restrict__ conf) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;   // cell * A + anchor
+  if (t >= HW * A) return;
+  const int cell = t / A, a = t % A;
+  const float* lm = locmap + (long long)b * A * 4 * HW + cell;
+  const float* cm = confmap + (long long)b * A * 2 * HW + cell;
+  float4 l = make_float4(lm[(long long)(a * 4 + 0) * HW], lm[(long long)(a * 4 + 1) * HW],
+                         lm[(long long)(a * 4 + 2) * HW], lm[(long long)(a * 4 + 3) * HW]);
+  float pn, pp;
+  softmax2(cm[(long long)(a * 2 + 0) * HW], cm[(long long)(a * 2 + 1) * HW], pn, pp);
+  const long long row = (long long)b * P + p_off + t;
+  reinterpret_cast<float4*>(loc)[row] = l;
+  reinterpret_cast<float2*>(conf)[row] = make_float2(pn, pp);
+}
+
+}  // namespace
+
+int launch_preprocess(const unsigned char* frames, int B, int H, int W, float m0, float m1, float m2,
+                      float scale, float* out, hipStream_t st) {
+  dim3 grid((unsigned)ceil_div_ll((long long)H * W, 256), B);
+  hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, st, frames, H, W, m0, m1, m2, scale, out);
+  FDT_LAUNCH_CHECK();
+  return FDT_OK;
+}
+
+int launch_maxpool3(const float* in, int B, int C, int H, int W, int stride, int crelu, float* out,
+                    int Ho, int Wo, hipStream_t st) {
+  const int Cout = crelu ? 2 * C : C;
+  FDT_REQUIRE((long long)B * Cout <= 65535 && Ho <= 65535, FDT_ERR_ARG, "maxpool: grid too large");
+  dim3 grid(ceil_div(Wo, 64), Ho, B * Cout);
+  hipLaunchKernelGGL(maxpool3_kernel, grid, dim3(64), 0, st, in, C, H, W, stride, crelu, out, Ho, Wo);
+  FDT_LAUNCH_CHECK();
+  return FDT_OK;
+}
+
+int launch_dwconv3(const float* in, const float* w9, const float* bias, int B, int C, int H, int W,
+                   int stride, int act, float* out, int Ho, int Wo, hipStream_t st) {
+  FDT_REQUIRE((long long)B * C <= 65535 && Ho <= 65535, FDT_ERR_ARG, "dwconv: grid too large");
+  dim3 grid(ceil_div(Wo, 64), Ho, B * C);
+  hipLaunchKernelGGL(dwconv3_kernel, grid, dim3(64), 0, st, in, w9, bias, C, H, W, stride, act, out, Ho, Wo);
+  FDT_LAUNCH_CHECK();
+  return FDT_OK;
+}
+
+int launch_head_finalize(const float* head, int B, int H, int W, int level0, int P, int p_off, float* loc,
+                         float* conf, float* logits, hipStream_t st) {
+  dim3 grid(ceil_div(H * W, 256), B);
+  hipLaunchKernelGGL(head_finalize_kernel, grid, dim3(256), 0, st, head, H * W, level0, P, p_off, loc, conf,
+                     logits);
+  FDT_LAUNCH_CHECK();
+  return FDT_OK;
+}
+
+int launch_multibox_finalize(const float* locmap, const float* confmap, int B, int A, int H, int W, int P,
+                             int p_off, float* loc, float* conf, hipStream_t st) {
+  dim3 grid(ceil_div(H * W * A, 256), B);
+  hipLaunchKernelGGL(multibox_finalize_kernel, grid, dim3(256), 0, st, locmap, confmap, A, H * W, P, p_off,
+                     loc, conf);
+  FDT_LAUNCH_CHECK();
+  return FDT_OK;
+}
+
+}  // namespace fdt

@@ -1,0 +1,161 @@
+/*
+ * fdt.h -- C ABI of libfdt_hip.so: the MI355X (gfx950) implementation of the per-frame
+ * face-detection-and-tracking hot path of limacv/Face-detection-and-tracking.
+ *
+ * The reference is pure Python/PyTorch and has no FFI of its own; these entry points are
+ * what a binding for each reference function on the path attaches to.
+ * Each declaration cites the reference interface it replaces (file:line under the
+ * reference root).  Plain pointers and sizes only: no torch / numpy types cross this
+ * boundary.  INTEGRATION.md shows the ctypes stubs the reference side would add.
+ *
+ * Conventions
+ *   - every function returns FDT_OK (0) or a negative FDT_ERR_* code; the message for the
+ *     calling thread's last failure is fdt_last_error().
+ *   - "host" entry points take host pointers, copy in/out and synchronise before returning.
+ *     "_dev" entry points take device pointers plus a hipStream_t (as void*; NULL = the
+ *     handle's own stream) and only enqueue work.
+ *   - caller owns every in/out buffer; the library owns weights and workspaces.
+ *   - a handle is not thread-safe; distinct handles may be used from distinct threads.
+ */
+#ifndef FDT_H_
+#define FDT_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDT_OK 0
+#define FDT_ERR_ARG (-1)    /* bad argument (the reference raises ValueError / returns None) */
+#define FDT_ERR_HIP (-2)    /* a HIP runtime call failed (no device, OOM, launch failure)   */
+#define FDT_ERR_STATE (-3)  /* call order: weights missing, model not finalized, ...       */
+#define FDT_ERR_NAME (-4)   /* unknown tensor name (strict load_state_dict)                */
+
+/* arch of fdt_model_create */
+#define FDT_ARCH_RES50 0    /* pyramid.py:367-374 build_sfd -> SFD(Bottleneck,[3,4,6,3])   */
+#define FDT_ARCH_TRY3 1     /* pyramid_mb2_try3.py:359-366 build_sfd_mobile               */
+#define FDT_ARCH_FACEBOX 2  /* FACEBOX/networks.py:60-116 FaceBox                          */
+
+/* frame formats of fdt_model_forward */
+#define FDT_FRAME_U8_HWC_BGR 0 /* raw video frame; mean (104,117,123) is subtracted on device:
+                                  iouTracke_cal.py:40-46 / My_test.py:23-29                  */
+#define FDT_FRAME_F32_NCHW 1   /* what the reference hands to net(x): already mean-subtracted */
+
+#define FDT_F32 0
+#define FDT_F64 1
+
+typedef struct fdt_model fdt_model;
+typedef struct fdt_tracker fdt_tracker;
+
+/* ------------------------------------------------------------------ library / device */
+const char* fdt_last_error(void);
+int fdt_version(void);
+int fdt_device_count(int* n);
+int fdt_device_name(int dev, char* buf, int buflen);
+int fdt_set_device(int dev);
+int fdt_device_synchronize(void);
+
+/* ------------------------------------------------------------------ SSD post-processing ops
+ * Stand-alone, no model handle: these are what `from layers import *` /
+ * `from layers.box_utils import decode, nms` resolve to.                                   */
+
+/* PriorBoxLayer.__call__(prior_idx, f_width, f_height)  layers/functions/prior_box.py:28-44.
+ * One level: for i<f_h, j<f_w, scale<n_scales: (cx,cy,w,h) then one more box per aspect
+ * ratio; computed in f64 and rounded once to f32 like torch.Tensor(list).
+ * out: [f_h*f_w*n_scales*(1+n_ar), 4] f32 host.                                             */
+int fdt_priorbox(int width, int height, int stride, int box, int n_scales,
+                 const double* aspect_ratios, int n_ar, int f_w, int f_h, float* out);
+
+/* decode(loc, priors, variances)  layers/box_utils.py:238-258.  [P,4],[P,4] -> [P,4] host.  */
+int fdt_decode(const float* loc, const float* priors, int P, float var0, float var1,
+               float* boxes);
+
+/* nms(boxes, scores, overlap, top_k)  layers/box_utils.py:275-340.
+ * keep: [n] int64 zero-padded (like the reference's `keep` tensor), *count = #kept.          */
+int fdt_nms(const float* boxes, const float* scores, int n, float overlap, int top_k,
+            long long* keep, int* count);
+
+/* Detect(num_classes,bkg,top_k,conf_thresh,nms_thresh)(loc,conf,priors)
+ * layers/functions/detection.py:15-84.  loc [B,P,4], conf [B,P,C] (already softmaxed),
+ * priors [P,4]; out [B,C,top_k,5] rows (score,x1,y1,x2,y2), zero padded; counts [B,C]
+ * (may be NULL).  nms_thresh <= 0 -> FDT_ERR_ARG (the reference raises ValueError, :28-29).  */
+int fdt_detect(const float* loc, const float* conf, const float* priors, int B, int P,
+               int num_classes, int top_k, float conf_thresh, float nms_thresh, int nms_top_k,
+               float var0, float var1, float* out, int* counts);
+int fdt_detect_dev(const float* loc, const float* conf, const float* priors, int B, int P,
+                   int num_classes, int top_k, float conf_thresh, float nms_thresh,
+                   int nms_top_k, float var0, float var1, float* out, int* counts,
+                   void* workspace, long long workspace_bytes, void* stream);
+long long fdt_detect_workspace_bytes(int B, int P, int nms_top_k);
+
+/* calculate_iou(box_a, box_b)  utils/calc_performance.py:54-74 (+ intersect :4-31).
+ * a [A,4], b [B,4] (x1,y1,x2,y2) -> out [A,B]; dtype FDT_F32 / FDT_F64 follows the input
+ * like numpy does (the tracker feeds f64).  0/0 -> NaN, no epsilon.                          */
+int fdt_pairwise_iou(const void* a, int A, const void* b, int B, int dtype, void* out);
+
+/* ------------------------------------------------------------------ IoU tracker
+ * The inline tracker of iouTracke_cal.py:113-156 (per frame) and :174-177 (finalise), as a
+ * device-resident state machine.  A track is {bboxes, max_score, start_frame}.               */
+fdt_tracker* fdt_tracker_create(double sigma_iou, double sigma_h, int t_min, int max_dets,
+                                int log_frames);
+void fdt_tracker_destroy(fdt_tracker* t);
+int fdt_tracker_reset(fdt_tracker* t);
+/* one frame of detections [n,5] f64 host rows (x1,y1,x2,y2,score) == `det0` at :124          */
+int fdt_tracker_step(fdt_tracker* t, const double* dets, int n);
+/* same, but reads the device-resident Detect output [C,top_k,5] of frame `image` directly and
+ * performs the host unpack of iouTracke_cal.py:53-84 on device (rows while score >= thr,
+ * boxes * (w,h,w,h) in f32, dummy row if none).  Asynchronous on `stream`.                   */
+int fdt_tracker_step_dev(fdt_tracker* t, const float* det_out, int num_classes, int top_k,
+                         int width, int height, float score_thresh, void* stream);
+/* iouTracke_cal.py:174-175, then copy the event log back.  After this the accessors work.    */
+int fdt_tracker_finish(fdt_tracker* t);
+int fdt_tracker_num_tracks(fdt_tracker* t, int* n);
+int fdt_tracker_track_info(fdt_tracker* t, int idx, int* n_boxes, double* max_score,
+                           int* start_frame);
+int fdt_tracker_track_boxes(fdt_tracker* t, int idx, double* boxes /* [n_boxes,4] */);
+
+/* ------------------------------------------------------------------ detector model
+ * build_sfd('test',640,2) / build_sfd_mobile('test',640,2) / FaceBox()                       */
+fdt_model* fdt_model_create(int arch, int device);
+void fdt_model_destroy(fdt_model* m);
+/* net.load_state_dict(d): one call per (key, tensor); unknown key -> FDT_ERR_NAME.
+ * data is f32 (num_batches_tracked may be passed with ndim 0 and is ignored).               */
+int fdt_model_set_tensor(fdt_model* m, const char* name, const float* data, int ndim,
+                         const long long* dims);
+/* number of state-dict keys still missing (strict load) and the i-th of them                 */
+int fdt_model_missing(fdt_model* m, int* n);
+int fdt_model_missing_name(fdt_model* m, int i, char* buf, int buflen);
+/* fold BN (eval, eps 1e-5), re-tile weights for the conv kernels, upload.                    */
+int fdt_model_finalize(fdt_model* m);
+/* net.priorbox = PriorBoxLayer(width,height,stride,box) + net.firstTime = True
+ * (iouTracke_cal.py:98,103; My_test.py:31-35).  n_levels strides/boxes.                      */
+int fdt_model_set_priorbox(fdt_model* m, int width, int height, int n_levels,
+                           const int* stride, const int* box);
+/* net.detect = Detect(2,0,top_k,conf_thresh,nms_thresh)  (My_test.py:36)                     */
+int fdt_model_set_detect(fdt_model* m, int top_k, float conf_thresh, float nms_thresh,
+                         int nms_top_k);
+/* y = net(x)  pyramid.py:218-351 (Res50), pyramid_mb2_try3.py:218-340 (try3).
+ * frames: B images in `format`; out: [B,2,top_k,5] f32; counts: [B,2] or NULL.               */
+int fdt_model_forward(fdt_model* m, const void* frames, int format, int B, int H, int W,
+                      float* out, int* counts);
+int fdt_model_forward_dev(fdt_model* m, const void* frames_dev, int format, int B, int H, int W,
+                          float* out_dev, int* counts_dev, void* stream);
+/* FaceBox.forward  FACEBOX/networks.py:87-116: returns raw loc [B,21824,4], conf [B,21824,2]  */
+int fdt_model_forward_raw(fdt_model* m, const void* frames, int format, int B, int H, int W,
+                          float* loc, float* conf);
+/* after a forward: number of priors, and a named activation of the last forward
+ * ("loc","conf","priors","c2".."c7","src0".."src5", ...) for stage-level parity tests.       */
+int fdt_model_num_priors(fdt_model* m, int* P);
+int fdt_model_get_tensor(fdt_model* m, const char* name, float* out, long long max_elems,
+                         long long* dims4);
+/* per-op timing of the next forwards (HIP events around every launch on the model stream).
+ * fdt_model_profile_read: fills up to max entries; returns count in *n.                      */
+int fdt_model_profile_enable(fdt_model* m, int on);
+int fdt_model_profile_read(fdt_model* m, int max, char* names /* max*48 */, float* ms,
+                           double* flops, int* n);
+/* algorithmic conv FLOPs (2*MAC, live convs only) of one frame at the last forward's size    */
+int fdt_model_flops(fdt_model* m, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDT_H_ */
