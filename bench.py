@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: detect + track on synthetic 1024x1024 frames (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (torch.distributed / RCCL when N > 1).  A *step* is one batch-1 frame per GPU:
+u8 frame (already resident in HBM) -> PyramidBox-Res50 forward -> decode + NMS + top-k on device ->
+(N > 1: one RCCL all-gather of the fixed-size detection records) -> sequential IoU-tracker
+association of the N frames, device resident.  Rank 0 prints ONE JSON line.
+
+`roofline`: dominant kernel = the f32-MFMA implicit-GEMM convolution.  achieved = algorithmic conv
+FLOPs per frame (2*MAC of the live convs, SURVEY.md 8(d): 755.751 GFLOP @1024x1024) divided by the
+summed conv-launch durations per frame, measured with HIP events around every launch on the stream
+the kernels run on (a profiled pass of the same frames right after the timed region).
+`cpu_baseline`: the CPU oracle (oracle/, PyTorch-CPU convs + numpy post-processing + tracker) timed on
+this host's cores on a bounded sample of the same frames; rank 0, N = 1 only.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--arch", default="res50", choices=["res50", "try3"])
+    ap.add_argument("--unique-frames", type=int, default=8)
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--profile-frames", type=int, default=4)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)"
+                             % (args.gpus, world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = importlib.import_module("face-detection-and-tracking_amd")
+    synth = importlib.import_module("face-detection-and-tracking_amd.synth")
+    layers = importlib.import_module("face-detection-and-tracking_amd.layers")
+    trk = importlib.import_module("face-detection-and-tracking_amd.tracker")
+    lib = pkg._lib
+
+    H = W = args.size
+    if args.arch == "res50":
+        net = importlib.import_module("face-detection-and-tracking_amd.pyramid").SFD(device=local_rank)
+        net.priorbox = layers.PriorBoxLayer(W, H)
+    else:
+        net = importlib.import_module("face-detection-and-tracking_amd.pyramid_mb2_try3").SFD_mobile(device=local_rank)
+        net.priorbox = layers.PriorBoxLayer(W, H, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256))
+    sd = synth.make_state_dict(args.arch, seed=0)
+    net.load_state_dict(sd)
+    net.cuda(); net.eval()
+    top_k = net.detect.top_k
+
+    # synthetic frames, resident in HBM before the timed region
+    frames_h = synth.make_frames(args.unique_frames, H, W, seed=1234 + rank)
+    frames_d = torch.from_numpy(frames_h).to(dev)
+    rec = 2 * top_k * 5
+    gathered = torch.zeros((world, rec), dtype=torch.float32, device=dev)
+    mine = gathered[rank] if world == 1 else torch.zeros(rec, dtype=torch.float32, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    tracker = trk.IouTracker(0.4, 0.6, 5, max_dets=2 * top_k, log_frames=64)
+    # a non-default torch stream: its handle goes through the C ABI, so torch.cuda.Event brackets and
+    # the RCCL collective are ordered with the library's launches
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = ctypes.c_void_p(tstream.cuda_stream)
+    assert stream.value, "need a real stream handle"
+    L = lib.lib()
+
+    # first call builds the plan (allocations, weight tiling/upload): outside the timed region
+    net._sync_attributes(H, W)
+
+    def step(i):
+        f = frames_d[i % args.unique_frames]
+        lib.check(L.fdt_model_forward_dev(net._h, ctypes.c_void_p(f.data_ptr()), lib.FRAME_U8_HWC_BGR, 1, H, W,
+                                          ctypes.c_void_p(mine.data_ptr()), ctypes.c_void_p(counts.data_ptr()),
+                                          stream))
+        if world > 1:
+            # the one exchange step of the path: fixed-size per-frame box lists, rank order == frame order
+            dist.all_gather_into_tensor(gathered.view(-1), mine)
+        for r in range(world):
+            tracker.step_dev(ctypes.c_void_p(gathered[r].data_ptr()), 2, top_k, W, H, 0.4, stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gpu_ms = e0.elapsed_time(e1)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_cand_last = int(counts.cpu()[1])
+    tracks = tracker.finish()
+
+    # ---- per-launch timing of the dominant kernel (HIP events on the same stream) ---------------
+    roof = None
+    if rank == 0:
+        net.profile(True)
+        conv_ms, other_ms, flops = [], [], 0.0
+        for i in range(args.profile_frames + 1):
+            lib.check(L.fdt_model_forward_dev(net._h, ctypes.c_void_p(frames_d[i % args.unique_frames].data_ptr()),
+                                              lib.FRAME_U8_HWC_BGR, 1, H, W, ctypes.c_void_p(mine.data_ptr()),
+                                              ctypes.c_void_p(counts.data_ptr()), stream))
+            torch.cuda.synchronize()
+            prof = net.profile_read()
+            if i == 0:
+                continue      # first profiled frame creates the events
+            conv_ms.append(sum(ms for nm, ms, fl in prof if "#k" in nm))
+            other_ms.append(sum(ms for nm, ms, fl in prof if "#k" not in nm))
+            flops = sum(fl for nm, ms, fl in prof if "#k" in nm)
+            n_conv = sum(1 for nm, ms, fl in prof if "#k" in nm)
+        net.profile(False)
+        cms = float(np.mean(conv_ms))
+        achieved = flops / (cms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "kernel": "conv_kernel (f32 MFMA implicit GEMM)", "launches_per_frame": n_conv,
+                "avg_launch_us": round(cms * 1e3 / n_conv, 2), "conv_ms_per_frame": round(cms, 3),
+                "other_ms_per_frame": round(float(np.mean(other_ms)), 3),
+                "algorithmic_gflop_per_frame": round(flops / 1e9, 3)}
+
+    # ---- CPU baseline: the oracle on this host's cores, bounded sample ---------------------------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        from oracle import postproc as opp
+        from oracle import pyramidbox as opb
+        ncores = torch.get_num_threads()
+        ref_trk = opp.IouTracker(0.4, 0.6, 5)
+        times = []
+        for i in range(args.cpu_frames):
+            t1 = time.perf_counter()
+            y = opb.detect_frame(sd, frames_h[i % args.unique_frames], args.arch)
+            with np.errstate(all="ignore"):
+                ref_trk.step(opp.unpack_detections(y, W, H, 0.4))
+            times.append(time.perf_counter() - t1)
+        per = float(np.mean(times[1:])) if len(times) > 1 else times[0]
+        cpu = {"value": round(1.0 / per, 4), "unit": "frames/s", "cores": ncores, "kind": "port",
+               "sample": "%d frames of the same %dx%d workload after 1 warm-up (oracle/: torch-CPU convs + numpy "
+                         "Detect + tracker), %.2f s/frame" % (max(len(times) - 1, 1), H, W, per)}
+
+    if rank == 0:
+        frames = args.steps * world
+        line = {
+            "metric": "frames/sec (detect+track) at %dx%d" % (H, W),
+            "value": round(frames / dt, 3),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "PyramidBox-%s %dx%d synthetic u8 frames, batch=1 per GPU, decode+NMS+IoU-tracker "
+                                   "on device" % ("Res50" if args.arch == "res50" else "MobileNetV2-try3", H, W),
+                       "frames_per_step": world, "parallelism": "frame-parallel x%d%s" % (
+                           world, ", RCCL all-gather of box lists" if world > 1 else ""),
+                       "weights": "seeded synthetic (seed 0)", "detections_last_frame": n_cand_last,
+                       "tracks": len(tracks), "gpu_ms_per_step_events": round(gpu_ms / args.steps, 4),
+                       "device": pkg.device_name(local_rank)},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,7 +51,12 @@ struct ConvArgs {
   int B, Cin, Hin, Win, Cout, Hout, Wout;
   int out_ctot, out_coff, res_ctot, res_coff, up_h, up_w;
   int act;
+  int ksplit;             // >= 1: split the input-channel reduction over this many workgroups
+  float* ws;              // split-K workspace, B*ksplit*Cout*Hout*Wout floats (ksplit > 1)
 };
+
+// Workspace floats a split-K launch needs.
+long long conv_ws_floats(const ConvArgs& a);
 
 // Re-tile OIHW weights for (kind, tile): [Cout_pad/BN][ceil(Cin/KC)][KC][taps][BN], zero padded.
 // `scale` (per output channel, may be null) is the folded BN factor.

@@ -44,6 +44,8 @@ template <int TH_, int TW_, int BN_, int WM_, int WN_>
 struct Tile {
   static constexpr int TH = TH_, TW = TW_, BM = TH_ * TW_, BN = BN_, WM = WM_, WN = WN_;
   static constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
+  // workgroups per CU we want resident (second __launch_bounds__ argument = waves per SIMD)
+  static constexpr int MIN_WAVES = (MI * NI >= 4) ? 3 : 4;
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(MI * WM * 32 == BM && NI * WN * 32 == BN, "tile/wave mismatch");
 };
@@ -54,18 +56,33 @@ struct Layout {
   static constexpr int PW = (T::TW - 1) * G::LS + (G::KW - 1) * G::D + 1;
   static constexpr int XPLANE = PH * PW;
   static constexpr int XSZ = G::KC * XPLANE;
-  static constexpr int XSZP = (XSZ + 3) / 4 * 4;
-  static constexpr int WSZ = G::KC * G::TAPS * T::BN;
-  static constexpr int STAGE = XSZP + WSZ;           // floats per LDS buffer
-  static constexpr int NX = (XSZ + 255) / 256;       // x elements staged per thread
-  static constexpr int NW4 = (WSZ / 4 + 255) / 256;  // float4 weights staged per thread
+  static constexpr int XSZP = (XSZ + 255) / 256 * 256;   // whole LDS-DMA wave-instructions (64 x 4 B)
+  static constexpr int WSZ = G::KC * G::TAPS * T::BN;     // floats per weight stage
+  static constexpr int WSZP = (WSZ + 1023) / 1024 * 1024; // whole LDS-DMA wave-instructions (64 x 16 B)
+  static constexpr int STAGE = XSZP + WSZP;              // floats per LDS buffer
+  static constexpr int NX = XSZP / 256;                  // dword LDS-DMA instructions per wave per stage
+  static constexpr int NW = WSZP / 1024;                 // dwordx4 LDS-DMA instructions per wave per stage
   static constexpr size_t LDS_BYTES = 2 * STAGE * sizeof(float);
-  static_assert(WSZ % 4 == 0, "weight stage must be float4-able");
   static_assert(G::KC % 2 == 0, "k-pairs are two input channels at one tap");
+  static_assert(NX <= 32, "okmask is 32 bits");
 };
 
+__device__ float g_zero_pad[4];   // source of every padded / out-of-image element (zero-initialised)
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// LDS-DMA: each lane's 4 / 16 bytes go global -> LDS without touching VGPRs.  The LDS address is the
+// wave-uniform `l` + lane * size; the global address is per lane.
+__device__ __forceinline__ void glds4(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 4, 0, 0);
+}
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
 template <class G, class T>
-__global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs a) {
   using L = Layout<G, T>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -80,17 +97,24 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
   const int oy0 = (tile_id / tiles_x) * T::TH;
   const int ox0 = (tile_id % tiles_x) * T::TW;
   const int n_tile = blockIdx.y;
-  const int b = blockIdx.z;
+  const int b = blockIdx.z / a.ksplit;
+  const int ks = blockIdx.z - b * a.ksplit;
 
   const int HWin = a.Hin * a.Win;
   const int HWout = a.Hout * a.Wout;
   const float* in_b = a.in + (long long)b * a.Cin * HWin;
   const int nstages = (a.Cin + G::KC - 1) / G::KC;
-  const float* w_t = a.w + (long long)n_tile * nstages * L::WSZ;
+  const float* w_t = a.w + (long long)n_tile * nstages * L::WSZP;
+  // this workgroup's share of the reduction (split-K over input-channel stages)
+  const int s_begin = (int)((long long)nstages * ks / a.ksplit);
+  const int s_end = (int)((long long)nstages * (ks + 1) / a.ksplit);
 
-  // ---- per-thread staging plan (invariant over the stages) -----------------------------------------
-  int goff[L::NX];   // offset inside the stage's channel block, or -1 if outside the image / patch
-  int gch[L::NX];    // channel inside the stage
+  // ---- per-lane staging plan (invariant over the stages) --------------------------------------------
+  // Element e = 256*k + tid of the [KC][PH][PW] patch is fetched by lane (tid & 63) of wave (tid >> 6)
+  // with its k-th LDS-DMA instruction.  Padding / out-of-image elements read g_zero_pad instead, so
+  // the loads are unconditional and nothing is predicated per lane.
+  int goff[L::NX];
+  unsigned okmask = 0;
 #pragma unroll
   for (int k = 0; k < L::NX; ++k) {
     int e = tid + 256 * k;
@@ -100,42 +124,25 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
     int gy = oy0 * G::S - G::PAD + yy * G::PS;
     int gx = ox0 * G::S - G::PAD + xx * G::PS;
     bool ok = (e < L::XSZ) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-    goff[k] = ok ? (c * HWin + gy * a.Win + gx) : -1;
-    gch[k] = c;
+    goff[k] = ok ? (c * HWin + gy * a.Win + gx) : 0;
+    if (ok) okmask |= (1u << k);
   }
 
-  float xr[L::NX];
-  float4 wr[L::NW4];
-
-  auto load_stage = [&](int s) {
-    const int c0 = s * G::KC;
-    const float* src = in_b + (long long)c0 * HWin;
-#pragma unroll
-    for (int k = 0; k < L::NX; ++k) {
-      bool ok = goff[k] >= 0 && (c0 + gch[k]) < a.Cin;
-      xr[k] = ok ? src[goff[k]] : 0.0f;
-    }
-    const float4* wsrc = reinterpret_cast<const float4*>(w_t + (long long)s * L::WSZ);
-#pragma unroll
-    for (int k = 0; k < L::NW4; ++k) {
-      int v = tid + 256 * k;
-      if (v < L::WSZ / 4) wr[k] = wsrc[v];
-    }
-  };
-  auto store_stage = [&](int buf) {
-    float* X = smem + buf * L::STAGE;
-    float4* W4 = reinterpret_cast<float4*>(X + L::XSZP);
-#pragma unroll
-    for (int k = 0; k < L::NX; ++k) {
-      int e = tid + 256 * k;
-      if (e < L::XSZ) X[e] = xr[k];
-    }
-#pragma unroll
-    for (int k = 0; k < L::NW4; ++k) {
-      int v = tid + 256 * k;
-      if (v < L::WSZ / 4) W4[v] = wr[k];
-    }
-  };
+#define FDT_STAGE(s_, buf_)                                                                 \
+  {                                                                                         \
+    const int c0_ = (s_) * G::KC;                                                           \
+    const float* src_ = in_b + (long long)c0_ * HWin;                                       \
+    const int crem_ = a.Cin - c0_;                                                          \
+    float* X_ = smem + (buf_) * L::STAGE + wave * 64;                                       \
+    _Pragma("unroll") for (int k = 0; k < L::NX; ++k) {                                     \
+      const int c_ = (tid + 256 * k) / L::XPLANE;                                           \
+      const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                  \
+      glds4(ok_ ? src_ + goff[k] : g_zero_pad, X_ + 256 * k);                               \
+    }                                                                                       \
+    const float* wsrc_ = w_t + (long long)(s_) * L::WSZP + tid * 4;                         \
+    float* W_ = smem + (buf_) * L::STAGE + L::XSZP + wave * 256;                            \
+    _Pragma("unroll") for (int k = 0; k < L::NW; ++k) glds16(wsrc_ + 1024 * k, W_ + 1024 * k); \
+  }
 
   // ---- per-lane LDS read offsets ------------------------------------------------------------------
   int xo[T::MI], wo[T::NI];
@@ -157,20 +164,18 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
 
-  load_stage(0);
-  store_stage(0);
-  __syncthreads();
+  if (s_begin < s_end) FDT_STAGE(s_begin, 0);
+  __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and publishes the stage
 
-  for (int s = 0; s < nstages; ++s) {
-    const bool more = (s + 1) < nstages;
-    if (more) load_stage(s + 1);
-    const float* S = smem + (s & 1) * L::STAGE;
+  for (int s = s_begin; s < s_end; ++s) {
+    const int cur = (s - s_begin) & 1;
+    // the other buffer was last read in the previous iteration, which ended with a barrier
+    if (s + 1 < s_end) FDT_STAGE(s + 1, cur ^ 1);
+    const float* S = smem + cur * L::STAGE;
 #pragma unroll
     for (int t = 0; t < G::TAPS; ++t) {
 #pragma unroll
       for (int cp = 0; cp < G::KC / 2; ++cp) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int kx = (2 * cp) * L::XPLANE + (t / G::KW) * G::D * L::PW + (t % G::KW) * G::D;
         const int kw = ((2 * cp) * G::TAPS + t) * T::BN;
         float av[T::NI], bv[T::MI];
@@ -185,57 +190,89 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvArgs a) {
             acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[i], acc[j][i], 0, 0, 0);
       }
     }
-    if (more) store_stage((s + 1) & 1);
-    __syncthreads();
+    __syncthreads();   // next stage landed (vmcnt(0)) and everyone is done reading `cur`
   }
+#undef FDT_STAGE
 
   // ---- epilogue -------------------------------------------------------------------------------------
+  const int co_base = n_tile * T::BN + wn * (T::NI * 32) + 4 * half;
+  if (a.ws) {
+    // raw partial sums -> workspace [b][ks][Cout][HWout]; splitk_reduce_kernel finishes the layer
+    float* ws = a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWout;
+#pragma unroll
+    for (int i = 0; i < T::MI; ++i) {
+      const int p = wm * (T::MI * 32) + i * 32 + l31;
+      const int oy = oy0 + p / T::TW, ox = ox0 + p % T::TW;
+      const bool pix_ok = oy < a.Hout && ox < a.Wout;
+      const int pix = oy * a.Wout + ox;
+#pragma unroll
+      for (int j = 0; j < T::NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_base + j * 32 + (r & 3) + 8 * (r >> 2);
+          if (pix_ok && co < a.Cout) ws[(long long)co * HWout + pix] = acc[j][i][r];
+        }
+    }
+    return;
+  }
   float* out_b = a.out + ((long long)b * a.out_ctot + a.out_coff) * HWout;
   const float* res_b = a.res ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWout : nullptr;
-  const float* up_b = a.up ? a.up + (long long)b * a.Cout * a.up_h * a.up_w : nullptr;
 #pragma unroll
   for (int i = 0; i < T::MI; ++i) {
     const int p = wm * (T::MI * 32) + i * 32 + l31;
     const int oy = oy0 + p / T::TW, ox = ox0 + p % T::TW;
     const bool pix_ok = oy < a.Hout && ox < a.Wout;
-    const int pix = oy * a.Wout + ox;
-    // bilinear x2, align_corners=False (F.interpolate, pyramid.py:65): src = 0.5*(dst+0.5)-0.5, >= 0
-    int y0 = 0, y1 = 0, x0 = 0, x1 = 0;
-    float ly = 0.f, lx = 0.f;
-    if (up_b) {
-      float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.0f);
-      float sx = fmaxf(0.5f * (ox + 0.5f) - 0.5f, 0.0f);
-      y0 = (int)sy;
-      x0 = (int)sx;
-      y0 = y0 < a.up_h - 1 ? y0 : a.up_h - 1;
-      x0 = x0 < a.up_w - 1 ? x0 : a.up_w - 1;
-      y1 = y0 + (y0 < a.up_h - 1 ? 1 : 0);
-      x1 = x0 + (x0 < a.up_w - 1 ? 1 : 0);
-      ly = sy - (float)y0;
-      lx = sx - (float)x0;
-    }
+    const int pix = pix_ok ? oy * a.Wout + ox : 0;
 #pragma unroll
     for (int j = 0; j < T::NI; ++j) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = n_tile * T::BN + wn * (T::NI * 32) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (pix_ok && co < a.Cout) {
-          float v = acc[j][i][r];
-          if (a.bias) v += a.bias[co];
-          if (up_b) {
-            const float* u = up_b + (long long)co * a.up_h * a.up_w;
-            float top = (1.0f - lx) * u[y0 * a.up_w + x0] + lx * u[y0 * a.up_w + x1];
-            float bot = (1.0f - lx) * u[y1 * a.up_w + x0] + lx * u[y1 * a.up_w + x1];
-            v += (1.0f - ly) * top + ly * bot;
-          }
-          if (res_b) v += res_b[(long long)co * HWout + pix];
-          if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
-          else if (a.act == ACT_RELU6) v = fminf(fmaxf(v, 0.0f), 6.0f);
-          out_b[(long long)co * HWout + pix] = v;
-        }
+        const int co = co_base + j * 32 + (r & 3) + 8 * (r >> 2);
+        const int coc = co < a.Cout ? co : a.Cout - 1;
+        float v = acc[j][i][r];
+        if (a.bias) v += a.bias[coc];
+        if (res_b) v += res_b[(long long)coc * HWout + pix];
+        if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
+        else if (a.act == ACT_RELU6) v = fminf(fmaxf(v, 0.0f), 6.0f);
+        if (pix_ok && co < a.Cout) out_b[(long long)co * HWout + pix] = v;
       }
     }
   }
+}
+
+// Second pass of a split-K layer: out = act(sum_ks partial + bias + upsample + residual).  Fixed
+// summation order -> bitwise reproducible (no float atomics).  One thread per 4 consecutive pixels.
+__global__ void splitk_reduce_kernel(const ConvArgs a) {
+  const int HWout = a.Hout * a.Wout;
+  const long long total = (long long)a.B * a.Cout * HWout;
+  long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x);
+  if (t >= total) return;
+  const int pix = (int)(t % HWout);
+  const int co = (int)((t / HWout) % a.Cout);
+  const int b = (int)(t / ((long long)HWout * a.Cout));
+  float v = 0.0f;
+  const float* ws = a.ws + ((long long)b * a.ksplit * a.Cout + co) * HWout + pix;
+  for (int k = 0; k < a.ksplit; ++k) v += ws[(long long)k * a.Cout * HWout];
+  if (a.bias) v += a.bias[co];
+  if (a.up) {
+    const int oy = pix / a.Wout, ox = pix % a.Wout;
+    float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.0f);
+    float sx = fmaxf(0.5f * (ox + 0.5f) - 0.5f, 0.0f);
+    int y0 = (int)sy, x0 = (int)sx;
+    y0 = y0 < a.up_h - 1 ? y0 : a.up_h - 1;
+    x0 = x0 < a.up_w - 1 ? x0 : a.up_w - 1;
+    const int y1 = y0 + (y0 < a.up_h - 1 ? 1 : 0);
+    const int x1 = x0 + (x0 < a.up_w - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float* u = a.up + ((long long)b * a.Cout + co) * a.up_h * a.up_w;
+    const float top = (1.0f - lx) * u[y0 * a.up_w + x0] + lx * u[y0 * a.up_w + x1];
+    const float bot = (1.0f - lx) * u[y1 * a.up_w + x0] + lx * u[y1 * a.up_w + x1];
+    v += (1.0f - ly) * top + ly * bot;
+  }
+  if (a.res) v += a.res[((long long)b * a.res_ctot + a.res_coff + co) * HWout + pix];
+  if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
+  else if (a.act == ACT_RELU6) v = fminf(fmaxf(v, 0.0f), 6.0f);
+  a.out[((long long)b * a.out_ctot + a.out_coff + co) * HWout + pix] = v;
 }
 
 // ---- kernel table ---------------------------------------------------------------------------------------
@@ -321,17 +358,22 @@ void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKin
   const int taps = g.kh * g.kw, BN = tile_bn(tile), KC = g.kc;
   const int n_tiles = (Cout + BN - 1) / BN;
   const int nstages = (Cin + KC - 1) / KC;
-  out.assign((size_t)n_tiles * nstages * KC * taps * BN, 0.0f);
+  const size_t wszp = ((size_t)KC * taps * BN + 1023) / 1024 * 1024;   // Layout::WSZP
+  out.assign((size_t)n_tiles * nstages * wszp, 0.0f);
   for (int co = 0; co < Cout; ++co) {
     const float sc = scale ? scale[co] : 1.0f;
     const int nt = co / BN, n = co % BN;
     for (int ci = 0; ci < Cin; ++ci) {
       const int s = ci / KC, c = ci % KC;
       const float* src = w + ((size_t)co * Cin + ci) * taps;
-      float* dst = out.data() + ((((size_t)nt * nstages + s) * KC + c) * taps) * BN + n;
+      float* dst = out.data() + ((size_t)nt * nstages + s) * wszp + ((size_t)c * taps) * BN + n;
       for (int t = 0; t < taps; ++t) dst[(size_t)t * BN] = src[t] * sc;
     }
   }
+}
+
+long long conv_ws_floats(const ConvArgs& a) {
+  return (a.ksplit > 1 || a.up) ? (long long)a.B * a.ksplit * a.Cout * a.Hout * a.Wout : 0;
 }
 
 double conv_flops(const ConvArgs& a, ConvKind kind) {
@@ -360,10 +402,22 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a, hipStream_t st)
                                 (int)ke.lds));
     table().attr_set[kind][tile] = true;
   }
+  const int nstages = ceil_div(a.Cin, g.kc);
+  FDT_REQUIRE(a.ksplit >= 1 && a.ksplit <= nstages, FDT_ERR_ARG,
+              "launch_conv: bad split-K %d (stages %d)", a.ksplit, nstages);
+  // split-K layers and layers with the fused upsample-add finish in splitk_reduce_kernel
+  FDT_REQUIRE(!(a.ksplit > 1 || a.up) || a.ws, FDT_ERR_ARG, "launch_conv: workspace required");
+  FDT_REQUIRE(!a.ws || a.ksplit > 1 || a.up, FDT_ERR_ARG, "launch_conv: unexpected workspace");
   const int tiles = ceil_div(a.Hout, tile_th(tile)) * ceil_div(a.Wout, tile_tw(tile));
-  dim3 grid(tiles, ceil_div(a.Cout, tile_bn(tile)), a.B);
+  dim3 grid(tiles, ceil_div(a.Cout, tile_bn(tile)), a.B * a.ksplit);
+  FDT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, FDT_ERR_ARG, "launch_conv: grid too large");
   hipLaunchKernelGGL(ke.fn, grid, dim3(256), ke.lds, st, a);
   FDT_LAUNCH_CHECK();
+  if (a.ws) {
+    const long long total = (long long)a.B * a.Cout * a.Hout * a.Wout;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div_ll(total, 256)), dim3(256), 0, st, a);
+    FDT_LAUNCH_CHECK();
+  }
   return FDT_OK;
 }
 

@@ -50,6 +50,7 @@ struct Op {
   const float* w = nullptr;
   const float* bias = nullptr;
   int level0 = 0, p_off = 0, anchors = 1;
+  bool needs_ws = false;
 };
 
 struct DevW {
@@ -88,6 +89,8 @@ struct fdt_model {
   DetectPlan dplan;
   unsigned char* d_frames_u8 = nullptr;
   double flops_per_frame = 0;
+  long long ws_floats = 0;   // split-K / fused-upsample workspace shared by all layers
+  float* d_convws = nullptr;
 
   // profiling
   bool profile = false;
@@ -114,6 +117,8 @@ struct fdt_model {
     d_counts = nullptr;
     d_ws = nullptr;
     d_frames_u8 = nullptr;
+    d_convws = nullptr;
+    ws_floats = 0;
     pB = pH = pW = 0;
   }
 };
@@ -182,25 +187,50 @@ struct Builder {
     }
   }
 
-  static ConvTile choose_tile(ConvKind kind, int Cout, int Ho, int Wo, int B) {
-    ConvTile best = TILE_128x128;
+  // Pick (tile, split-K) for one layer with a small analytic model of the kernel: every wave issues
+  // its MFMAs (64 cycles each) on its own SIMD; how well one SIMD stays busy depends on how many
+  // waves share it (latency hiding) and on the MFMAs a wave issues per LDS round trip.  Layers with
+  // few output tiles and a deep reduction (the 32x32 .. 8x8 maps with 512-2048 channels) are split
+  // along K so that >= 2-3 workgroups land on every CU; the partial sums are combined in a fixed
+  // order by splitk_reduce_kernel.
+  static void choose(ConvKind kind, int Cout, int Cin, int Ho, int Wo, int B, bool needs_ws,
+                     ConvTile& best_tile, int& best_split) {
+    const ConvGeom g = conv_geom(kind);
+    const int nstages = ceil_div(Cin, g.kc);
+    const double mfma_per_stage_tile = (double)g.kh * g.kw * (g.kc / 2);
     double best_cost = 1e300;
+    best_tile = TILE_128x128;
+    best_split = 1;
     for (int t = 0; t < CONV_TILE_COUNT; ++t) {
       if (!conv_supported(kind, (ConvTile)t)) continue;
       const int bm = tile_bm((ConvTile)t), bn = tile_bn((ConvTile)t);
+      const int mfma_per_wave = (bm / 32) * (bn / 32) / 4;   // 32x32 tiles per wave (4 waves)
+      const int resident = mfma_per_wave >= 4 ? 3 : 4;          // workgroups per CU (launch bounds)
+      const double tile_eff = mfma_per_wave >= 4 ? 1.0 : (mfma_per_wave == 2 ? 0.85 : 0.7);
       const long long tiles_m = (long long)ceil_div(Ho, tile_th((ConvTile)t)) * ceil_div(Wo, tile_tw((ConvTile)t));
-      const long long blocks = tiles_m * ceil_div(Cout, bn) * B;
-      // rounds over 256 CUs x 2 resident workgroups, times the work of one workgroup; small
-      // wave tiles pay ~15% for their lower MFMA:LDS-read ratio
-      const double rounds = std::ceil((double)blocks / 512.0);
-      double cost = rounds * bm * bn;
-      if (bm * bn <= 64 * 64) cost *= 1.15;
-      if (cost < best_cost - 1e-9) {
-        best_cost = cost;
-        best = (ConvTile)t;
+      const long long base_blocks = tiles_m * ceil_div(Cout, bn) * B;
+      for (int split = 1; split <= 64; split *= 2) {
+        if (split > 1 && (split > nstages / 2 || nstages < 8)) break;
+        const long long blocks = base_blocks * split;
+        const double per_cu = (double)blocks / 256.0;
+        const double share = std::min((double)resident, std::max(1.0, std::ceil(per_cu)));
+        const double occ_eff = share >= 4 ? 0.80 : (share >= 3 ? 0.72 : (share >= 2 ? 0.55 : 0.32));
+        const double rounds = std::max(1.0, std::ceil(per_cu));   // workgroups each CU runs in total
+        const double stage_cycles = mfma_per_stage_tile * mfma_per_wave * 64.0;
+        const double block_cycles = 4000.0 + std::ceil((double)nstages / split) * stage_cycles;
+        double cycles = rounds * block_cycles / (occ_eff * tile_eff);
+        if (split > 1 || needs_ws) {
+          // reduce pass: read split partials + write, ~3 TB/s effective, plus a launch
+          const double bytes = (double)B * Cout * Ho * Wo * 4.0 * (split + 1);
+          cycles += 2.0e9 * (bytes / 3.0e12) + 6000.0;
+        }
+        if (cycles < best_cost) {
+          best_cost = cycles;
+          best_tile = (ConvTile)t;
+          best_split = split;
+        }
       }
     }
-    return best;
   }
 
   // Upload (cached) tiled weights + bias for a conv given concatenated OIHW weights.
@@ -260,9 +290,11 @@ struct Builder {
     op.type = OP_CONV;
     op.name = name;
     op.kind = kind;
-    op.tile = choose_tile(kind, Ctot, Ho, Wo, B);
+    int ksplit = 1;
+    choose(kind, Ctot, in.C, Ho, Wo, B, o.up_t >= 0, op.tile, ksplit);
     ConvArgs& a = op.ca;
     memset(&a, 0, sizeof(a));
+    a.ksplit = ksplit;
     a.B = B;
     a.Cin = in.C;
     a.Hin = in.H;
@@ -275,6 +307,12 @@ struct Builder {
     a.act = o.act;
     op.flops = conv_flops(a, kind);
     op.out_t = out_t;
+    op.needs_ws = ksplit > 1 || o.up_t >= 0;
+    if (op.needs_ws) {
+      ConvArgs tmp = a;
+      tmp.up = (const float*)1;
+      m->ws_floats = std::max(m->ws_floats, conv_ws_floats(tmp));
+    }
     if (!m->dry) {
       if (rc != FDT_OK) return -1;
       const size_t per = (size_t)in.C * g.kh * g.kw;
@@ -719,6 +757,11 @@ int make_plan(fdt_model* m, int B, int H, int W) {
   FDT_TRY(dalloc((void**)&m->d_frames_u8, (size_t)B * H * W * 3));
   m->dplan = make_detect_plan(B, P, m->nms_top_k);
   FDT_TRY(dalloc(&m->d_ws, m->dplan.bytes));
+  if (m->ws_floats) {
+    FDT_TRY(dalloc((void**)&m->d_convws, (size_t)m->ws_floats * 4));
+    for (auto& op : m->ops)
+      if (op.type == OP_CONV && op.needs_ws) op.ca.ws = m->d_convws;
+  }
   FDT_TRY(make_priors(m, H, W));
   m->pB = B;
   m->pH = H;
@@ -1044,7 +1087,8 @@ extern "C" int fdt_model_profile_read(fdt_model* m, int max, char* names, float*
     if (names) {
       std::string nm = i < (int)m->ops.size() ? m->ops[i].name : std::string("detect");
       if (i < (int)m->ops.size() && m->ops[i].type == OP_CONV)
-        nm += "#k" + std::to_string((int)m->ops[i].kind) + "t" + std::to_string((int)m->ops[i].tile);
+        nm += "#k" + std::to_string((int)m->ops[i].kind) + "t" + std::to_string((int)m->ops[i].tile) + "s" +
+              std::to_string(m->ops[i].ca.ksplit);
       snprintf(names + (size_t)i * 48, 48, "%s", nm.c_str());
     }
   }

@@ -45,13 +45,20 @@ def rel_rms(a, b):
 
 
 def match_detections(got, exp, n_exp):
-    """Same count, same order; per-box IoU deficit and score delta."""
+    """Same count; every reference box has a GPU box within the IoU / score tolerance.  Matching is by
+    best IoU, not by row: two detections whose scores differ by less than the f32 accumulation noise
+    (~3e-6) may legitimately swap places in the score-ordered output."""
     n_got = int((got[:, 0] > 0).sum())
     assert n_got == n_exp, (n_got, n_exp)
     if n_exp == 0:
         return 0.0, 0.0
-    iou = np.array([opp.calculate_iou(got[i:i + 1, 1:], exp[i:i + 1, 1:])[0, 0] for i in range(n_exp)])
-    return float((1 - iou).max()), float(np.abs(got[:n_exp, 0] - exp[:n_exp, 0]).max())
+    iou = opp.calculate_iou(exp[:n_exp, 1:].astype(np.float64), got[:n_exp, 1:].astype(np.float64))
+    j = iou.argmax(1)
+    assert len(set(j.tolist())) == n_exp, "two reference boxes matched the same detection"
+    d_sc = np.abs(got[j, 0] - exp[:n_exp, 0]).max()
+    # rows may only move among (near-)equal scores
+    assert np.abs(got[:n_exp, 0] - exp[:n_exp, 0]).max() <= SCORE_ATOL
+    return float((1 - iou[np.arange(n_exp), j]).max()), float(d_sc)
 
 
 RES50_STAGES = ["stem", "pool", "c2", "c3", "c4", "c5", "c6", "c7", "c4_ct", "c3_ct", "c2_ct",
@@ -107,7 +114,12 @@ def test_res50_batch2_equals_two_singles(res50, synth):
     res50.detect = M("layers").Detect(2, 0, 750, 0.05, 0.35)
     yb = res50(frames).numpy()
     y0 = res50(frames[0]).numpy(); y1 = res50(frames[1]).numpy()
-    assert np.array_equal(yb[0], y0[0]) and np.array_equal(yb[1], y1[0])
+    # the (tile, split-K) plan depends on the batch size, so sums are re-associated: tolerance, not bits
+    for got, exp in ((yb[0, 1], y0[0, 1]), (yb[1, 1], y1[0, 1])):
+        n = int((exp[:, 0] > 0).sum())
+        assert n > 5
+        d_iou, d_sc = match_detections(got, exp, n)
+        assert d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
 
 
 def test_load_state_dict_strictness(res50_sd):

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Per-launch timing table of one forward (HIP events around every op, fdt_model_profile_*).
+    python tools/profile_layers.py [--arch res50] [--size 1024] [--batch 1] [--top 40]
+"""
+import argparse
+import importlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+KIND = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2"]
+TILE = ["128x128", "128x64", "128x32", "64x64", "64x128"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--arch", default="res50")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--top", type=int, default=200)
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    synth = importlib.import_module("face-detection-and-tracking_amd.synth")
+    layers = importlib.import_module("face-detection-and-tracking_amd.layers")
+    if a.arch == "res50":
+        net = importlib.import_module("face-detection-and-tracking_amd.pyramid").SFD()
+        net.priorbox = layers.PriorBoxLayer(a.size, a.size)
+    else:
+        net = importlib.import_module("face-detection-and-tracking_amd.pyramid_mb2_try3").SFD_mobile()
+        net.priorbox = layers.PriorBoxLayer(a.size, a.size, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256))
+    net.load_state_dict(synth.make_state_dict(a.arch, 0))
+    frames = synth.make_frames(a.batch, a.size, a.size, seed=1234)
+    net(frames)
+    net.profile(True)
+    acc = None
+    for r in range(a.reps + 1):
+        net(frames)
+        p = net.profile_read()
+        if r == 0:
+            continue
+        ms = np.array([x[1] for x in p])
+        acc = ms if acc is None else acc + ms
+    acc /= a.reps
+    rows = []
+    for (nm, _, fl), ms in zip(p, acc):
+        kt = ""
+        if "#k" in nm:
+            base, code = nm.split("#k")
+            k, t = code.split("t")
+            t, sp = t.split("s")
+            kt = "%s %s /%s" % (KIND[int(k)], TILE[int(t)], sp)
+            nm = base
+        rows.append((ms, nm, kt, fl))
+    tot = sum(r[0] for r in rows)
+    conv = sum(r[0] for r in rows if r[2])
+    fl = sum(r[3] for r in rows if r[2])
+    print("total %.3f ms  conv %.3f ms  %.1f GFLOP  conv %.1f TFLOP/s" % (tot, conv, fl / 1e9, fl / conv / 1e9))
+    print("%-28s %-20s %9s %9s %7s" % ("op", "kernel", "ms", "GFLOP", "TF/s"))
+    for ms, nm, kt, f in sorted(rows, reverse=True)[:a.top]:
+        print("%-28s %-20s %9.3f %9.2f %7.1f" % (nm, kt, ms, f / 1e9, f / ms / 1e9 if ms > 0 else 0))
+    # aggregate by kernel class
+    agg = {}
+    for ms, nm, kt, f in rows:
+        k = kt or nm
+        a_ = agg.setdefault(k, [0.0, 0.0, 0])
+        a_[0] += ms; a_[1] += f; a_[2] += 1
+    print("\nby kernel class:")
+    for k, (ms, f, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        print("%-22s n=%3d %9.3f ms %9.2f GFLOP %7.1f TF/s" % (k, n, ms, f / 1e9, f / ms / 1e9 if ms > 0 else 0))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Stage-by-stage relative RMS error of the HIP forward against the CPU oracle at any size.
+    python tools/stage_diff.py [--arch res50] [--size 1024]"""
+import argparse, importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pyramidbox as opb
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--arch", default="res50"); ap.add_argument("--size", type=int, default=1024)
+ap.add_argument("--height", type=int, default=0)
+a = ap.parse_args()
+W = a.size; H = a.height or a.size
+synth = importlib.import_module("face-detection-and-tracking_amd.synth")
+layers = importlib.import_module("face-detection-and-tracking_amd.layers")
+sd = synth.make_state_dict(a.arch, 0)
+if a.arch == "res50":
+    net = importlib.import_module("face-detection-and-tracking_amd.pyramid").SFD()
+    net.priorbox = layers.PriorBoxLayer(W, H)
+    stages = ["stem", "pool", "c2", "c3", "c4", "c5", "c6", "c7", "c4_ct", "c3_ct", "c2_ct", "c2_smooth", "c3_smooth",
+              "c4_smooth", "src0", "src1", "src2", "src3", "src4", "src5"]
+    fwd = opb.res50_forward
+else:
+    net = importlib.import_module("face-detection-and-tracking_amd.pyramid_mb2_try3").SFD_mobile()
+    net.priorbox = layers.PriorBoxLayer(W, H, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256))
+    stages = ["stem", "c2", "c3", "c4", "c5", "c6", "c2_smooth", "c3_smooth", "c4_smooth", "c5_smooth", "c6_smooth",
+              "src0", "src1", "src2", "src3", "src4"]
+    fwd = opb.try3_forward
+net.load_state_dict(sd)
+frame = synth.make_frames(1, H, W, seed=1234)[0]
+x = opb.preprocess(frame)
+net(x)
+o = fwd(sd, x, want=stages)
+for st in stages + ["loc", "conf"]:
+    g = net.get_tensor(st); e = o[st]
+    d = g.astype(np.float64) - e
+    rr = np.sqrt((d ** 2).mean()) / (np.sqrt((e.astype(np.float64) ** 2).mean()) + 1e-30)
+    bad = np.argwhere(np.abs(d) > 1e-2 * (np.abs(e).max() + 1e-9))
+    print("%-10s %-22s rel_rms %.3e  max|d| %.3e  nbad %d %s" % (st, g.shape, rr, np.abs(d).max(), len(bad),
+                                                            bad[:3].tolist() if len(bad) else ""))
