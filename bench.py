@@ -66,6 +66,7 @@ def main():
     synth = importlib.import_module("face-detection-and-tracking_amd.synth")
     layers = importlib.import_module("face-detection-and-tracking_amd.layers")
     trk = importlib.import_module("face-detection-and-tracking_amd.tracker")
+    par = importlib.import_module("face-detection-and-tracking_amd.parallel")
     lib = pkg._lib
 
     H = W = args.size
@@ -83,9 +84,8 @@ def main():
     # synthetic frames, resident in HBM before the timed region
     frames_h = synth.make_frames(args.unique_frames, H, W, seed=1234 + rank)
     frames_d = torch.from_numpy(frames_h).to(dev)
-    rec = 2 * top_k * 5
-    gathered = torch.zeros((world, rec), dtype=torch.float32, device=dev)
-    mine = gathered[rank] if world == 1 else torch.zeros(rec, dtype=torch.float32, device=dev)
+    fp = par.FrameParallel(rank, world, 2 * top_k * 5, dev)
+    gathered, mine = fp.gathered, fp.mine
     counts = torch.zeros(2, dtype=torch.int32, device=dev)
     tracker = trk.IouTracker(0.4, 0.6, 5, max_dets=2 * top_k, log_frames=64)
     # a non-default torch stream: its handle goes through the C ABI, so torch.cuda.Event brackets and
@@ -104,9 +104,8 @@ def main():
         lib.check(L.fdt_model_forward_dev(net._h, ctypes.c_void_p(f.data_ptr()), lib.FRAME_U8_HWC_BGR, 1, H, W,
                                           ctypes.c_void_p(mine.data_ptr()), ctypes.c_void_p(counts.data_ptr()),
                                           stream))
-        if world > 1:
-            # the one exchange step of the path: fixed-size per-frame box lists, rank order == frame order
-            dist.all_gather_into_tensor(gathered.view(-1), mine)
+        # the one exchange step of the path: fixed-size per-frame box lists, rank order == frame order
+        fp.exchange()
         for r in range(world):
             tracker.step_dev(ctypes.c_void_p(gathered[r].data_ptr()), 2, top_k, W, H, 0.4, stream)
 

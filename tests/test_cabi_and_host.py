@@ -1,0 +1,108 @@
+"""CPU-only checks of the boundary: the C-ABI library loads, exports every symbol include/fdt.h
+declares, validates arguments before touching the GPU, and fails loudly without one.  No compute."""
+import ctypes
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "fdt.h")
+
+
+def M(name):
+    return importlib.import_module("face-detection-and-tracking_amd." + name)
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fdt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = M("_lib")
+    L = lib.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(L, s), "include/fdt.h declares %s but libfdt_hip.so does not export it" % s
+    assert set(syms) == set(lib.SIGNATURES), set(syms) ^ set(lib.SIGNATURES)
+    assert L.fdt_version() >= 100
+
+
+def test_header_cites_reference_lines():
+    src = open(HEADER).read()
+    for ref in ("prior_box.py:28-44", "box_utils.py:238-258", "box_utils.py:275-340", "detection.py:15-84",
+                "calc_performance.py:54-74", "iouTracke_cal.py:113-156", "pyramid.py:218-351"):
+        assert ref in src, ref
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    lib = M("_lib")
+    L = lib.lib()
+    z = np.zeros((1, 4, 4), np.float32)
+    out = np.zeros((1, 2, 750, 5), np.float32)
+    rc = L.fdt_detect(lib.ptr(z), lib.ptr(np.zeros((1, 4, 2), np.float32)), lib.ptr(z[0]), 1, 4, 2, 750,
+                      0.3, 0.0, 5000, 0.1, 0.2, lib.ptr(out), None)
+    assert rc == lib.FDT_ERR_ARG
+    assert b"nms_threshold must be non negative" in L.fdt_last_error()
+    assert L.fdt_detect_workspace_bytes(1, 87360, 5000) > 4 * 1024 * 1024
+    assert L.fdt_pairwise_iou(None, 3, None, 3, 7, None) == lib.FDT_ERR_ARG
+    cnt = ctypes.c_int(-1)
+    assert L.fdt_nms(None, None, 0, 0.5, 10, lib.ptr(np.zeros(1, np.int64)), ctypes.byref(cnt)) == 0
+    assert cnt.value == 0            # empty input: reference box_utils.py:290-291 returns (keep, 0)
+
+
+def test_fails_loudly_without_gpu_or_library(monkeypatch):
+    import torch
+    lib = M("_lib")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(lib.FdtError):
+        M("pyramid").build_sfd('test', 640, 2)
+    with pytest.raises(lib.FdtError):
+        M("layers").PriorBoxLayer(640, 640)(0, 4, 4)
+    with pytest.raises(lib.FdtError):
+        M("tracker").IouTracker()
+    # a missing shared object is an error, never a CPU fallback
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libfdt_hip.so")
+    with pytest.raises(lib.FdtError, match="no CPU fallback"):
+        lib.lib()
+
+
+def test_product_does_not_import_the_oracle():
+    pkg_dir = os.path.join(ROOT, "face-detection-and-tracking_amd")
+    for dp, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(dp, f)
+
+
+def test_reference_api_surface():
+    assert M("pyramid").build_sfd('bogus', 640, 2) is None            # pyramid.py:368-370
+    assert M("pyramid").build_sfd('test', 300, 2) is None             # pyramid.py:371-373
+    assert M("pyramid_mb2_try3").build_sfd_mobile('test', 300, 2) is None
+    with pytest.raises(ValueError):
+        M("layers").Detect(2, 0, 750, 0.3, 0)                         # detection.py:28-29
+    d = M("layers").Detect(2, 0, 750, 0.05, 0.3)
+    assert (d.top_k, d.nms_top_k, d.variance) == (750, 5000, [0.1, 0.2])
+    pb = M("layers").PriorBoxLayer(640, 480)
+    assert (pb.width, pb.height, tuple(pb.stride)) == (640, 480, (4, 8, 16, 32, 64, 128))
+
+
+def test_synthetic_schema_counts(synth):
+    r = synth.res50_schema()
+    assert len(r) == 474
+    n_params = sum(int(np.prod(s)) for _, s, k in r if k != "bn_nbt" and "running" not in _)
+    assert n_params == 67269390
+    t = synth.try3_schema()
+    assert len([1 for _, _, k in t if k != "bn_nbt"]) == 386
+    a = synth.make_state_dict("try3", 3)["features.5.conv.3.weight"]
+    b = synth.make_state_dict("try3", 3)["features.5.conv.3.weight"]
+    assert np.array_equal(a, b) and a.shape == (192, 1, 3, 3)
