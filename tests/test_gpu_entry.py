@@ -1,0 +1,60 @@
+"""GPU test of the iouTracke_cal-compatible entry point: detect_face unpack, device-resident vs
+host-stepped association, track-ID/boxes bit-exact vs the oracle tracker given identical boxes, and
+the .npy track file the reference's display script reads."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import postproc as opp
+
+pytestmark = pytest.mark.gpu
+
+
+def M(name):
+    return importlib.import_module("face-detection-and-tracking_amd." + name)
+
+
+@pytest.fixture(scope="module")
+def entry(synth):
+    cal = M("iouTracke_cal")
+    sd = synth.make_state_dict("res50", seed=0, conf_shift=-3.0)    # plenty of scores >= 0.4
+    cal.load_net(sd, 160, 128, which='repo')
+    cal.net.detect = M("layers").Detect(2, 0, 750, 0.3, 0.5)
+    yield cal
+    cal.net.close()
+
+
+def frames_sequence(synth):
+    base = synth.make_frames(3, 128, 160, seed=77)
+    return [base[i // 7] for i in range(21)]        # each frame shown 7 times: tracks persist
+
+
+def test_detect_face_matches_oracle_unpack(entry, synth):
+    fr = frames_sequence(synth)[0]
+    det = entry.detect_face(fr, 1)
+    y = entry.net(fr).numpy()
+    exp = opp.unpack_detections(y, 160, 128, 0.4)
+    assert det.dtype == exp.dtype and np.array_equal(det, exp) and det.shape[0] > 3
+    with pytest.raises(NotImplementedError):
+        entry.detect_face(fr, 2)
+
+
+def test_track_device_resident_equals_host_and_oracle(entry, synth, tmp_path):
+    frames = frames_sequence(synth)
+    t_dev = entry.track(frames, device_resident=True)
+    t_host = entry.track(frames, device_resident=False)
+    ref = opp.IouTracker(entry.sigma_iou, entry.sigma_h, entry.t_min)
+    for f in frames:
+        with np.errstate(all="ignore"):
+            ref.step(entry.detect_face(f, 1))
+    t_ref = [{"bboxes": [list(map(float, b)) for b in t["bboxes"]], "max_score": float(t["max_score"]),
+              "start_frame": t["start_frame"]} for t in ref.finish()]
+    assert len(t_ref) > 3
+    assert t_dev == t_ref and t_host == t_ref          # track-ID assignment bit-exact given identical boxes
+    # on-disk schema of reference iouTracke_cal.py:177 / iouTracke_display.py:29
+    p = str(tmp_path / "video.npy")
+    entry.save_tracks(t_dev, p)
+    back = np.load(p, allow_pickle=True).tolist()
+    assert back == t_dev and set(back[0]) == {"bboxes", "max_score", "start_frame"}
