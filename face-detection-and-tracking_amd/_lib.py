@@ -49,6 +49,8 @@ SIGNATURES = {
                                  C.c_longlong, _vp]),
     "fdt_detect_workspace_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "fdt_pairwise_iou": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp]),
+    "fdt_facebox_anchors": (C.c_int, [_vp]),
+    "fdt_facebox_decode": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_float, C.c_float, _vp, _vp, _c_int_p]),
     "fdt_tracker_create": (_vp, [C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]),
     "fdt_tracker_destroy": (None, [_vp]),
     "fdt_tracker_reset": (C.c_int, [_vp]),
@@ -69,6 +71,10 @@ SIGNATURES = {
     "fdt_model_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "fdt_model_forward_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "fdt_model_forward_raw": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "fdt_model_detect_facebox": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                           _vp, _vp, _vp]),
+    "fdt_model_detect_facebox_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                               C.c_float, _vp, _vp]),
     "fdt_model_num_priors": (C.c_int, [_vp, _c_int_p]),
     "fdt_model_get_tensor": (C.c_int, [_vp, C.c_char_p, _vp, C.c_longlong, _c_i64_p]),
     "fdt_model_profile_enable": (C.c_int, [_vp, C.c_int]),

@@ -88,6 +88,7 @@ struct fdt_model {
   void* d_ws = nullptr;
   DetectPlan dplan;
   unsigned char* d_frames_u8 = nullptr;
+  float *d_fb_boxes = nullptr, *d_fb_probs = nullptr;
   double flops_per_frame = 0;
   long long ws_floats = 0;   // split-K / fused-upsample workspace shared by all layers
   float* d_convws = nullptr;
@@ -117,6 +118,7 @@ struct fdt_model {
     d_counts = nullptr;
     d_ws = nullptr;
     d_frames_u8 = nullptr;
+    d_fb_boxes = d_fb_probs = nullptr;
     d_convws = nullptr;
     ws_floats = 0;
     pB = pH = pW = 0;
@@ -435,6 +437,18 @@ struct Builder {
     return out_t;
   }
 
+  void mboxfin(int map_t, int anchors) {   // FACEBOX/multibox_layer.py:34-48
+    if (rc != FDT_OK) return;
+    Op op;
+    op.type = OP_MBOXFIN;
+    op.name = "multibox_finalize";
+    op.in_t = map_t;
+    op.anchors = anchors;
+    memset(&op.ca, 0, sizeof(op.ca));
+    m->levels.push_back({m->tensors[map_t].H * anchors, m->tensors[map_t].W});
+    m->ops.push_back(op);
+  }
+
   void headfin(int head_t, int level0) {
     if (rc != FDT_OK) return;
     Op op;
@@ -658,6 +672,68 @@ struct Builder {
     for (size_t i = 0; i < src.size(); ++i) m->tensors[src[i]].name = "src" + std::to_string(i);
     heads(src);   // zip() truncates to the 5 sources (:288): face_*.5 are dead weights
   }
+
+  // ---------------------------------------------------------------- FaceBox   FACEBOX/networks.py:87-116
+  int cbr(const std::string& n, int x, int cout, ConvKind kind, int out_t = -1, int coff = 0) {
+    ConvOpt o;   // conv_bn_relu(): Conv2d(bias) -> BatchNorm2d -> ReLU   (networks.py:11-16)
+    o.bn = n + ".1";
+    o.act = ACT_RELU;
+    o.out_t = out_t;
+    o.out_coff = coff;
+    return conv(n + ".0", x, cout, kind, o);
+  }
+
+  int inception(const std::string& n, int x) {   // networks.py:43-57
+    if (rc != FDT_OK) return -1;
+    const Tensor xin = m->tensors[x];
+    int out = new_tensor(n, 128, xin.H, xin.W);
+    if (out < 0) return -1;
+    cbr(n + ".conv1", x, 32, CONV_1x1_S1, out, 0);
+    int xp = pool(n + ".pool", x, 1, 0);
+    cbr(n + ".conv2", xp, 32, CONV_1x1_S1, out, 32);
+    int t3 = cbr(n + ".conv3", x, 24, CONV_1x1_S1);
+    cbr(n + ".conv4", t3, 32, CONV_3x3_S1, out, 64);
+    int t5 = cbr(n + ".conv5", x, 24, CONV_1x1_S1);
+    int t6 = cbr(n + ".conv6", t5, 32, CONV_3x3_S1);
+    cbr(n + ".conv7", t6, 32, CONV_3x3_S1, out, 96);
+    return out;
+  }
+
+  void build_facebox(int H, int W) {
+    int x = new_tensor("input", 3, H, W);
+    ConvOpt o1;
+    o1.bn = "bn1";
+    int c1 = conv("conv1", x, 24, CONV_7x7_S4, o1);       // :89-90
+    int p1 = pool("crelu_pool1", c1, 2, 1);               // :91-93  CReLU + max_pool2d(3,2,1)
+    ConvOpt o2;
+    o2.bn = "bn2";
+    int c2 = conv("conv2", p1, 64, CONV_5x5_S2, o2);      // :94-95
+    int p2 = pool("crelu_pool2", c2, 2, 1);               // :96-98
+    if (rc != FDT_OK) return;
+    int h = inception("inception1", p2);
+    h = inception("inception2", h);
+    h = inception("inception3", h);                        // :99-101
+    if (rc != FDT_OK) return;
+    m->tensors[h].name = "hs0";
+    int c31 = cbr("conv3_1", h, 128, CONV_1x1_S1);
+    int hs1 = cbr("conv3_2", c31, 256, CONV_3x3_S2);      // :105-106
+    int c41 = cbr("conv4_1", hs1, 128, CONV_1x1_S1);
+    int hs2 = cbr("conv4_2", c41, 256, CONV_3x3_S2);      // :109-110
+    if (rc != FDT_OK) return;
+    m->tensors[hs1].name = "hs1";
+    m->tensors[hs2].name = "hs2";
+    const int srcs[3] = {h, hs1, hs2};
+    const int anchors[3] = {21, 1, 1};                     // multibox_layer.py:14
+    for (int i = 0; i < 3; ++i) {
+      ConvOpt o;
+      o.name2 = "multilbox.conf_layers." + std::to_string(i);
+      o.cout2 = anchors[i] * 2;
+      int mp = conv("multilbox.loc_layers." + std::to_string(i), srcs[i], anchors[i] * 4, CONV_3x3_S1, o);
+      if (mp < 0) return;
+      m->tensors[mp].name = "mbox" + std::to_string(i);
+      mboxfin(mp, anchors[i]);
+    }
+  }
 };
 
 bool ignored_key(const fdt_model* m, const std::string& k) {
@@ -681,8 +757,10 @@ int build_graph(fdt_model* m, int B, int H, int W) {
     bld.build_res50(H, W);
   else if (m->arch == FDT_ARCH_TRY3)
     bld.build_try3(H, W);
+  else if (m->arch == FDT_ARCH_FACEBOX)
+    bld.build_facebox(H, W);
   else {
-    set_error("arch %d: forward graph not available in this build", m->arch);
+    set_error("unknown arch %d", m->arch);
     return FDT_ERR_ARG;
   }
   return bld.rc;
@@ -690,6 +768,12 @@ int build_graph(fdt_model* m, int B, int H, int W) {
 
 // priors (net.priorbox(idx, f_w, f_h) per source, pyramid.py:275-283)
 int make_priors(fdt_model* m, int H, int W) {
+  if (m->arch == FDT_ARCH_FACEBOX) {   // anchors are fixed: DataEncoder.__init__ (encoderl.py:12-48)
+    FDT_REQUIRE(m->P == 21824, FDT_ERR_ARG, "FaceBox needs 1024x1024 input (21824 anchors), got %d priors", m->P);
+    FDT_TRY(launch_facebox_anchors(m->d_priors, m->stream));
+    m->priors_dirty = false;
+    return FDT_OK;
+  }
   const int nl = (int)m->levels.size();
   std::vector<int> stride = m->pb_stride, box = m->pb_box;
   int pw = m->pb_set ? m->pb_w : W, ph = m->pb_set ? m->pb_h : H;
@@ -737,7 +821,7 @@ int make_plan(fdt_model* m, int B, int H, int W) {
   int P = 0;
   size_t li = 0;
   for (auto& op : m->ops)
-    if (op.type == OP_HEADFIN) {
+    if (op.type == OP_HEADFIN || op.type == OP_MBOXFIN) {
       op.p_off = P;
       P += m->levels[li].first * m->levels[li].second;
       ++li;
@@ -755,7 +839,11 @@ int make_plan(fdt_model* m, int B, int H, int W) {
   FDT_TRY(dalloc((void**)&m->d_out, (size_t)B * 2 * m->top_k * 5 * 4));
   FDT_TRY(dalloc((void**)&m->d_counts, (size_t)B * 2 * 4));
   FDT_TRY(dalloc((void**)&m->d_frames_u8, (size_t)B * H * W * 3));
-  m->dplan = make_detect_plan(B, P, m->nms_top_k);
+  m->dplan = make_detect_plan(B, P, m->arch == FDT_ARCH_FACEBOX ? P : m->nms_top_k);
+  if (m->arch == FDT_ARCH_FACEBOX) {
+    FDT_TRY(dalloc((void**)&m->d_fb_boxes, (size_t)B * P * 16));
+    FDT_TRY(dalloc((void**)&m->d_fb_probs, (size_t)B * P * 4));
+  }
   FDT_TRY(dalloc(&m->d_ws, m->dplan.bytes));
   if (m->ws_floats) {
     FDT_TRY(dalloc((void**)&m->d_convws, (size_t)m->ws_floats * 4));
@@ -807,6 +895,14 @@ int run_ops(fdt_model* m, int B, hipStream_t st) {
                                      m->d_logits, st));
         break;
       }
+      case OP_MBOXFIN: {
+        const Tensor& in = m->tensors[op.in_t];
+        const long long hw = (long long)in.H * in.W;
+        FDT_TRY(launch_multibox_finalize(in.d, in.d + (long long)op.anchors * 4 * hw, (long long)in.C * hw, B,
+                                         op.anchors, in.H, in.W, m->P, op.p_off, m->d_loc, m->d_conf,
+                                         m->d_logits, st));
+        break;
+      }
       default:
         break;
     }
@@ -836,14 +932,18 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
       src = m->d_frames_u8;
     }
     if (m->arch == FDT_ARCH_FACEBOX)
-      FDT_TRY(launch_preprocess(src, B, H, W, 0.f, 0.f, 0.f, 1.0f / 255.0f, x, st));
+      FDT_TRY(launch_preprocess(src, B, H, W, 0.f, 0.f, 0.f, 255.0f, x, st));
     else
       FDT_TRY(launch_preprocess(src, B, H, W, 104.f, 117.f, 123.f, 1.0f, x, st));
   } else {
     FDT_HIP(hipMemcpyAsync(x, frames, (size_t)B * 3 * H * W * 4, kind, st));
   }
   FDT_TRY(run_ops(m, B, st));
-  if (run_detect) {
+  if (run_detect && m->arch == FDT_ARCH_FACEBOX) {
+    FDT_TRY(launch_facebox_decode(m->dplan, m->d_ws, m->d_loc, m->d_conf, m->d_priors, m->conf_t, m->nms_t,
+                                  m->d_fb_boxes, m->d_fb_probs, counts_dev ? counts_dev : m->d_counts, st));
+    if (m->profile) FDT_HIP(hipEventRecord(m->ev[m->ops.size() + 1], st));
+  } else if (run_detect) {
     FDT_TRY(launch_detect(m->dplan, m->d_ws, m->d_loc, m->d_conf, m->d_priors, 2, m->top_k, m->conf_t,
                           m->nms_t, 0.1f, 0.2f, out_dev ? out_dev : m->d_out,
                           counts_dev ? counts_dev : m->d_counts, st));
@@ -856,7 +956,7 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
 
 // ================================================================================== C ABI
 extern "C" fdt_model* fdt_model_create(int arch, int device) {
-  if (arch != FDT_ARCH_RES50 && arch != FDT_ARCH_TRY3) {
+  if (arch != FDT_ARCH_RES50 && arch != FDT_ARCH_TRY3 && arch != FDT_ARCH_FACEBOX) {
     set_error("fdt_model_create: unknown arch %d", arch);
     return nullptr;
   }
@@ -875,9 +975,13 @@ extern "C" fdt_model* fdt_model_create(int arch, int device) {
     m->conf_t = 0.2f;
     m->nms_t = 0.35f;
   }
+  if (arch == FDT_ARCH_FACEBOX) {   // decode_np(conf_thres=0.35), nms_np(threshold=0.5)  encoderl.py:217,308
+    m->conf_t = 0.35f;
+    m->nms_t = 0.5f;
+  }
   // dry build: collect the state-dict keys the forward graph reads
   m->dry = true;
-  int rc = build_graph(m.get(), 1, 256, 256);
+  int rc = build_graph(m.get(), 1, arch == FDT_ARCH_FACEBOX ? 1024 : 256, arch == FDT_ARCH_FACEBOX ? 1024 : 256);
   m->dry = false;
   m->tensors.clear();
   m->ops.clear();
@@ -982,9 +1086,37 @@ extern "C" int fdt_model_set_detect(fdt_model* m, int top_k, float conf_thresh, 
   return FDT_OK;
 }
 
+extern "C" int fdt_model_detect_facebox(fdt_model* m, const void* frames, int format, int B, int H, int W,
+                                        float conf_thresh, float nms_thresh, float* boxes, float* probs,
+                                        int* counts) {
+  FDT_REQUIRE(m && boxes && probs && counts, FDT_ERR_ARG, "fdt_model_detect_facebox: null argument");
+  FDT_REQUIRE(m->arch == FDT_ARCH_FACEBOX, FDT_ERR_ARG, "fdt_model_detect_facebox: not a FaceBox model");
+  FDT_REQUIRE(nms_thresh > 0.f, FDT_ERR_ARG, "nms threshold must be positive");
+  m->conf_t = conf_thresh;
+  m->nms_t = nms_thresh;
+  FDT_TRY(forward_impl(m, frames, false, format, B, H, W, true, nullptr, nullptr, nullptr));
+  FDT_HIP(hipMemcpyAsync(counts, m->d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+  FDT_HIP(hipMemcpyAsync(boxes, m->d_fb_boxes, (size_t)B * m->P * 16, hipMemcpyDeviceToHost, m->stream));
+  FDT_HIP(hipMemcpyAsync(probs, m->d_fb_probs, (size_t)B * m->P * 4, hipMemcpyDeviceToHost, m->stream));
+  FDT_HIP(hipStreamSynchronize(m->stream));
+  return FDT_OK;
+}
+
+extern "C" int fdt_model_detect_facebox_dev(fdt_model* m, const void* frames_dev, int format, int B, int H,
+                                            int W, float conf_thresh, float nms_thresh, int* counts_dev,
+                                            void* stream) {
+  FDT_REQUIRE(m && m->arch == FDT_ARCH_FACEBOX, FDT_ERR_ARG, "fdt_model_detect_facebox_dev: not a FaceBox model");
+  FDT_REQUIRE(nms_thresh > 0.f, FDT_ERR_ARG, "nms threshold must be positive");
+  m->conf_t = conf_thresh;
+  m->nms_t = nms_thresh;
+  return forward_impl(m, frames_dev, true, format, B, H, W, true, nullptr, counts_dev, (hipStream_t)stream);
+}
+
 extern "C" int fdt_model_forward(fdt_model* m, const void* frames, int format, int B, int H, int W,
                                  float* out, int* counts) {
   FDT_REQUIRE(out, FDT_ERR_ARG, "fdt_model_forward: null output");
+  FDT_REQUIRE(m && m->arch != FDT_ARCH_FACEBOX, FDT_ERR_ARG,
+              "fdt_model_forward: FaceBox has no Detect layer; use fdt_model_detect_facebox");
   FDT_TRY(forward_impl(m, frames, false, format, B, H, W, true, nullptr, nullptr, nullptr));
   FDT_HIP(hipMemcpyAsync(out, m->d_out, (size_t)B * 2 * m->top_k * 5 * 4, hipMemcpyDeviceToHost, m->stream));
   if (counts) FDT_HIP(hipMemcpyAsync(counts, m->d_counts, (size_t)B * 2 * 4, hipMemcpyDeviceToHost, m->stream));
@@ -995,6 +1127,8 @@ extern "C" int fdt_model_forward(fdt_model* m, const void* frames, int format, i
 extern "C" int fdt_model_forward_dev(fdt_model* m, const void* frames_dev, int format, int B, int H, int W,
                                      float* out_dev, int* counts_dev, void* stream) {
   FDT_REQUIRE(out_dev, FDT_ERR_ARG, "fdt_model_forward_dev: null output");
+  FDT_REQUIRE(m && m->arch != FDT_ARCH_FACEBOX, FDT_ERR_ARG,
+              "fdt_model_forward_dev: FaceBox has no Detect layer; use fdt_model_detect_facebox_dev");
   return forward_impl(m, frames_dev, true, format, B, H, W, true, out_dev, counts_dev, (hipStream_t)stream);
 }
 
@@ -1003,7 +1137,9 @@ extern "C" int fdt_model_forward_raw(fdt_model* m, const void* frames, int forma
   FDT_REQUIRE(loc && conf, FDT_ERR_ARG, "fdt_model_forward_raw: null output");
   FDT_TRY(forward_impl(m, frames, false, format, B, H, W, false, nullptr, nullptr, nullptr));
   FDT_HIP(hipMemcpyAsync(loc, m->d_loc, (size_t)B * m->P * 16, hipMemcpyDeviceToHost, m->stream));
-  FDT_HIP(hipMemcpyAsync(conf, m->d_conf, (size_t)B * m->P * 8, hipMemcpyDeviceToHost, m->stream));
+  // PyramidBox forwards end in nn.Softmax (pyramid.py:332); FaceBox.forward returns raw conf_preds
+  FDT_HIP(hipMemcpyAsync(conf, m->arch == FDT_ARCH_FACEBOX ? m->d_logits : m->d_conf, (size_t)B * m->P * 8,
+                         hipMemcpyDeviceToHost, m->stream));
   FDT_HIP(hipStreamSynchronize(m->stream));
   return FDT_OK;
 }
@@ -1036,6 +1172,16 @@ extern "C" int fdt_model_get_tensor(fdt_model* m, const char* name, float* out, 
     src = m->d_logits;
     d[1] = m->P;
     d[2] = 2;
+    d[3] = 1;
+  } else if (k == "fb_boxes" && m->d_fb_boxes) {
+    src = m->d_fb_boxes;
+    d[1] = m->P;
+    d[2] = 4;
+    d[3] = 1;
+  } else if (k == "fb_probs" && m->d_fb_probs) {
+    src = m->d_fb_probs;
+    d[1] = m->P;
+    d[2] = 1;
     d[3] = 1;
   } else if (k == "priors") {
     src = m->d_priors;

@@ -5,8 +5,8 @@
 
 namespace fdt {
 
-// u8 BGR HWC -> f32 NCHW, minus per-channel mean (iouTracke_cal.py:41-44) then * scale
-// (FaceBox: mean 0, scale 1/255: FACEBOX/My_test_facebox.py:14-15).
+// u8 BGR HWC -> f32 NCHW, minus per-channel mean (iouTracke_cal.py:41-44) then / scale
+// (FaceBox: mean 0, divide by 255: FACEBOX/My_test_facebox.py:14-15).
 int launch_preprocess(const unsigned char* frames, int B, int H, int W, float m0, float m1, float m2,
                       float scale, float* out, hipStream_t st);
 
@@ -26,9 +26,11 @@ int launch_dwconv3(const float* in, const float* w9, const float* bias, int B, i
 int launch_head_finalize(const float* head, int B, int H, int W, int level0, int P, int p_off,
                          float* loc, float* conf, float* logits, hipStream_t st);
 
-// FaceBox multibox level: loc map [B][A*4][H][W], conf map [B][A*2][H][W] -> rows of A anchors per
-// cell (FACEBOX/multibox_layer.py:34-48) + softmax.
-int launch_multibox_finalize(const float* locmap, const float* confmap, int B, int A, int H, int W,
-                             int P, int p_off, float* loc, float* conf, hipStream_t st);
+// FaceBox multibox level: loc map [A*4][H][W] and conf map [A*2][H][W] inside one per-image block of
+// `img_stride` floats -> rows of A anchors per cell (FACEBOX/multibox_layer.py:34-48), raw logits and
+// softmax (FACEBOX/My_test_facebox.py:25).
+int launch_multibox_finalize(const float* locmap, const float* confmap, long long img_stride, int B, int A,
+                             int H, int W, int P, int p_off, float* loc, float* conf, float* logits,
+                             hipStream_t st);
 
 }  // namespace fdt

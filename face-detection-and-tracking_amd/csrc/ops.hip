@@ -16,7 +16,7 @@ __global__ void preprocess_kernel(const unsigned char* __restrict__ in, int H, i
   float* o = out + (long long)b * 3 * hw + p;
   // x.astype(f32) - mean (exact in f32), optional scale
   float v0 = (float)px[0] - m0, v1 = (float)px[1] - m1, v2 = (float)px[2] - m2;
-  if (scale != 1.0f) { v0 *= scale; v1 *= scale; v2 *= scale; }
+  if (scale != 1.0f) { v0 /= scale; v1 /= scale; v2 /= scale; }   // im_tensor.float().div(255)
   o[0] = v0;
   o[hw] = v1;
   o[2 * hw] = v2;
@@ -112,21 +112,24 @@ __global__ void head_finalize_kernel(const float* __restrict__ head, int HW, int
 }
 
 __global__ void multibox_finalize_kernel(const float* __restrict__ locmap, const float* __restrict__ confmap,
-                                         int A, int HW, int P, int p_off, float* __restrict__ loc,
-                                         float* __restrict__ conf) {
+                                         long long img_stride, int A, int HW, int P, int p_off,
+                                         float* __restrict__ loc, float* __restrict__ conf,
+                                         float* __restrict__ logits) {
   const int b = blockIdx.y;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;   // cell * A + anchor
   if (t >= HW * A) return;
   const int cell = t / A, a = t % A;
-  const float* lm = locmap + (long long)b * A * 4 * HW + cell;
-  const float* cm = confmap + (long long)b * A * 2 * HW + cell;
+  const float* lm = locmap + (long long)b * img_stride + cell;
+  const float* cm = confmap + (long long)b * img_stride + cell;
   float4 l = make_float4(lm[(long long)(a * 4 + 0) * HW], lm[(long long)(a * 4 + 1) * HW],
                          lm[(long long)(a * 4 + 2) * HW], lm[(long long)(a * 4 + 3) * HW]);
   float pn, pp;
-  softmax2(cm[(long long)(a * 2 + 0) * HW], cm[(long long)(a * 2 + 1) * HW], pn, pp);
+  const float c0 = cm[(long long)(a * 2 + 0) * HW], c1 = cm[(long long)(a * 2 + 1) * HW];
+  softmax2(c0, c1, pn, pp);
   const long long row = (long long)b * P + p_off + t;
   reinterpret_cast<float4*>(loc)[row] = l;
   reinterpret_cast<float2*>(conf)[row] = make_float2(pn, pp);
+  if (logits) reinterpret_cast<float2*>(logits)[row] = make_float2(c0, c1);
 }
 
 }  // namespace
@@ -167,11 +170,12 @@ int launch_head_finalize(const float* head, int B, int H, int W, int level0, int
   return FDT_OK;
 }
 
-int launch_multibox_finalize(const float* locmap, const float* confmap, int B, int A, int H, int W, int P,
-                             int p_off, float* loc, float* conf, hipStream_t st) {
+int launch_multibox_finalize(const float* locmap, const float* confmap, long long img_stride, int B, int A,
+                             int H, int W, int P, int p_off, float* loc, float* conf, float* logits,
+                             hipStream_t st) {
   dim3 grid(ceil_div(H * W * A, 256), B);
-  hipLaunchKernelGGL(multibox_finalize_kernel, grid, dim3(256), 0, st, locmap, confmap, A, H * W, P, p_off,
-                     loc, conf);
+  hipLaunchKernelGGL(multibox_finalize_kernel, grid, dim3(256), 0, st, locmap, confmap, img_stride, A, H * W,
+                     P, p_off, loc, conf, logits);
   FDT_LAUNCH_CHECK();
   return FDT_OK;
 }

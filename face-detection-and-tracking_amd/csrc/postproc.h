@@ -22,6 +22,10 @@ int launch_detect(const DetectPlan& pl, void* ws, const float* loc, const float*
                   float v1, float* out, int* counts, hipStream_t st);
 int launch_nms(const DetectPlan& pl, void* ws, const float* boxes, const float* scores,
                float overlap, long long* keep, int* count, hipStream_t st);
+int launch_facebox_decode(const DetectPlan& pl, void* ws, const float* loc, const float* conf,
+                          const float* anchors, float conf_t, float nms_t, float* boxes, float* probs,
+                          int* counts, hipStream_t st);
+int launch_facebox_anchors(float* out, hipStream_t st);
 int launch_pairwise_iou(const void* a, int A, const void* b, int B, int dtype, void* out,
                         hipStream_t st);
 

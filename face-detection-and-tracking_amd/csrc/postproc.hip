@@ -70,6 +70,54 @@ __device__ __forceinline__ float4 decode_one(float4 l, float4 p, float v0, float
   return make_float4(x1, y1, w + x1, h + y1);
 }
 
+// FaceBox: DataEncoder.decode_np (FACEBOX/encoderl.py:318-320): cxcy = loc*0.1*a_wh + a_xy;
+// wh = exp(loc*0.2)*a_wh; box = [cxcy - wh/2, cxcy + wh/2]   (x2 = cx + w/2, unlike decode()).
+__device__ __forceinline__ float4 decode_facebox(float4 l, float4 p) {
+  float cx = (l.x * 0.1f) * p.z + p.x;
+  float cy = (l.y * 0.1f) * p.w + p.y;
+  float w = expf(l.z * 0.2f) * p.z;
+  float h = expf(l.w * 0.2f) * p.w;
+  return make_float4(cx - w / 2.0f, cy - h / 2.0f, cx + w / 2.0f, cy + h / 2.0f);
+}
+
+// FaceBox anchors: DataEncoder.__init__ (FACEBOX/encoderl.py:21-47), f64 then one rounding to f32.
+// level 0: 32x32 cells x (16 anchors of 32 px on a 4x4 sub-grid, 4 of 64 px on 2x2, 1 of 128 px);
+// levels 1,2: one anchor of 256 / 512 px per cell of the 16x16 / 8x8 maps.  21 824 anchors.
+__global__ void facebox_anchors_kernel(float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 21824) return;
+  const double scale = 1024.0;
+  double cx, cy, sz;
+  if (t < 32 * 32 * 21) {
+    const int cell = t / 21, k = t % 21;
+    const int hh = cell / 32, ww = cell % 32;
+    const double step = 32.0 / scale, s = 32.0 / scale;
+    cx = (ww + 0.5) * step;
+    cy = (hh + 0.5) * step;
+    double ar, dx, dy;
+    if (k < 16) {          // ar = 1, density [-3,-1,1,3]; itertools.product: dx outer, dy inner
+      ar = 1.0; dx = -3.0 + 2.0 * (k / 4); dy = -3.0 + 2.0 * (k % 4);
+    } else if (k < 20) {   // ar = 2, density [-1,1]
+      ar = 2.0; dx = -1.0 + 2.0 * ((k - 16) / 2); dy = -1.0 + 2.0 * ((k - 16) % 2);
+    } else {               // ar = 4, density [0]
+      ar = 4.0; dx = 0.0; dy = 0.0;
+    }
+    cx = cx + dx / 8. * s * ar;
+    cy = cy + dy / 8. * s * ar;
+    sz = s * ar;
+  } else {
+    int r = t - 32 * 32 * 21;
+    int fm = 16;
+    double step = 64.0 / scale, s = 256.0 / scale;
+    if (r >= 256) { r -= 256; fm = 8; step = 128.0 / scale; s = 512.0 / scale; }
+    const int hh = r / fm, ww = r % fm;
+    cx = (ww + 0.5) * step;
+    cy = (hh + 0.5) * step;
+    sz = s * 1.0;
+  }
+  reinterpret_cast<float4*>(out)[t] = make_float4((float)cx, (float)cy, (float)sz, (float)sz);
+}
+
 __global__ void decode_kernel(const float4* __restrict__ loc, const float4* __restrict__ pri, int P,
                               float v0, float v1, float4* __restrict__ out) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -168,7 +216,7 @@ __global__ __launch_bounds__(1024) void sort_kernel(unsigned long long* __restri
 __global__ void gather_kernel(const unsigned long long* __restrict__ keys, long long key_stride,
                               const int* __restrict__ cand, int K, int Kp,
                               const float4* __restrict__ loc, const float4* __restrict__ pri,
-                              const float4* __restrict__ boxes_in, int P, float v0, float v1,
+                              const float4* __restrict__ boxes_in, int P, float v0, float v1, int facebox,
                               const float* __restrict__ scores, int score_stride, int score_off,
                               long long score_img_stride, float4* __restrict__ sbox,
                               float* __restrict__ sarea, float* __restrict__ sscore,
@@ -182,6 +230,8 @@ __global__ void gather_kernel(const unsigned long long* __restrict__ keys, long 
   float4 bx;
   if (boxes_in)
     bx = boxes_in[(long long)b * P + p];
+  else if (facebox)
+    bx = decode_facebox(loc[(long long)b * P + p], pri[p]);
   else
     bx = decode_one(loc[(long long)b * P + p], pri[p], v0, v1);
   long long o = (long long)b * Kp + r;
@@ -198,7 +248,7 @@ __global__ void gather_kernel(const unsigned long long* __restrict__ keys, long 
 __global__ __launch_bounds__(64) void mask_kernel(const float4* __restrict__ sbox,
                                                   const float* __restrict__ sarea,
                                                   const int* __restrict__ cand, int K, int Kp,
-                                                  float overlap,
+                                                  float overlap, int facebox,
                                                   unsigned long long* __restrict__ mask) {
   const int bj = blockIdx.x, bi = blockIdx.y, b = blockIdx.z;
   if (bj < bi) return;
@@ -236,7 +286,8 @@ __global__ __launch_bounds__(64) void mask_kernel(const float4* __restrict__ sbo
     w = (w < 0.0f) ? 0.0f : w;
     h = (h < 0.0f) ? 0.0f : h;
     float inter = w * h;
-    float uni = (ca[c] - inter) + ai;
+    // box_utils.py:336: (area_j - inter) + area_i;  nms_np (encoderl.py:251): (area_i + area_j) - inter
+    float uni = facebox ? ((ai + ca[c]) - inter) : ((ca[c] - inter) + ai);
     float iou = inter / uni;
     if (!(iou < overlap)) word |= (1ull << c);
   }
@@ -253,7 +304,7 @@ __global__ __launch_bounds__(64) void scan_kernel(
     const float* __restrict__ sscore, const int* __restrict__ sidx, const int* __restrict__ cand,
     int K, int Kp, int max_keep, int skip_single, float* __restrict__ out, long long out_img_stride,
     int* __restrict__ counts, int count_stride, int count_off, long long* __restrict__ keep_idx,
-    long long keep_stride) {
+    long long keep_stride, float* __restrict__ fb_boxes, float* __restrict__ fb_probs, int fb_stride) {
   extern __shared__ unsigned long long removed[];  // Kp/64 words
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
@@ -297,6 +348,10 @@ __global__ __launch_bounds__(64) void scan_kernel(
         o[4] = bx.w;
       }
       if (keep_idx) keep_idx[b * keep_stride + row] = (long long)sidx[src];
+      if (fb_boxes) {   // boxes[keep], score[ids][keep]  (encoderl.py:325)
+        reinterpret_cast<float4*>(fb_boxes)[(long long)b * fb_stride + row] = sbox[src];
+        fb_probs[(long long)b * fb_stride + row] = sscore[src];
+      }
     }
     kept_total = kt;
     if (kept_total >= limit) break;
@@ -409,7 +464,8 @@ int launch_decode(const float* loc, const float* pri, int P, float v0, float v1,
 
 // Shared tail of Detect and stand-alone nms: sort -> gather -> mask -> scan.
 static int run_sorted_nms(const DetectPlan& pl, char* ws, const float* loc, const float* pri,
-                          const float* boxes_in, float v0, float v1, const float* scores,
+                          const float* boxes_in, float v0, float v1, int facebox, float* fb_boxes,
+                          float* fb_probs, const float* scores,
                           int score_stride, int score_off, long long score_img_stride, float overlap,
                           int max_keep, int skip_single, float* out, long long out_img_stride,
                           int* counts, int count_stride, int count_off, long long* keep_idx,
@@ -425,16 +481,16 @@ static int run_sorted_nms(const DetectPlan& pl, char* ws, const float* loc, cons
   FDT_LAUNCH_CHECK();
   hipLaunchKernelGGL(gather_kernel, dim3(ceil_div(pl.K, 256), pl.B), dim3(256), 0, st, keys,
                      pl.key_stride, cand, pl.K, pl.Kp, (const float4*)loc, (const float4*)pri,
-                     (const float4*)boxes_in, pl.P, v0, v1, scores, score_stride, score_off,
+                     (const float4*)boxes_in, pl.P, v0, v1, facebox, scores, score_stride, score_off,
                      score_img_stride, sbox, sarea, sscore, sidx);
   FDT_LAUNCH_CHECK();
   int nw = pl.Kp / 64;
   hipLaunchKernelGGL(mask_kernel, dim3(nw, nw, pl.B), dim3(64), 0, st, sbox, sarea, cand, pl.K,
-                     pl.Kp, overlap, mask);
+                     pl.Kp, overlap, facebox, mask);
   FDT_LAUNCH_CHECK();
   hipLaunchKernelGGL(scan_kernel, dim3(pl.B), dim3(64), (size_t)nw * 8, st, mask, sbox, sscore,
                      sidx, cand, pl.K, pl.Kp, max_keep, skip_single, out, out_img_stride, counts,
-                     count_stride, count_off, keep_idx, keep_stride);
+                     count_stride, count_off, keep_idx, keep_stride, fb_boxes, fb_probs, pl.P);
   FDT_LAUNCH_CHECK();
   return FDT_OK;
 }
@@ -455,7 +511,7 @@ int launch_detect(const DetectPlan& pl, void* ws_v, const float* loc, const floa
                        num_classes, cl, (long long)pl.P * num_classes, conf_t, 1,
                        (unsigned long long*)(ws + pl.off_keys), pl.key_stride, cand);
     FDT_LAUNCH_CHECK();
-    FDT_TRY(run_sorted_nms(pl, ws, loc, pri, nullptr, v0, v1, conf, num_classes, cl,
+    FDT_TRY(run_sorted_nms(pl, ws, loc, pri, nullptr, v0, v1, 0, nullptr, nullptr, conf, num_classes, cl,
                            (long long)pl.P * num_classes, nms_t, top_k, 1,
                            out + (long long)cl * top_k * 5, (long long)num_classes * top_k * 5,
                            counts, num_classes, cl, nullptr, 0, st));
@@ -479,8 +535,31 @@ int launch_nms(const DetectPlan& pl, void* ws_v, const float* boxes, const float
                      0, (long long)pl.P, 0.0f, 0, (unsigned long long*)(ws + pl.off_keys),
                      pl.key_stride, cand);
   FDT_LAUNCH_CHECK();
-  return run_sorted_nms(pl, ws, nullptr, nullptr, boxes, 0.f, 0.f, scores, 1, 0, (long long)pl.P,
-                        overlap, pl.K, 0, nullptr, 0, count, 1, 0, keep, pl.P, st);
+  return run_sorted_nms(pl, ws, nullptr, nullptr, boxes, 0.f, 0.f, 0, nullptr, nullptr, scores, 1, 0,
+                        (long long)pl.P, overlap, pl.K, 0, nullptr, 0, count, 1, 0, keep, pl.P, st);
+}
+
+// DataEncoder.decode_np (FACEBOX/encoderl.py:308-325): score > conf_thres, decode, nms_np(thr) with no
+// candidate cap and no output cap; boxes/probs come back in keep order.  `pl` must be built with K = P.
+int launch_facebox_decode(const DetectPlan& pl, void* ws_v, const float* loc, const float* conf,
+                          const float* anchors, float conf_t, float nms_t, float* boxes, float* probs,
+                          int* counts, hipStream_t st) {
+  char* ws = (char*)ws_v;
+  int* cand = (int*)(ws + pl.off_cand);
+  hipLaunchKernelGGL(reset_kernel, dim3(1), dim3(256), 0, st, nullptr, 0ll, counts, pl.B, cand, pl.B);
+  FDT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(compact_kernel, dim3(ceil_div(pl.P, 256), pl.B), dim3(256), 0, st, conf, pl.P, 2, 1,
+                     (long long)pl.P * 2, conf_t, 1, (unsigned long long*)(ws + pl.off_keys), pl.key_stride,
+                     cand);
+  FDT_LAUNCH_CHECK();
+  return run_sorted_nms(pl, ws, loc, anchors, nullptr, 0.1f, 0.2f, 1, boxes, probs, conf, 2, 1,
+                        (long long)pl.P * 2, nms_t, pl.K, 0, nullptr, 0, counts, 1, 0, nullptr, 0, st);
+}
+
+int launch_facebox_anchors(float* out, hipStream_t st) {
+  hipLaunchKernelGGL(facebox_anchors_kernel, dim3(ceil_div(21824, 256)), dim3(256), 0, st, out);
+  FDT_LAUNCH_CHECK();
+  return FDT_OK;
 }
 
 int launch_pairwise_iou(const void* a, int A, const void* b, int B, int dtype, void* out,
@@ -624,5 +703,39 @@ extern "C" int fdt_pairwise_iou(const void* a, int A, const void* b, int B, int 
   FDT_HIP(hipMemcpy(db.p, b, (size_t)B * 4 * es, hipMemcpyHostToDevice));
   FDT_TRY(launch_pairwise_iou(da.p, A, db.p, B, dtype, dout.p, 0));
   FDT_HIP(hipMemcpy(out, dout.p, (size_t)A * B * es, hipMemcpyDeviceToHost));
+  return FDT_OK;
+}
+
+extern "C" int fdt_facebox_anchors(float* out) {
+  FDT_REQUIRE(out, FDT_ERR_ARG, "fdt_facebox_anchors: null pointer");
+  DevBuf d;
+  FDT_TRY(d.alloc(21824 * 16));
+  FDT_TRY(launch_facebox_anchors(d.as<float>(), 0));
+  FDT_HIP(hipMemcpy(out, d.p, 21824 * 16, hipMemcpyDeviceToHost));
+  return FDT_OK;
+}
+
+extern "C" int fdt_facebox_decode(const float* loc, const float* conf, const float* anchors, int P,
+                                  float conf_thresh, float nms_thresh, float* boxes, float* probs,
+                                  int* count) {
+  FDT_REQUIRE(P >= 1 && loc && conf && anchors && boxes && probs && count, FDT_ERR_ARG,
+              "fdt_facebox_decode: bad argument");
+  DetectPlan pl = make_detect_plan(1, P, P);
+  DevBuf ws, dl, dc, da, db, dp, dn;
+  FDT_TRY(ws.alloc(pl.bytes));
+  FDT_TRY(dl.alloc((size_t)P * 16));
+  FDT_TRY(dc.alloc((size_t)P * 8));
+  FDT_TRY(da.alloc((size_t)P * 16));
+  FDT_TRY(db.alloc((size_t)P * 16));
+  FDT_TRY(dp.alloc((size_t)P * 4));
+  FDT_TRY(dn.alloc(4));
+  FDT_HIP(hipMemcpy(dl.p, loc, (size_t)P * 16, hipMemcpyHostToDevice));
+  FDT_HIP(hipMemcpy(dc.p, conf, (size_t)P * 8, hipMemcpyHostToDevice));
+  FDT_HIP(hipMemcpy(da.p, anchors, (size_t)P * 16, hipMemcpyHostToDevice));
+  FDT_TRY(launch_facebox_decode(pl, ws.p, dl.as<float>(), dc.as<float>(), da.as<float>(), conf_thresh,
+                                nms_thresh, db.as<float>(), dp.as<float>(), dn.as<int>(), 0));
+  FDT_HIP(hipMemcpy(count, dn.p, 4, hipMemcpyDeviceToHost));
+  FDT_HIP(hipMemcpy(boxes, db.p, (size_t)P * 16, hipMemcpyDeviceToHost));
+  FDT_HIP(hipMemcpy(probs, dp.p, (size_t)P * 4, hipMemcpyDeviceToHost));
   return FDT_OK;
 }

@@ -92,6 +92,14 @@ long long fdt_detect_workspace_bytes(int B, int P, int nms_top_k);
  * like numpy does (the tracker feeds f64).  0/0 -> NaN, no epsilon.                          */
 int fdt_pairwise_iou(const void* a, int A, const void* b, int B, int dtype, void* out);
 
+/* FaceBoxes anchors: DataEncoder.__init__  FACEBOX/encoderl.py:12-48.  out [21824,4] (cx,cy,w,h)/1024. */
+int fdt_facebox_anchors(float* out);
+/* DataEncoder.decode_np(loc, conf, conf_thres) + nms_np(threshold)  FACEBOX/encoderl.py:308-325,217-266.
+ * loc [P,4], conf [P,2] (softmaxed), anchors [P,4] -> boxes [<=P,4] (x1,y1,x2,y2 in [0,1], keep
+ * order) and probs; *count = number kept.  No candidate cap, no output cap (like the reference).      */
+int fdt_facebox_decode(const float* loc, const float* conf, const float* anchors, int P,
+                       float conf_thresh, float nms_thresh, float* boxes, float* probs, int* count);
+
 /* ------------------------------------------------------------------ IoU tracker
  * The inline tracker of iouTracke_cal.py:113-156 (per frame) and :174-177 (finalise), as a
  * device-resident state machine.  A track is {bboxes, max_score, start_frame}.               */
@@ -139,9 +147,17 @@ int fdt_model_forward(fdt_model* m, const void* frames, int format, int B, int H
                       float* out, int* counts);
 int fdt_model_forward_dev(fdt_model* m, const void* frames_dev, int format, int B, int H, int W,
                           float* out_dev, int* counts_dev, void* stream);
-/* FaceBox.forward  FACEBOX/networks.py:87-116: returns raw loc [B,21824,4], conf [B,21824,2]  */
+/* Network output without Detect: loc [B,P,4], conf [B,P,2].  PyramidBox: conf is softmaxed
+ * (pyramid.py:332).  FaceBox.forward (FACEBOX/networks.py:87-116): conf is the raw conf_preds.       */
 int fdt_model_forward_raw(fdt_model* m, const void* frames, int format, int B, int H, int W,
                           float* loc, float* conf);
+/* detect(im)  FACEBOX/My_test_facebox.py:12-36 after the resize: /255, FaceBox forward, softmax,
+ * decode_np + nms_np.  frames must be 1024x1024.  boxes [B,21824,4], probs [B,21824], counts [B].
+ * The _dev form leaves boxes/probs on the device (fdt_model_get_tensor "fb_boxes"/"fb_probs").       */
+int fdt_model_detect_facebox(fdt_model* m, const void* frames, int format, int B, int H, int W,
+                             float conf_thresh, float nms_thresh, float* boxes, float* probs, int* counts);
+int fdt_model_detect_facebox_dev(fdt_model* m, const void* frames_dev, int format, int B, int H, int W,
+                                 float conf_thresh, float nms_thresh, int* counts_dev, void* stream);
 /* after a forward: number of priors, and a named activation of the last forward
  * ("loc","conf","priors","c2".."c7","src0".."src5", ...) for stage-level parity tests.       */
 int fdt_model_num_priors(fdt_model* m, int* P);

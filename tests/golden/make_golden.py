@@ -363,7 +363,68 @@ def gen_nets():
     save("nets", **out)
 
 
-GENS = {"priors": gen_priors, "detect": gen_detect, "iou": gen_iou, "tracker": gen_tracker, "nets": gen_nets}
+# ----------------------------------------------------------------------------- FaceBoxes (real weights)
+def gen_facebox():
+    """Reference FaceBox + DataEncoder with the weights that ship in the reference tree
+    (FACEBOX/faceboxes.pt, loaded with weights_only=True).  The weights are saved as plain arrays
+    (tests/golden/faceboxes_weights.npz) so the GPU box can rebuild the same model; inputs are two of
+    the reference's sample JPEGs (PIL-decoded, resized to 1024x1024, RGB->BGR; stored post-resize since
+    cv2.resize is unavailable) and one seeded noise frame."""
+    import torch.nn.functional as F
+    from PIL import Image
+    from FACEBOX.networks import FaceBox
+    from FACEBOX.encoderl import DataEncoder
+    sd = torch.load(os.path.join(_refshim.REFERENCE, "FACEBOX", "faceboxes.pt"), map_location="cpu",
+                    weights_only=True)
+    net = FaceBox()
+    net.load_state_dict(sd)
+    net.eval()
+    np.savez_compressed(os.path.join(HERE, "faceboxes_weights.npz"), **{k: v.numpy() for k, v in sd.items()})
+    enc = DataEncoder()
+    out = {"anchors_sha": np.frombuffer(sha(enc.default_boxes_np).encode(), dtype=np.uint8),
+           "anchors_head": enc.default_boxes_np[:64], "anchors_tail": enc.default_boxes_np[-400:]}
+    imgdir = os.path.join(_refshim.REFERENCE, "image_and_anno", "test_image", "try1")
+    names = sorted(os.listdir(imgdir))
+    frames = []
+    for nm in (names[0], names[7]):
+        im = Image.open(os.path.join(imgdir, nm)).convert("RGB").resize((1024, 1024), Image.BILINEAR)
+        frames.append(np.ascontiguousarray(np.asarray(im)[:, :, ::-1]))
+    frames.append(synth.make_frames(1, 1024, 1024, seed=55)[0])
+    meta = {}
+    for i, fr in enumerate(frames):
+        x = torch.from_numpy(fr.transpose((2, 0, 1)).copy()).float().div(255)          # My_test_facebox.py:14-15
+        with torch.no_grad():
+            loc, conf = net(x[None])
+        loc = loc.squeeze(0)
+        confs = F.softmax(conf.squeeze(0), dim=1)
+        boxes, probs = enc.decode_np(loc, confs)
+        sel = np.linspace(0, 21823, 2048).astype(np.int64)
+        key = "img%d" % i
+        if i < 2:
+            out[key + "_frame"] = fr
+        out[key + "_sel"] = sel
+        out[key + "_loc_s"], out[key + "_conf_s"] = loc.numpy()[sel], conf.squeeze(0).numpy()[sel]
+        out[key + "_boxes"], out[key + "_probs"] = boxes, probs
+        meta[key] = {"n": int(len(probs)), "n_cand": int((confs[:, 1] > 0.35).sum()),
+                     "top": float(probs.max()) if len(probs) else 0.0, "noise_seed": 55 if i == 2 else None}
+        print("facebox", key, meta[key])
+    # decode_np / nms_np on crafted predictions: ~600 candidates on clustered anchors, distinct scores
+    rng = np.random.default_rng(8)
+    loc = rng.normal(0, 1.0, (21824, 4)).astype(np.float32)
+    sc = np.zeros(21824, np.float32)
+    hot = rng.choice(21824, 600, replace=False)
+    hot[:300] = (rng.integers(0, 40, 300) * 21 * 7 + rng.integers(0, 21, 300)) % 21824   # crowded cells
+    sc[hot] = rng.permutation(np.linspace(0.36, 0.999, hot.size)).astype(np.float32)
+    conf = np.stack([1 - sc, sc], 1).astype(np.float32)
+    boxes, probs = enc.decode_np(torch.from_numpy(loc), torch.from_numpy(conf))
+    out["dec_loc"], out["dec_conf"], out["dec_boxes"], out["dec_probs"] = loc, conf, boxes, probs
+    meta["dec"] = {"n": int(len(probs)), "n_cand": int((sc > 0.35).sum())}
+    print("facebox dec", meta["dec"])
+    out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    save("facebox", **out)
+
+
+GENS = {"facebox": gen_facebox, "priors": gen_priors, "detect": gen_detect, "iou": gen_iou, "tracker": gen_tracker, "nets": gen_nets}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
