@@ -42,6 +42,10 @@ def main():
     ap.add_argument("--unique-frames", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--profile-frames", type=int, default=4)
+    ap.add_argument("--autotune", type=int, default=1, help="autotune (tile, split-K) per conv layer at start-up")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="frames in flight per GPU: consecutive batch-1 steps overlap on separate HIP streams "
+                         "(detection of frame i+1 runs beside the tail / tracker step of frame i)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -70,44 +74,62 @@ def main():
     lib = pkg._lib
 
     H = W = args.size
-    if args.arch == "res50":
-        net = importlib.import_module("face-detection-and-tracking_amd.pyramid").SFD(device=local_rank)
-        net.priorbox = layers.PriorBoxLayer(W, H)
-    else:
-        net = importlib.import_module("face-detection-and-tracking_amd.pyramid_mb2_try3").SFD_mobile(device=local_rank)
-        net.priorbox = layers.PriorBoxLayer(W, H, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256))
     sd = synth.make_state_dict(args.arch, seed=0)
-    net.load_state_dict(sd)
-    net.cuda(); net.eval()
+    NF = max(1, args.inflight)
+    nets = []
+    for _ in range(NF):     # one handle (own activations + stream) per frame in flight; weights replicated
+        if args.arch == "res50":
+            n = importlib.import_module("face-detection-and-tracking_amd.pyramid").SFD(device=local_rank)
+            n.priorbox = layers.PriorBoxLayer(W, H)
+        else:
+            n = importlib.import_module("face-detection-and-tracking_amd.pyramid_mb2_try3").SFD_mobile(device=local_rank)
+            n.priorbox = layers.PriorBoxLayer(W, H, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256))
+        n.load_state_dict(sd)
+        n.cuda(); n.eval()
+        n._sync_attributes(H, W)
+        if args.autotune:
+            # plan-time measurement of every (tile, split-K) variant per layer; outside the timed region
+            n(synth.make_frames(1, H, W, seed=99)[0])
+            n.autotune(3)
+        nets.append(n)
+    net = nets[0]
     top_k = net.detect.top_k
 
     # synthetic frames, resident in HBM before the timed region
     frames_h = synth.make_frames(args.unique_frames, H, W, seed=1234 + rank)
     frames_d = torch.from_numpy(frames_h).to(dev)
-    fp = par.FrameParallel(rank, world, 2 * top_k * 5, dev)
-    gathered, mine = fp.gathered, fp.mine
+    fps = [par.FrameParallel(rank, world, 2 * top_k * 5, dev) for _ in range(NF)]
     counts = torch.zeros(2, dtype=torch.int32, device=dev)
     tracker = trk.IouTracker(0.4, 0.6, 5, max_dets=2 * top_k, log_frames=64)
-    # a non-default torch stream: its handle goes through the C ABI, so torch.cuda.Event brackets and
-    # the RCCL collective are ordered with the library's launches
-    tstream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(tstream)
-    stream = ctypes.c_void_p(tstream.cuda_stream)
-    assert stream.value, "need a real stream handle"
+    # non-default torch streams: their handles go through the C ABI, so torch.cuda.Event brackets and the
+    # RCCL collective are ordered with the library's launches.  One stream per frame in flight for the
+    # detector, one for the (strictly sequential) exchange + association.
+    det_streams = [torch.cuda.Stream(device=dev) for _ in range(NF)]
+    trk_stream = torch.cuda.Stream(device=dev)
+    sp_det = [ctypes.c_void_p(s_.cuda_stream) for s_ in det_streams]
+    sp_trk = ctypes.c_void_p(trk_stream.cuda_stream)
+    assert all(p_.value for p_ in sp_det) and sp_trk.value, "need real stream handles"
+    det_done = [torch.cuda.Event() for _ in range(NF)]
+    trk_done = [torch.cuda.Event() for _ in range(NF)]
     L = lib.lib()
 
-    # first call builds the plan (allocations, weight tiling/upload): outside the timed region
-    net._sync_attributes(H, W)
-
     def step(i):
+        k = i % NF
         f = frames_d[i % args.unique_frames]
-        lib.check(L.fdt_model_forward_dev(net._h, ctypes.c_void_p(f.data_ptr()), lib.FRAME_U8_HWC_BGR, 1, H, W,
-                                          ctypes.c_void_p(mine.data_ptr()), ctypes.c_void_p(counts.data_ptr()),
-                                          stream))
-        # the one exchange step of the path: fixed-size per-frame box lists, rank order == frame order
-        fp.exchange()
-        for r in range(world):
-            tracker.step_dev(ctypes.c_void_p(gathered[r].data_ptr()), 2, top_k, W, H, 0.4, stream)
+        fp = fps[k]
+        with torch.cuda.stream(det_streams[k]):
+            det_streams[k].wait_event(trk_done[k])        # slot k's record was consumed (step i - NF)
+            lib.check(L.fdt_model_forward_dev(nets[k]._h, ctypes.c_void_p(f.data_ptr()), lib.FRAME_U8_HWC_BGR, 1,
+                                              H, W, ctypes.c_void_p(fp.mine.data_ptr()),
+                                              ctypes.c_void_p(counts.data_ptr()), sp_det[k]))
+            det_done[k].record(det_streams[k])
+        with torch.cuda.stream(trk_stream):
+            trk_stream.wait_event(det_done[k])
+            # the one exchange step of the path: fixed-size per-frame box lists, rank order == frame order
+            g = fp.exchange()
+            for r in range(world):
+                tracker.step_dev(ctypes.c_void_p(g[r].data_ptr()), 2, top_k, W, H, 0.4, sp_trk)
+            trk_done[k].record(trk_stream)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -121,10 +143,10 @@ def main():
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    e0.record()
+    e0.record(trk_stream)
     for i in range(args.steps):
         step(args.warmup + i)
-    e1.record()
+    e1.record(trk_stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -137,6 +159,9 @@ def main():
         dt = float(t.item())
     n_cand_last = int(counts.cpu()[1])
     tracks = tracker.finish()
+    mine = fps[0].mine
+    stream = sp_det[0]
+    torch.cuda.set_stream(det_streams[0])
 
     # ---- per-launch timing of the dominant kernel (HIP events on the same stream) ---------------
     roof = None
@@ -201,7 +226,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "PyramidBox-%s %dx%d synthetic u8 frames, batch=1 per GPU, decode+NMS+IoU-tracker "
                                    "on device" % ("Res50" if args.arch == "res50" else "MobileNetV2-try3", H, W),
-                       "frames_per_step": world, "parallelism": "frame-parallel x%d%s" % (
+                       "frames_per_step": world, "frames_in_flight_per_gpu": NF, "autotuned": bool(args.autotune), "parallelism": "frame-parallel x%d%s" % (
                            world, ", RCCL all-gather of box lists" if world > 1 else ""),
                        "weights": "seeded synthetic (seed 0)", "detections_last_frame": n_cand_last,
                        "tracks": len(tracks), "gpu_ms_per_step_events": round(gpu_ms / args.steps, 4),

@@ -187,6 +187,10 @@ class DetectorNet:
             out = out.reshape(shape[:3])
         return out
 
+    def autotune(self, iters=3):
+        """Measure every (tile, split-K) variant per conv layer at the last forward's shape, keep the best."""
+        _lib.check(_lib.lib().fdt_model_autotune(self._h, int(iters)))
+
     def flops_per_frame(self):
         f = C.c_double(0)
         _lib.check(_lib.lib().fdt_model_flops(self._h, C.byref(f)))

@@ -422,3 +422,55 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a, hipStream_t st)
 }
 
 }  // namespace fdt
+
+// ---------------------------------------------------------------------------------------------------
+// Tuning hook (not part of include/fdt.h): time one conv configuration on random data with HIP events.
+// Used by tools/conv_bench.py and tools/autotune.py.
+extern "C" int fdt_debug_conv_bench(int kind, int tile, int ksplit, int B, int Cin, int Hin, int Win,
+                                    int Cout, int has_res, int has_up, int act, int iters, float* ms_out) {
+  using namespace fdt;
+  FDT_REQUIRE(kind >= 0 && kind < CONV_KIND_COUNT && tile >= 0 && tile < CONV_TILE_COUNT && ms_out && iters >= 1,
+              FDT_ERR_ARG, "fdt_debug_conv_bench: bad argument");
+  FDT_REQUIRE(conv_supported((ConvKind)kind, (ConvTile)tile), FDT_ERR_ARG, "kernel not instantiated");
+  const ConvGeom g = conv_geom((ConvKind)kind);
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = B; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout;
+  a.Hout = (Hin + 2 * g.pad - g.dil * (g.kh - 1) - 1) / g.stride + 1;
+  a.Wout = (Win + 2 * g.pad - g.dil * (g.kw - 1) - 1) / g.stride + 1;
+  a.out_ctot = Cout; a.res_ctot = Cout; a.act = act; a.ksplit = ksplit;
+  std::vector<float> w((size_t)Cout * Cin * g.kh * g.kw), tiled;
+  unsigned s = 12345u;
+  for (auto& v : w) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
+  tile_weights(w.data(), nullptr, Cout, Cin, (ConvKind)kind, (ConvTile)tile, tiled);
+  DevBuf din, dw, db, dout, dres, dup, dws;
+  const size_t n_in = (size_t)B * Cin * Hin * Win, n_out = (size_t)B * Cout * a.Hout * a.Wout;
+  FDT_TRY(din.alloc(n_in * 4)); FDT_TRY(dw.alloc(tiled.size() * 4)); FDT_TRY(db.alloc((size_t)Cout * 4));
+  FDT_TRY(dout.alloc(n_out * 4));
+  std::vector<float> hin(n_in);
+  for (auto& v : hin) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
+  FDT_HIP(hipMemcpy(din.p, hin.data(), n_in * 4, hipMemcpyHostToDevice));
+  FDT_HIP(hipMemcpy(dw.p, tiled.data(), tiled.size() * 4, hipMemcpyHostToDevice));
+  FDT_HIP(hipMemset(db.p, 0, (size_t)Cout * 4));
+  a.in = din.as<float>(); a.w = dw.as<float>(); a.bias = db.as<float>(); a.out = dout.as<float>();
+  if (has_res) { FDT_TRY(dres.alloc(n_out * 4)); FDT_HIP(hipMemset(dres.p, 0, n_out * 4)); a.res = dres.as<float>(); }
+  if (has_up) {
+    a.up_h = (a.Hout + 1) / 2; a.up_w = (a.Wout + 1) / 2;
+    FDT_TRY(dup.alloc((size_t)B * Cout * a.up_h * a.up_w * 4));
+    FDT_HIP(hipMemset(dup.p, 0, (size_t)B * Cout * a.up_h * a.up_w * 4));
+    a.up = dup.as<float>();
+  }
+  if (ksplit > 1 || has_up) { FDT_TRY(dws.alloc((size_t)conv_ws_floats(a) * 4)); a.ws = dws.as<float>(); }
+  hipEvent_t e0, e1;
+  FDT_HIP(hipEventCreate(&e0)); FDT_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) FDT_TRY(launch_conv((ConvKind)kind, (ConvTile)tile, a, 0));
+  FDT_HIP(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) FDT_TRY(launch_conv((ConvKind)kind, (ConvTile)tile, a, 0));
+  FDT_HIP(hipEventRecord(e1, 0));
+  FDT_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  FDT_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return FDT_OK;
+}

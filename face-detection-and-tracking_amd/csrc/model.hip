@@ -79,7 +79,14 @@ struct fdt_model {
   bool dry = false;
   std::vector<Tensor> tensors;
   std::vector<Op> ops;
-  std::map<std::string, DevW> wcache;  // key: layer|tile
+  std::map<std::string, DevW> wcache;  // key: layer|kind|tile
+  struct HostW {
+    std::vector<float> w, bias;   // BN-folded OIHW weights (+ fused second conv), bias
+    int Cout = 0, Cin = 0;
+  };
+  std::map<std::string, HostW> host_w;                      // per conv layer, kept for re-tiling
+  std::map<std::string, std::pair<int, int>> hints;         // autotuned (tile, split) per layer
+  int hB = 0, hH = 0, hW = 0;                               // shape the hints were tuned for
   std::vector<void*> plan_allocs;
   std::vector<std::pair<int, int>> levels;  // (H, W) of each detection source
   int P = 0;
@@ -235,23 +242,23 @@ struct Builder {
     }
   }
 
-  // Upload (cached) tiled weights + bias for a conv given concatenated OIHW weights.
-  int device_weights(const std::string& key, const std::vector<float>& w_oihw,
-                     const std::vector<float>& scale, const std::vector<float>& bias, int Cout, int Cin,
-                     ConvKind kind, ConvTile tile, DevW& out) {
+  // Upload (cached) tiled weights + bias of a layer for (kind, tile) from the folded host copy.
+  static int device_weights(fdt_model* m, const std::string& key, ConvKind kind, ConvTile tile, DevW& out) {
     std::string ck = key + "|" + std::to_string((int)kind) + "|" + std::to_string((int)tile);
     auto it = m->wcache.find(ck);
     if (it != m->wcache.end()) {
       out = it->second;
       return FDT_OK;
     }
+    auto hw = m->host_w.find(key);
+    FDT_REQUIRE(hw != m->host_w.end(), FDT_ERR_STATE, "no folded weights for layer %s", key.c_str());
     std::vector<float> tiled;
-    tile_weights(w_oihw.data(), scale.data(), Cout, Cin, kind, tile, tiled);
+    tile_weights(hw->second.w.data(), nullptr, hw->second.Cout, hw->second.Cin, kind, tile, tiled);
     DevW d;
     FDT_HIP(hipMalloc((void**)&d.w, tiled.size() * 4));
     FDT_HIP(hipMemcpy(d.w, tiled.data(), tiled.size() * 4, hipMemcpyHostToDevice));
-    FDT_HIP(hipMalloc((void**)&d.bias, (size_t)Cout * 4));
-    FDT_HIP(hipMemcpy(d.bias, bias.data(), (size_t)Cout * 4, hipMemcpyHostToDevice));
+    FDT_HIP(hipMalloc((void**)&d.bias, (size_t)hw->second.Cout * 4));
+    FDT_HIP(hipMemcpy(d.bias, hw->second.bias.data(), (size_t)hw->second.Cout * 4, hipMemcpyHostToDevice));
     m->wcache[ck] = d;
     out = d;
     return FDT_OK;
@@ -293,7 +300,14 @@ struct Builder {
     op.name = name;
     op.kind = kind;
     int ksplit = 1;
-    choose(kind, Ctot, in.C, Ho, Wo, B, o.up_t >= 0, op.tile, ksplit);
+    auto hint = m->hints.find(name);
+    if (hint != m->hints.end() && m->hB == B && m->hH == m->tensors[0].H && m->hW == m->tensors[0].W &&
+        conv_supported(kind, (ConvTile)hint->second.first)) {
+      op.tile = (ConvTile)hint->second.first;
+      ksplit = hint->second.second;
+    } else {
+      choose(kind, Ctot, in.C, Ho, Wo, B, o.up_t >= 0, op.tile, ksplit);
+    }
     ConvArgs& a = op.ca;
     memset(&a, 0, sizeof(a));
     a.ksplit = ksplit;
@@ -335,8 +349,18 @@ struct Builder {
         for (int c = 0; c < o.cout2; ++c) bias[Cout + c] = b2->v[c];
         wsrc = &wcat;
       }
+      if (!m->host_w.count(name)) {
+        fdt_model::HostW hw;
+        hw.Cout = Ctot;
+        hw.Cin = in.C;
+        hw.bias = bias;
+        hw.w = *wsrc;
+        for (int co = 0; co < Ctot; ++co)
+          for (size_t k = 0; k < per; ++k) hw.w[(size_t)co * per + k] *= scale[co];
+        m->host_w[name] = std::move(hw);
+      }
       DevW dw;
-      int r = device_weights(name, *wsrc, scale, bias, Ctot, in.C, kind, op.tile, dw);
+      int r = device_weights(m, name, kind, op.tile, dw);
       if (r != FDT_OK) return fail(r);
       a.in = in.d;
       a.w = dw.w;
@@ -1054,6 +1078,7 @@ extern "C" int fdt_model_finalize(fdt_model* m) {
     if (kv.second.bias) (void)hipFree(kv.second.bias);
   }
   m->wcache.clear();
+  m->host_w.clear();
   m->finalized = true;
   return FDT_OK;
 }
@@ -1206,6 +1231,104 @@ extern "C" int fdt_model_get_tensor(fdt_model* m, const char* name, float* out, 
   FDT_REQUIRE(max_elems >= n, FDT_ERR_ARG, "fdt_model_get_tensor: buffer too small (%lld < %lld)", max_elems, n);
   FDT_HIP(hipStreamSynchronize(m->stream));
   FDT_HIP(hipMemcpy(out, src, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return FDT_OK;
+}
+
+// Measure every conv layer of the current plan with each instantiated (tile, split-K) candidate on the
+// layer's real buffers (HIP events, min of `iters` runs) and keep the fastest.  The analytic model in
+// Builder::choose is the starting point; this replaces guessing with measurement ("measure, don't guess").
+extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
+  FDT_REQUIRE(m && iters >= 1, FDT_ERR_ARG, "fdt_model_autotune: bad argument");
+  FDT_REQUIRE(m->pB > 0 && !m->ops.empty(), FDT_ERR_STATE, "fdt_model_autotune: run a forward first");
+  FDT_HIP(hipSetDevice(m->device));
+  hipStream_t st = m->stream;
+  FDT_HIP(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  FDT_HIP(hipEventCreate(&e0));
+  FDT_HIP(hipEventCreate(&e1));
+  const long long kMaxWsFloats = 256ll * 1024 * 1024;   // 1 GiB of partial sums at most per candidate
+  int rc = FDT_OK;
+  for (auto& op : m->ops) {
+    if (op.type != OP_CONV) continue;
+    const ConvGeom g = conv_geom(op.kind);
+    const int nstages = ceil_div(op.ca.Cin, g.kc);
+    struct Cand { int tile, split; float ms; };
+    std::vector<Cand> cands;
+    long long ws_need = 0;
+    for (int t = 0; t < CONV_TILE_COUNT; ++t) {
+      if (!conv_supported(op.kind, (ConvTile)t)) continue;
+      for (int split = 1; split <= 64; split *= 2) {
+        if (split > 1 && (split > nstages / 2 || nstages < 8)) break;
+        ConvArgs a = op.ca;
+        a.ksplit = split;
+        long long wsf = conv_ws_floats(a);
+        if (wsf > kMaxWsFloats) break;
+        ws_need = std::max(ws_need, wsf);
+        cands.push_back({t, split, 0.f});
+      }
+    }
+    float* tmp_ws = nullptr;
+    if (ws_need && hipMalloc((void**)&tmp_ws, (size_t)ws_need * 4) != hipSuccess) {
+      set_error("fdt_model_autotune: workspace allocation failed");
+      rc = FDT_ERR_HIP;
+      break;
+    }
+    Cand best{(int)op.tile, op.ca.ksplit, 1e30f};
+    for (auto& c : cands) {
+      DevW dw;
+      rc = Builder::device_weights(m, op.name, op.kind, (ConvTile)c.tile, dw);
+      if (rc != FDT_OK) break;
+      ConvArgs a = op.ca;
+      a.w = dw.w;
+      a.bias = dw.bias;
+      a.ksplit = c.split;
+      a.ws = (c.split > 1 || a.up) ? tmp_ws : nullptr;
+      float best_ms = 1e30f;
+      for (int it = 0; it < iters + 1 && rc == FDT_OK; ++it) {
+        (void)hipEventRecord(e0, st);
+        rc = launch_conv(op.kind, (ConvTile)c.tile, a, st);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) { set_error("autotune: kernel failed"); rc = FDT_ERR_HIP; }
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (it > 0) best_ms = std::min(best_ms, ms);
+      }
+      if (rc != FDT_OK) break;
+      c.ms = best_ms;
+      if (best_ms < best.ms) best = c;
+    }
+    if (tmp_ws) (void)hipFree(tmp_ws);
+    if (rc != FDT_OK) break;
+    DevW dw;
+    rc = Builder::device_weights(m, op.name, op.kind, (ConvTile)best.tile, dw);
+    if (rc != FDT_OK) break;
+    op.tile = (ConvTile)best.tile;
+    op.ca.ksplit = best.split;
+    op.ca.w = dw.w;
+    op.ca.bias = dw.bias;
+    op.needs_ws = best.split > 1 || op.ca.up;
+    m->hints[op.name] = {best.tile, best.split};
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  FDT_TRY(rc);
+  m->hB = m->pB;
+  m->hH = m->pH;
+  m->hW = m->pW;
+  // final shared workspace
+  long long need = 0;
+  for (auto& op : m->ops)
+    if (op.type == OP_CONV && op.needs_ws) need = std::max(need, conv_ws_floats(op.ca));
+  if (need > m->ws_floats || (need && !m->d_convws)) {
+    float* p = nullptr;
+    FDT_HIP(hipMalloc((void**)&p, (size_t)need * 4));
+    m->plan_allocs.push_back(p);
+    m->d_convws = p;
+    m->ws_floats = need;
+  }
+  for (auto& op : m->ops)
+    if (op.type == OP_CONV) op.ca.ws = op.needs_ws ? m->d_convws : nullptr;
+  // re-run the forward once so every activation is consistent with the final plan
   return FDT_OK;
 }
 

@@ -163,6 +163,11 @@ int fdt_model_detect_facebox_dev(fdt_model* m, const void* frames_dev, int forma
 int fdt_model_num_priors(fdt_model* m, int* P);
 int fdt_model_get_tensor(fdt_model* m, const char* name, float* out, long long max_elems,
                          long long* dims4);
+/* After a forward at the shape of interest: time every instantiated (tile, split-K) variant of each
+ * conv layer on its real buffers (min of `iters` runs) and keep the fastest for later forwards at
+ * that shape.  Results stay within the f32 tolerance but are re-associated (not bitwise) vs the
+ * untuned plan.                                                                                  */
+int fdt_model_autotune(fdt_model* m, int iters);
 /* per-op timing of the next forwards (HIP events around every launch on the model stream).
  * fdt_model_profile_read: fills up to max entries; returns count in *n.                      */
 int fdt_model_profile_enable(fdt_model* m, int on);

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Sweep (tile, split-K) for conv shapes with the library's tuning hook.
+    python tools/conv_bench.py                 # the Res50 @1024 layer classes
+    python tools/conv_bench.py K CIN H W COUT [res]   # one shape, all tiles/splits (K = kind index)
+"""
+import ctypes as C
+import importlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+lib = importlib.import_module("face-detection-and-tracking_amd._lib")
+KIND = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2"]
+TILE = ["128x128", "128x64", "128x32", "64x64", "64x128"]
+GEOM = {0: (1, 1), 1: (1, 2), 2: (3, 1), 3: (3, 1), 4: (3, 2), 5: (7, 2), 6: (7, 4), 7: (5, 2)}
+KC = {0: 16, 1: 16, 2: 4, 3: 4, 4: 4, 5: 2, 6: 2, 7: 2}
+
+
+def bench(kind, tile, split, cin, h, w, cout, res=0, up=0, iters=20, B=1):
+    L = lib.lib()
+    L.fdt_debug_conv_bench.restype = C.c_int
+    ms = C.c_float(0)
+    rc = L.fdt_debug_conv_bench(kind, tile, split, B, cin, h, w, cout, res, up, 1, iters, C.byref(ms))
+    return ms.value if rc == 0 else None
+
+
+def sweep(kind, cin, h, w, cout, res=0, up=0, B=1):
+    k, s = GEOM[kind]
+    ho, wo = (h - 1) // s + 1, (w - 1) // s + 1
+    gf = 2.0 * B * ho * wo * cout * cin * k * k / 1e9
+    nst = (cin + KC[kind] - 1) // KC[kind]
+    rows = []
+    for t in range(5):
+        for sp in (1, 2, 4, 8, 16, 32, 64):
+            if sp > 1 and sp > nst // 2:
+                break
+            ms = bench(kind, t, sp, cin, h, w, cout, res, up, B=B)
+            if ms:
+                rows.append((ms, t, sp))
+    rows.sort()
+    print("%s cin %d %dx%d cout %d res %d: %.2f GFLOP" % (KIND[kind], cin, h, w, cout, res, gf))
+    for ms, t, sp in rows[:6]:
+        print("   %-8s /%-2d %8.1f us %7.1f TF/s" % (TILE[t], sp, ms * 1e3, gf / ms))
+    return rows
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 5:
+        a = list(map(int, sys.argv[1:]))
+        sweep(a[0], a[1], a[2], a[3], a[4], a[5] if len(a) > 5 else 0)
+    else:
+        shapes = [(2, 256, 256, 256, 256, 0), (0, 64, 256, 256, 256, 1), (0, 256, 256, 256, 64, 0),
+                  (2, 64, 256, 256, 64, 0), (0, 512, 128, 128, 128, 0), (0, 128, 128, 128, 512, 1),
+                  (2, 128, 128, 128, 128, 0), (0, 1024, 64, 64, 256, 0), (0, 256, 64, 64, 1024, 1),
+                  (2, 256, 64, 64, 256, 0), (0, 2048, 32, 32, 512, 0), (0, 512, 32, 32, 2048, 1),
+                  (2, 512, 32, 32, 512, 0), (0, 2048, 32, 32, 2048, 0), (2, 2048, 32, 32, 256, 0),
+                  (2, 512, 256, 256, 8, 0), (2, 1024, 64, 64, 1024, 0), (3, 256, 256, 256, 128, 0)]
+        for sh in shapes:
+            sweep(*sh)
