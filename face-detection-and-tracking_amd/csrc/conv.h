@@ -27,6 +27,15 @@ enum ConvTile {
   TILE_128x32,       // 8x16 px,  32 ch : narrow heads (Cout = 8) and thin MobileNet layers
   TILE_64x64,        // 8x8  px,  64 ch : small maps
   TILE_64x128,       // 8x8  px, 128 ch : small maps, wide layers
+  TILE_128x128W,     // 4x32 px ("wide"): one 128-byte image row per half wave, conflict-free patch reads
+  TILE_128x64W,
+  TILE_128x128R3,    // R3: ring of three LDS stages (one more stage of LDS-DMA in flight)
+  TILE_128x64R3,
+  TILE_64x64R3,
+  TILE_64x128R3,
+  TILE_128x128WR3,
+  TILE_128x64WR3,
+  TILE_128x32R3,
   CONV_TILE_COUNT
 };
 

@@ -1,0 +1,6 @@
+// Instantiations of conv_kernel<> for one convolution class (compiled in parallel with the others).
+#include "conv_kernel.h"
+
+namespace fdt {
+void conv_fill_3x3_s2(void* row) { fill_row<G_3x3_S2>((KernelEntry*)row); }
+}  // namespace fdt

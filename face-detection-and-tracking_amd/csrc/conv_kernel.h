@@ -1,0 +1,300 @@
+// conv_kernel.h -- the implicit-GEMM convolution kernel template (see conv.hip for the design notes).
+// Included by conv.hip (table, launch) and by one conv_inst_*.hip per convolution class so that the
+// ~70 instantiations compile in parallel.
+#pragma once
+#include "common.h"
+#include "conv.h"
+
+namespace fdt {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KH_, int KW_, int S_, int D_, int PAD_, int KC_>
+struct Geom {
+  static constexpr int KH = KH_, KW = KW_, S = S_, D = D_, PAD = PAD_, KC = KC_;
+  static constexpr int TAPS = KH * KW;
+  // 1x1 strided convs stage only the pixels they use (patch sampling stride = conv stride)
+  static constexpr int PS = (KH == 1 && KW == 1) ? S : 1;
+  static constexpr int LS = S / PS;  // lane-to-lane stride inside the staged patch
+};
+
+template <int TH_, int TW_, int BN_, int WM_, int WN_, int NBUF_>
+struct Tile {
+  static constexpr int TH = TH_, TW = TW_, BM = TH_ * TW_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int NBUF = NBUF_;   // LDS stage buffers: 2 = double buffer, 3 = ring, one stage further ahead
+  static constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
+  // workgroups per CU we want resident (second __launch_bounds__ argument = waves per SIMD)
+  static constexpr int MIN_WAVES = (MI * NI >= 4) ? 3 : 4;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(MI * WM * 32 == BM && NI * WN * 32 == BN, "tile/wave mismatch");
+};
+
+template <class G, class T>
+struct Layout {
+  static constexpr int PH = (T::TH - 1) * G::LS + (G::KH - 1) * G::D + 1;
+  static constexpr int PW = (T::TW - 1) * G::LS + (G::KW - 1) * G::D + 1;
+  static constexpr int XPLANE = PH * PW;
+  static constexpr int XSZ = G::KC * XPLANE;
+  static constexpr int XSZP = (XSZ + 255) / 256 * 256;   // whole LDS-DMA wave-instructions (64 x 4 B)
+  static constexpr int WSZ = G::KC * G::TAPS * T::BN;     // floats per weight stage
+  static constexpr int WSZP = (WSZ + 1023) / 1024 * 1024; // whole LDS-DMA wave-instructions (64 x 16 B)
+  static constexpr int STAGE = XSZP + WSZP;              // floats per LDS buffer
+  static constexpr int NX = XSZP / 256;                  // dword LDS-DMA instructions per wave per stage
+  static constexpr int NW = WSZP / 1024;                 // dwordx4 LDS-DMA instructions per wave per stage
+  static constexpr size_t LDS_BYTES = (size_t)T::NBUF * STAGE * sizeof(float);
+  static constexpr int LOADS = NX + NW;                  // LDS-DMA wave-instructions per stage
+  static_assert(LOADS < 64, "vmcnt is 6 bits");
+  static_assert(G::KC % 2 == 0, "k-pairs are two input channels at one tap");
+  static_assert(NX <= 32, "okmask is 32 bits");
+};
+
+__device__ float g_zero_pad[4];   // source of every padded / out-of-image element (zero-initialised)
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// LDS-DMA: each lane's 4 / 16 bytes go global -> LDS without touching VGPRs.  The LDS address is the
+// wave-uniform `l` + lane * size; the global address is per lane.
+__device__ __forceinline__ void glds4(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 4, 0, 0);
+}
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+template <class G, class T>
+__global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs a) {
+  using L = Layout<G, T>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / T::WN, wn = wave % T::WN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int tiles_x = (a.Wout + T::TW - 1) / T::TW;
+  const int tile_id = blockIdx.x;
+  const int oy0 = (tile_id / tiles_x) * T::TH;
+  const int ox0 = (tile_id % tiles_x) * T::TW;
+  const int n_tile = blockIdx.y;
+  const int b = blockIdx.z / a.ksplit;
+  const int ks = blockIdx.z - b * a.ksplit;
+
+  const int HWin = a.Hin * a.Win;
+  const int HWout = a.Hout * a.Wout;
+  const float* in_b = a.in + (long long)b * a.Cin * HWin;
+  const int nstages = (a.Cin + G::KC - 1) / G::KC;
+  const float* w_t = a.w + (long long)n_tile * nstages * L::WSZP;
+  // this workgroup's share of the reduction (split-K over input-channel stages)
+  const int s_begin = (int)((long long)nstages * ks / a.ksplit);
+  const int s_end = (int)((long long)nstages * (ks + 1) / a.ksplit);
+
+  // ---- per-lane staging plan (invariant over the stages) --------------------------------------------
+  // Element e = 256*k + tid of the [KC][PH][PW] patch is fetched by lane (tid & 63) of wave (tid >> 6)
+  // with its k-th LDS-DMA instruction.  Padding / out-of-image elements read g_zero_pad instead, so
+  // the loads are unconditional and nothing is predicated per lane.
+  int goff[L::NX];
+  unsigned okmask = 0;
+#pragma unroll
+  for (int k = 0; k < L::NX; ++k) {
+    int e = tid + 256 * k;
+    int c = e / L::XPLANE;
+    int r = e - c * L::XPLANE;
+    int yy = r / L::PW, xx = r - yy * L::PW;
+    int gy = oy0 * G::S - G::PAD + yy * G::PS;
+    int gx = ox0 * G::S - G::PAD + xx * G::PS;
+    bool ok = (e < L::XSZ) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+    goff[k] = ok ? (c * HWin + gy * a.Win + gx) : 0;
+    if (ok) okmask |= (1u << k);
+  }
+
+#define FDT_STAGE(s_, buf_)                                                                 \
+  {                                                                                         \
+    const int c0_ = (s_) * G::KC;                                                           \
+    const float* src_ = in_b + (long long)c0_ * HWin;                                       \
+    const int crem_ = a.Cin - c0_;                                                          \
+    float* X_ = smem + (buf_) * L::STAGE + wave * 64;                                       \
+    _Pragma("unroll") for (int k = 0; k < L::NX; ++k) {                                     \
+      const int c_ = (tid + 256 * k) / L::XPLANE;                                           \
+      const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                  \
+      glds4(ok_ ? src_ + goff[k] : g_zero_pad, X_ + 256 * k);                               \
+    }                                                                                       \
+    const float* wsrc_ = w_t + (long long)(s_) * L::WSZP + tid * 4;                         \
+    float* W_ = smem + (buf_) * L::STAGE + L::XSZP + wave * 256;                            \
+    _Pragma("unroll") for (int k = 0; k < L::NW; ++k) glds16(wsrc_ + 1024 * k, W_ + 1024 * k); \
+  }
+
+  // ---- per-lane LDS read offsets ------------------------------------------------------------------
+  int xo[T::MI], wo[T::NI];
+#pragma unroll
+  for (int i = 0; i < T::MI; ++i) {
+    int p = wm * (T::MI * 32) + i * 32 + l31;
+    int py = p / T::TW, px = p % T::TW;
+    xo[i] = half * L::XPLANE + py * G::LS * L::PW + px * G::LS;
+  }
+#pragma unroll
+  for (int j = 0; j < T::NI; ++j)
+    wo[j] = L::XSZP + half * G::TAPS * T::BN + wn * (T::NI * 32) + j * 32 + l31;
+
+  f32x16 acc[T::NI][T::MI];
+#pragma unroll
+  for (int j = 0; j < T::NI; ++j)
+#pragma unroll
+    for (int i = 0; i < T::MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
+
+  // ---- main loop: LDS ring of NBUF stages ---------------------------------------------------------------
+  // Stage it+NBUF-1 is issued (LDS-DMA, nothing in VGPRs) right after the barrier that retires the buffer
+  // it overwrites; stage `it` is waited for with a COUNTED vmcnt (the newer stages stay in flight) and a
+  // raw s_barrier -- __syncthreads() would drain vmcnt(0) and serialise the ring.
+  const int nst = s_end - s_begin;
+#pragma unroll
+  for (int p = 0; p < T::NBUF - 1; ++p)
+    if (p < nst) FDT_STAGE(s_begin + p, p);
+  int cur = 0, nxt = T::NBUF - 1;
+  for (int it = 0; it < nst; ++it) {
+    if (T::NBUF >= 3 && it + 1 < nst)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::LOADS) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + T::NBUF - 1 < nst) FDT_STAGE(s_begin + it + T::NBUF - 1, nxt);
+    const float* S = smem + cur * L::STAGE;
+#pragma unroll
+    for (int t = 0; t < G::TAPS; ++t) {
+#pragma unroll
+      for (int cp = 0; cp < G::KC / 2; ++cp) {
+        const int kx = (2 * cp) * L::XPLANE + (t / G::KW) * G::D * L::PW + (t % G::KW) * G::D;
+        const int kw = ((2 * cp) * G::TAPS + t) * T::BN;
+        float av[T::NI], bv[T::MI];
+#pragma unroll
+        for (int j = 0; j < T::NI; ++j) av[j] = S[wo[j] + kw];
+#pragma unroll
+        for (int i = 0; i < T::MI; ++i) bv[i] = S[xo[i] + kx];
+#pragma unroll
+        for (int j = 0; j < T::NI; ++j)
+#pragma unroll
+          for (int i = 0; i < T::MI; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[i], acc[j][i], 0, 0, 0);
+      }
+    }
+    cur = (cur + 1 == T::NBUF) ? 0 : cur + 1;
+    nxt = (nxt + 1 == T::NBUF) ? 0 : nxt + 1;
+  }
+#undef FDT_STAGE
+
+  // ---- epilogue -------------------------------------------------------------------------------------
+  const int co_base = n_tile * T::BN + wn * (T::NI * 32) + 4 * half;
+  if (a.ws) {
+    // raw partial sums -> workspace [b][ks][Cout][HWout]; splitk_reduce_kernel finishes the layer
+    float* ws = a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWout;
+#pragma unroll
+    for (int i = 0; i < T::MI; ++i) {
+      const int p = wm * (T::MI * 32) + i * 32 + l31;
+      const int oy = oy0 + p / T::TW, ox = ox0 + p % T::TW;
+      const bool pix_ok = oy < a.Hout && ox < a.Wout;
+      const int pix = oy * a.Wout + ox;
+#pragma unroll
+      for (int j = 0; j < T::NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_base + j * 32 + (r & 3) + 8 * (r >> 2);
+          if (pix_ok && co < a.Cout) ws[(long long)co * HWout + pix] = acc[j][i][r];
+        }
+    }
+    return;
+  }
+  float* out_b = a.out + ((long long)b * a.out_ctot + a.out_coff) * HWout;
+  const float* res_b = a.res ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWout : nullptr;
+#pragma unroll
+  for (int i = 0; i < T::MI; ++i) {
+    const int p = wm * (T::MI * 32) + i * 32 + l31;
+    const int oy = oy0 + p / T::TW, ox = ox0 + p % T::TW;
+    const bool pix_ok = oy < a.Hout && ox < a.Wout;
+    const int pix = pix_ok ? oy * a.Wout + ox : 0;
+#pragma unroll
+    for (int j = 0; j < T::NI; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_base + j * 32 + (r & 3) + 8 * (r >> 2);
+        const int coc = co < a.Cout ? co : a.Cout - 1;
+        float v = acc[j][i][r];
+        if (a.bias) v += a.bias[coc];
+        if (res_b) v += res_b[(long long)coc * HWout + pix];
+        if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
+        else if (a.act == ACT_RELU6) v = fminf(fmaxf(v, 0.0f), 6.0f);
+        if (pix_ok && co < a.Cout) out_b[(long long)co * HWout + pix] = v;
+      }
+    }
+  }
+}
+
+
+struct KernelEntry {
+  void (*fn)(const ConvArgs);
+  size_t lds;
+};
+
+//                     TH  TW  BN  WM WN NBUF
+using T_128x128    = Tile<8, 16, 128, 2, 2, 2>;
+using T_128x64     = Tile<8, 16, 64, 2, 2, 2>;
+using T_128x32     = Tile<8, 16, 32, 4, 1, 2>;
+using T_64x64      = Tile<8, 8, 64, 2, 2, 2>;
+using T_64x128     = Tile<8, 8, 128, 1, 4, 2>;
+using T_128x128W   = Tile<4, 32, 128, 2, 2, 2>;   // "wide": 4 rows x 32 px -- one 128-byte row per half wave
+using T_128x64W    = Tile<4, 32, 64, 2, 2, 2>;
+using T_128x128R3  = Tile<8, 16, 128, 2, 2, 3>;   // ring of 3 LDS stages
+using T_128x64R3   = Tile<8, 16, 64, 2, 2, 3>;
+using T_64x64R3    = Tile<8, 8, 64, 2, 2, 3>;
+using T_64x128R3   = Tile<8, 8, 128, 1, 4, 3>;
+using T_128x128WR3 = Tile<4, 32, 128, 2, 2, 3>;
+using T_128x64WR3  = Tile<4, 32, 64, 2, 2, 3>;
+using T_128x32R3   = Tile<8, 16, 32, 4, 1, 3>;
+
+template <class G, class T>
+KernelEntry entry() {
+  return KernelEntry{conv_kernel<G, T>, Layout<G, T>::LDS_BYTES};
+}
+
+template <class G>
+void fill_row(KernelEntry* row) {
+  row[TILE_128x128] = entry<G, T_128x128>();
+  row[TILE_128x64] = entry<G, T_128x64>();
+  row[TILE_128x32] = entry<G, T_128x32>();
+  row[TILE_64x64] = entry<G, T_64x64>();
+  row[TILE_64x128] = entry<G, T_64x128>();
+  row[TILE_128x128W] = entry<G, T_128x128W>();
+  row[TILE_128x64W] = entry<G, T_128x64W>();
+  row[TILE_128x128R3] = entry<G, T_128x128R3>();
+  row[TILE_128x64R3] = entry<G, T_128x64R3>();
+  row[TILE_64x64R3] = entry<G, T_64x64R3>();
+  row[TILE_64x128R3] = entry<G, T_64x128R3>();
+  row[TILE_128x128WR3] = entry<G, T_128x128WR3>();
+  row[TILE_128x64WR3] = entry<G, T_128x64WR3>();
+  row[TILE_128x32R3] = entry<G, T_128x32R3>();
+}
+
+using G_1x1_S1 = Geom<1, 1, 1, 1, 0, 16>;
+using G_1x1_S2 = Geom<1, 1, 2, 1, 0, 16>;
+using G_3x3_S1 = Geom<3, 3, 1, 1, 1, 4>;
+using G_3x3_S1_D2 = Geom<3, 3, 1, 2, 2, 4>;
+using G_3x3_S2 = Geom<3, 3, 2, 1, 1, 4>;
+using G_7x7_S2 = Geom<7, 7, 2, 1, 3, 2>;
+using G_7x7_S4 = Geom<7, 7, 4, 1, 3, 2>;
+using G_5x5_S2 = Geom<5, 5, 2, 1, 2, 2>;
+
+}  // namespace
+
+// one per conv_inst_*.hip
+void conv_fill_1x1_s1(void* row);
+void conv_fill_1x1_s2(void* row);
+void conv_fill_3x3_s1(void* row);
+void conv_fill_3x3_s1_d2(void* row);
+void conv_fill_3x3_s2(void* row);
+void conv_fill_stems(void* row_7x7_s2, void* row_7x7_s4, void* row_5x5_s2);
+
+}  // namespace fdt
