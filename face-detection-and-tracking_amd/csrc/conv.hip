@@ -174,6 +174,74 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a, hipStream_t st)
 }  // namespace fdt
 
 // ---------------------------------------------------------------------------------------------------
+// Stand-alone convolution op (host pointers): F.conv2d + bias + optional fused residual / bilinear x2
+// upsample-add / activation, i.e. one launch of the kernel the detector graphs are made of.  `tile` and
+// `ksplit` select a specific kernel variant (tile < 0 / ksplit <= 0: pick automatically); the parity
+// tests sweep every instantiated variant through this entry point.
+extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const float* w_oihw,
+                          const float* bias, int Cout, int ksize, int stride, int pad, int dil,
+                          const float* residual, const float* up, int up_h, int up_w, int act, int tile,
+                          int ksplit, float* out) {
+  using namespace fdt;
+  FDT_REQUIRE(x && w_oihw && out && B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, FDT_ERR_ARG,
+              "fdt_conv2d: bad argument");
+  int kind = -1;
+  for (int k = 0; k < CONV_KIND_COUNT; ++k) {
+    const ConvGeom g = conv_geom((ConvKind)k);
+    if (g.kh == ksize && g.kw == ksize && g.stride == stride && g.pad == pad && g.dil == dil) kind = k;
+  }
+  FDT_REQUIRE(kind >= 0, FDT_ERR_ARG, "fdt_conv2d: no kernel class for k=%d stride=%d pad=%d dil=%d", ksize,
+              stride, pad, dil);
+  const ConvGeom g = conv_geom((ConvKind)kind);
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = B; a.Cin = Cin; a.Hin = H; a.Win = W; a.Cout = Cout;
+  a.Hout = (H + 2 * g.pad - g.dil * (g.kh - 1) - 1) / g.stride + 1;
+  a.Wout = (W + 2 * g.pad - g.dil * (g.kw - 1) - 1) / g.stride + 1;
+  FDT_REQUIRE(a.Hout >= 1 && a.Wout >= 1, FDT_ERR_ARG, "fdt_conv2d: empty output");
+  a.out_ctot = Cout; a.res_ctot = Cout; a.act = act;
+  if (tile < 0) {
+    tile = -1;
+    for (int t = 0; t < CONV_TILE_COUNT && tile < 0; ++t)
+      if (conv_supported((ConvKind)kind, (ConvTile)t) && (Cout > 64 || tile_bn((ConvTile)t) <= 64)) tile = t;
+    for (int t = 0; t < CONV_TILE_COUNT && tile < 0; ++t)
+      if (conv_supported((ConvKind)kind, (ConvTile)t)) tile = t;
+  }
+  FDT_REQUIRE(tile >= 0 && tile < CONV_TILE_COUNT && conv_supported((ConvKind)kind, (ConvTile)tile), FDT_ERR_ARG,
+              "fdt_conv2d: kernel (kind %d, tile %d) not instantiated", kind, tile);
+  a.ksplit = ksplit > 0 ? ksplit : 1;
+  std::vector<float> tiled;
+  tile_weights(w_oihw, nullptr, Cout, Cin, (ConvKind)kind, (ConvTile)tile, tiled);
+  const size_t n_in = (size_t)B * Cin * H * W, n_out = (size_t)B * Cout * a.Hout * a.Wout;
+  DevBuf din, dw, db, dout, dres, dup, dws;
+  FDT_TRY(din.alloc(n_in * 4)); FDT_TRY(dw.alloc(tiled.size() * 4)); FDT_TRY(dout.alloc(n_out * 4));
+  FDT_HIP(hipMemcpy(din.p, x, n_in * 4, hipMemcpyHostToDevice));
+  FDT_HIP(hipMemcpy(dw.p, tiled.data(), tiled.size() * 4, hipMemcpyHostToDevice));
+  a.in = din.as<float>(); a.w = dw.as<float>(); a.out = dout.as<float>();
+  if (bias) {
+    FDT_TRY(db.alloc((size_t)Cout * 4));
+    FDT_HIP(hipMemcpy(db.p, bias, (size_t)Cout * 4, hipMemcpyHostToDevice));
+    a.bias = db.as<float>();
+  }
+  if (residual) {
+    FDT_TRY(dres.alloc(n_out * 4));
+    FDT_HIP(hipMemcpy(dres.p, residual, n_out * 4, hipMemcpyHostToDevice));
+    a.res = dres.as<float>();
+  }
+  if (up) {
+    FDT_REQUIRE(up_h >= 1 && up_w >= 1, FDT_ERR_ARG, "fdt_conv2d: bad upsample source size");
+    const size_t n_up = (size_t)B * Cout * up_h * up_w;
+    FDT_TRY(dup.alloc(n_up * 4));
+    FDT_HIP(hipMemcpy(dup.p, up, n_up * 4, hipMemcpyHostToDevice));
+    a.up = dup.as<float>(); a.up_h = up_h; a.up_w = up_w;
+  }
+  if (a.ksplit > 1 || a.up) { FDT_TRY(dws.alloc((size_t)conv_ws_floats(a) * 4)); a.ws = dws.as<float>(); }
+  FDT_TRY(launch_conv((ConvKind)kind, (ConvTile)tile, a, 0));
+  FDT_HIP(hipMemcpy(out, dout.p, n_out * 4, hipMemcpyDeviceToHost));
+  return FDT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Tuning hook (not part of include/fdt.h): time one conv configuration on random data with HIP events.
 // Used by tools/conv_bench.py and tools/autotune.py.
 extern "C" int fdt_debug_conv_bench(int kind, int tile, int ksplit, int B, int Cin, int Hin, int Win,

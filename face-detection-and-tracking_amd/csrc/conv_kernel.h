@@ -42,7 +42,14 @@ struct Layout {
   static constexpr int STAGE = XSZP + WSZP;              // floats per LDS buffer
   static constexpr int NX = XSZP / 256;                  // dword LDS-DMA instructions per wave per stage
   static constexpr int NW = WSZP / 1024;                 // dwordx4 LDS-DMA instructions per wave per stage
-  static constexpr size_t LDS_BYTES = (size_t)T::NBUF * STAGE * sizeof(float);
+  // epilogue transpose tile: one NI slice at a time, [WN*32 couts][BM pixels (+4 pad)] floats
+  static constexpr int EROW = T::BM + 4;
+  static constexpr int EPI = T::WN * 32 * EROW;
+  static constexpr int RING = T::NBUF * STAGE;
+  static constexpr size_t LDS_BYTES = (size_t)(RING > EPI ? RING : EPI) * sizeof(float);
+  // 1x1 stride-1: the patch IS the output tile, rows are 16-byte multiples -> stage X with dwordx4 DMA
+  static constexpr bool VECX = (G::KH == 1 && G::KW == 1 && G::S == 1 && (XSZ % 1024) == 0);
+  static constexpr int NXV = XSZ / 1024;
   static constexpr int LOADS = NX + NW;                  // LDS-DMA wave-instructions per stage
   static_assert(LOADS < 64, "vmcnt is 6 bits");
   static_assert(G::KC % 2 == 0, "k-pairs are two input channels at one tap");
@@ -97,6 +104,20 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
   // the loads are unconditional and nothing is predicated per lane.
   int goff[L::NX];
   unsigned okmask = 0;
+  const bool vecx = L::VECX && (a.Win % 4 == 0);
+  if (L::VECX && vecx) {
+    // float4 v = 256*k + tid covers 4 consecutive pixels of one tile row of one channel
+#pragma unroll
+    for (int k = 0; k < L::NXV; ++k) {
+      int v = tid + 256 * k;
+      int c = v / (T::BM / 4);
+      int p = (v - c * (T::BM / 4)) * 4;
+      int gy = oy0 + p / T::TW, gx = ox0 + p % T::TW;
+      bool ok = gy < a.Hin && gx < a.Win;
+      goff[k] = ok ? (c * HWin + gy * a.Win + gx) : 0;
+      if (ok) okmask |= (1u << k);
+    }
+  } else
 #pragma unroll
   for (int k = 0; k < L::NX; ++k) {
     int e = tid + 256 * k;
@@ -115,11 +136,20 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
     const int c0_ = (s_) * G::KC;                                                           \
     const float* src_ = in_b + (long long)c0_ * HWin;                                       \
     const int crem_ = a.Cin - c0_;                                                          \
-    float* X_ = smem + (buf_) * L::STAGE + wave * 64;                                       \
-    _Pragma("unroll") for (int k = 0; k < L::NX; ++k) {                                     \
-      const int c_ = (tid + 256 * k) / L::XPLANE;                                           \
-      const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                  \
-      glds4(ok_ ? src_ + goff[k] : g_zero_pad, X_ + 256 * k);                               \
+    if (L::VECX && vecx) {                                                                  \
+      float* X_ = smem + (buf_) * L::STAGE + wave * 256;                                    \
+      _Pragma("unroll") for (int k = 0; k < L::NXV; ++k) {                                  \
+        const int c_ = (tid + 256 * k) / (T::BM / 4);                                       \
+        const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                \
+        glds16(ok_ ? src_ + goff[k] : g_zero_pad, X_ + 1024 * k);                           \
+      }                                                                                     \
+    } else {                                                                                \
+      float* X_ = smem + (buf_) * L::STAGE + wave * 64;                                     \
+      _Pragma("unroll") for (int k = 0; k < L::NX; ++k) {                                   \
+        const int c_ = (tid + 256 * k) / L::XPLANE;                                         \
+        const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                \
+        glds4(ok_ ? src_ + goff[k] : g_zero_pad, X_ + 256 * k);                             \
+      }                                                                                     \
     }                                                                                       \
     const float* wsrc_ = w_t + (long long)(s_) * L::WSZP + tid * 4;                         \
     float* W_ = smem + (buf_) * L::STAGE + L::XSZP + wave * 256;                            \
@@ -156,10 +186,16 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
     if (p < nst) FDT_STAGE(s_begin + p, p);
   int cur = 0, nxt = T::NBUF - 1;
   for (int it = 0; it < nst; ++it) {
-    if (T::NBUF >= 3 && it + 1 < nst)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::LOADS) : "memory");
-    else
+    // leave exactly the newest stage's LDS-DMA instructions in flight (their count differs between
+    // the dword and the dwordx4 staging of X)
+    if (T::NBUF >= 3 && it + 1 < nst) {
+      if (L::VECX && vecx)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NXV + L::NW) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::LOADS) : "memory");
+    } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (it + T::NBUF - 1 < nst) FDT_STAGE(s_begin + it + T::NBUF - 1, nxt);
@@ -189,6 +225,67 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
 
   // ---- epilogue -------------------------------------------------------------------------------------
   const int co_base = n_tile * T::BN + wn * (T::NI * 32) + 4 * half;
+  if (a.Wout % 4 == 0) {
+    // Vector path: transpose each 32-cout slice through LDS so that every lane owns 4 consecutive
+    // pixels of one output channel -> 16-byte residual loads and stores (4x fewer VMEM instructions,
+    // whole 64/128-byte row segments per 4/8 lanes).  The stage ring is dead by now and is reused.
+    float* E = smem;
+    float* dst_b;
+    long long dst_cstride = HWout;
+    const bool raw = a.ws != nullptr;
+    if (raw)
+      dst_b = a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWout;
+    else
+      dst_b = a.out + ((long long)b * a.out_ctot + a.out_coff) * HWout;
+    const float* res_b = (!raw && a.res) ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWout : nullptr;
+    constexpr int ROWS = T::WN * 32;
+    constexpr int C4 = T::BM / 4;
+    constexpr int PER = (ROWS * C4 + 255) / 256;
+#pragma unroll
+    for (int j = 0; j < T::NI; ++j) {
+      __syncthreads();   // previous pass consumed / main loop finished reading the ring
+#pragma unroll
+      for (int i = 0; i < T::MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          E[row * L::EROW + wm * (T::MI * 32) + i * 32 + l31] = acc[j][i][r];
+        }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int idx = tid + 256 * q;
+        if (idx < ROWS * C4) {
+          const int row = idx / C4, c4 = idx - row * C4;
+          const int p = c4 * 4;
+          const int oy = oy0 + p / T::TW, ox = ox0 + p % T::TW;
+          const int co = n_tile * T::BN + (row >> 5) * (T::NI * 32) + j * 32 + (row & 31);
+          if (oy < a.Hout && ox < a.Wout && co < a.Cout) {
+            float4 v = *reinterpret_cast<const float4*>(E + row * L::EROW + p);
+            const long long off = (long long)co * dst_cstride + (long long)oy * a.Wout + ox;
+            if (!raw) {
+              if (a.bias) {
+                const float bv = a.bias[co];
+                v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+              }
+              if (res_b) {
+                const float4 rv = *reinterpret_cast<const float4*>(res_b + off);
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+              }
+              if (a.act == ACT_RELU) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+              } else if (a.act == ACT_RELU6) {
+                v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
+                v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+              }
+            }
+            *reinterpret_cast<float4*>(dst_b + off) = v;
+          }
+        }
+      }
+    }
+    return;
+  }
   if (a.ws) {
     // raw partial sums -> workspace [b][ks][Cout][HWout]; splitk_reduce_kernel finishes the layer
     float* ws = a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWout;

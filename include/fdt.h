@@ -100,6 +100,16 @@ int fdt_facebox_anchors(float* out);
 int fdt_facebox_decode(const float* loc, const float* conf, const float* anchors, int P,
                        float conf_thresh, float nms_thresh, float* boxes, float* probs, int* count);
 
+/* nn.Conv2d / F.conv2d as the nets use it (pyramid.py:14,35-39,58-59,83-94; pyramid_mb2_try3.py:16,98,
+ * 113; FACEBOX/networks.py:13,63-66), NCHW f32, OIHW weights, with the fusions of the forward graphs:
+ * + bias, + residual [B,Cout,Ho,Wo], + bilinear x2 (align_corners=False) upsample of up [B,Cout,uh,uw]
+ * (pyramid.py:65-68), then act (0 none, 1 ReLU, 2 ReLU6).  (ksize,stride,pad,dil) must be one of the
+ * instantiated classes: 1x1 s1|s2 p0; 3x3 s1 p1; 3x3 s1 p2 d2; 3x3 s2 p1; 7x7 s2 p3; 7x7 s4 p3; 5x5 s2 p2.
+ * tile/ksplit pick a kernel variant explicitly (tile < 0, ksplit <= 0: automatic).                  */
+int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const float* w_oihw, const float* bias,
+               int Cout, int ksize, int stride, int pad, int dil, const float* residual, const float* up,
+               int up_h, int up_w, int act, int tile, int ksplit, float* out);
+
 /* ------------------------------------------------------------------ IoU tracker
  * The inline tracker of iouTracke_cal.py:113-156 (per frame) and :174-177 (finalise), as a
  * device-resident state machine.  A track is {bboxes, max_score, start_frame}.               */

@@ -174,3 +174,22 @@ def test_try3_vs_reference_fixture(try3, synth, key):
     d_iou, d_sc = match_detections(y[0, 1], np.vstack([exp, np.zeros((750 - exp.shape[0], 5), np.float32)]),
                                    m["n_out"])
     assert d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
+
+
+def test_autotuned_plan_keeps_parity(res50, res50_sd, synth):
+    """The autotuner may pick any instantiated (tile, split-K) variant per layer (ring / wide tiles,
+    vector staging): the tuned forward must stay inside the same tolerance as the default plan."""
+    H, W = 192, 256
+    frame = synth.make_frames(1, H, W, seed=41)[0]
+    res50.priorbox = M("layers").PriorBoxLayer(W, H); res50.firstTime = True
+    res50.detect = M("layers").Detect(2, 0, 750, 0.05, 0.35)
+    res50(frame)
+    res50.autotune(2)
+    y = res50(frame).numpy()
+    o = opb.res50_forward(res50_sd, opb.preprocess(frame), want=["c2", "c5", "src0", "src3", "src5"])
+    for st in ["c2", "c5", "src0", "src3", "src5"]:
+        assert rel_rms(res50.get_tensor(st), o[st]) < STAGE_RTOL, st
+    exp = opp.Detect(2, 0, 750, 0.05, 0.35)(o["loc"], o["conf"], opp.build_priors(opp.PriorBoxLayer(W, H), H, W))
+    n = int((exp[0, 1, :, 0] > 0).sum())
+    d_iou, d_sc = match_detections(y[0, 1], exp[0, 1], n)
+    assert n > 10 and d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
