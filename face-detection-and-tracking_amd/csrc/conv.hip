@@ -29,38 +29,71 @@ namespace fdt {
 namespace {
 
 // Second pass of a split-K layer: out = act(sum_ks partial + bias + upsample + residual).  Fixed
-// summation order -> bitwise reproducible (no float atomics).  One thread per 4 consecutive pixels.
+// summation order -> bitwise reproducible (no float atomics).  VEC = 4: one thread per 4 consecutive
+// pixels with 16-byte accesses (Wout % 4 == 0), else one pixel per thread.
+template <int VEC>
 __global__ void splitk_reduce_kernel(const ConvArgs a) {
   const int HWout = a.Hout * a.Wout;
-  const long long total = (long long)a.B * a.Cout * HWout;
+  const int HWv = HWout / VEC;
+  const long long total = (long long)a.B * a.Cout * HWv;
   long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x);
   if (t >= total) return;
-  const int pix = (int)(t % HWout);
-  const int co = (int)((t / HWout) % a.Cout);
-  const int b = (int)(t / ((long long)HWout * a.Cout));
-  float v = 0.0f;
+  const int pix = (int)(t % HWv) * VEC;
+  const int co = (int)((t / HWv) % a.Cout);
+  const int b = (int)(t / ((long long)HWv * a.Cout));
+  float v[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) v[e] = 0.0f;
   const float* ws = a.ws + ((long long)b * a.ksplit * a.Cout + co) * HWout + pix;
-  for (int k = 0; k < a.ksplit; ++k) v += ws[(long long)k * a.Cout * HWout];
-  if (a.bias) v += a.bias[co];
-  if (a.up) {
-    const int oy = pix / a.Wout, ox = pix % a.Wout;
-    float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.0f);
-    float sx = fmaxf(0.5f * (ox + 0.5f) - 0.5f, 0.0f);
-    int y0 = (int)sy, x0 = (int)sx;
-    y0 = y0 < a.up_h - 1 ? y0 : a.up_h - 1;
-    x0 = x0 < a.up_w - 1 ? x0 : a.up_w - 1;
-    const int y1 = y0 + (y0 < a.up_h - 1 ? 1 : 0);
-    const int x1 = x0 + (x0 < a.up_w - 1 ? 1 : 0);
-    const float ly = sy - (float)y0, lx = sx - (float)x0;
-    const float* u = a.up + ((long long)b * a.Cout + co) * a.up_h * a.up_w;
-    const float top = (1.0f - lx) * u[y0 * a.up_w + x0] + lx * u[y0 * a.up_w + x1];
-    const float bot = (1.0f - lx) * u[y1 * a.up_w + x0] + lx * u[y1 * a.up_w + x1];
-    v += (1.0f - ly) * top + ly * bot;
+  const long long kstride = (long long)a.Cout * HWout;
+  for (int k = 0; k < a.ksplit; ++k) {
+    if (VEC == 4) {
+      const float4 p = *reinterpret_cast<const float4*>(ws + k * kstride);
+      v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+    } else {
+      v[0] += ws[k * kstride];
+    }
   }
-  if (a.res) v += a.res[((long long)b * a.res_ctot + a.res_coff + co) * HWout + pix];
-  if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
-  else if (a.act == ACT_RELU6) v = fminf(fmaxf(v, 0.0f), 6.0f);
-  a.out[((long long)b * a.out_ctot + a.out_coff + co) * HWout + pix] = v;
+  const float bv = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) v[e] += bv;
+  if (a.up) {
+    const float* u = a.up + ((long long)b * a.Cout + co) * a.up_h * a.up_w;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int oy = (pix + e) / a.Wout, ox = (pix + e) % a.Wout;
+      float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.0f);
+      float sx = fmaxf(0.5f * (ox + 0.5f) - 0.5f, 0.0f);
+      int y0 = (int)sy, x0 = (int)sx;
+      y0 = y0 < a.up_h - 1 ? y0 : a.up_h - 1;
+      x0 = x0 < a.up_w - 1 ? x0 : a.up_w - 1;
+      const int y1 = y0 + (y0 < a.up_h - 1 ? 1 : 0);
+      const int x1 = x0 + (x0 < a.up_w - 1 ? 1 : 0);
+      const float ly = sy - (float)y0, lx = sx - (float)x0;
+      const float top = (1.0f - lx) * u[y0 * a.up_w + x0] + lx * u[y0 * a.up_w + x1];
+      const float bot = (1.0f - lx) * u[y1 * a.up_w + x0] + lx * u[y1 * a.up_w + x1];
+      v[e] += (1.0f - ly) * top + ly * bot;
+    }
+  }
+  const long long ooff = ((long long)b * a.out_ctot + a.out_coff + co) * HWout + pix;
+  if (a.res) {
+    const float* r = a.res + ((long long)b * a.res_ctot + a.res_coff + co) * HWout + pix;
+    if (VEC == 4) {
+      const float4 p = *reinterpret_cast<const float4*>(r);
+      v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+    } else {
+      v[0] += r[0];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    if (a.act == ACT_RELU) v[e] = fmaxf(v[e], 0.0f);
+    else if (a.act == ACT_RELU6) v[e] = fminf(fmaxf(v[e], 0.0f), 6.0f);
+  }
+  if (VEC == 4)
+    *reinterpret_cast<float4*>(a.out + ooff) = make_float4(v[0], v[1], v[2], v[3]);
+  else
+    a.out[ooff] = v[0];
 }
 
 struct Table {
@@ -165,7 +198,10 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a, hipStream_t st)
   FDT_LAUNCH_CHECK();
   if (a.ws) {
     const long long total = (long long)a.B * a.Cout * a.Hout * a.Wout;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div_ll(total, 256)), dim3(256), 0, st, a);
+    if (a.Wout % 4 == 0)
+      hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)ceil_div_ll(total / 4, 256)), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)ceil_div_ll(total, 256)), dim3(256), 0, st, a);
     FDT_LAUNCH_CHECK();
   }
   return FDT_OK;
