@@ -42,7 +42,10 @@ def main():
     ap.add_argument("--unique-frames", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--profile-frames", type=int, default=4)
-    ap.add_argument("--autotune", type=int, default=1, help="autotune (tile, split-K) per conv layer at start-up")
+    ap.add_argument("--autotune", type=int, default=1,
+                    help="1: use the committed tuned plan for this shape if there is one, else autotune (tile, split-K) "
+                         "per conv layer at start-up; 2: always autotune; 0: analytic model only")
+    ap.add_argument("--save-plan", type=int, default=0, help="write the autotuned plan under tuned/")
     ap.add_argument("--inflight", type=int, default=3,
                     help="frames in flight per GPU: consecutive batch-1 steps overlap on separate HIP streams "
                          "(detection of frame i+1 runs beside the tail / tracker step of frame i)")
@@ -87,10 +90,21 @@ def main():
         n.load_state_dict(sd)
         n.cuda(); n.eval()
         n._sync_attributes(H, W)
-        if args.autotune:
+        plan_file = os.path.join(ROOT, "face-detection-and-tracking_amd", "tuned",
+                                 "%s_%dx%d_b1.plan" % (args.arch, H, W))
+        if args.autotune == 1 and os.path.exists(plan_file):
+            n.import_plan(open(plan_file).read())      # committed result of an earlier autotune on MI355X
+            plan_src = "tuned/" + os.path.basename(plan_file)
+        elif args.autotune:
             # plan-time measurement of every (tile, split-K) variant per layer; outside the timed region
             n(synth.make_frames(1, H, W, seed=99)[0])
             n.autotune(3)
+            plan_src = "autotuned at start-up"
+            if args.save_plan and not nets:
+                with open(plan_file, "w") as f:
+                    f.write(n.export_plan())
+        else:
+            plan_src = "analytic model"
         nets.append(n)
     net = nets[0]
     top_k = net.detect.top_k
@@ -183,8 +197,16 @@ def main():
         net.profile(False)
         cms = float(np.mean(conv_ms))
         achieved = flops / (cms * 1e-3) / 1e12
+        # HBM bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+        # command (PMC cannot be read from inside the process); the committed summary is quoted here.
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, "profiles", "r01", "conv_hbm_traffic.json")
+        if args.arch == "res50" and H == 1024 and os.path.exists(tj):
+            tdata = json.load(open(tj))
+            traffic = round(tdata["hbm_bytes_per_launch"])
+            traffic_src = "profiles/r01/conv_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "conv_kernel (f32 MFMA implicit GEMM)", "launches_per_frame": n_conv,
                 "avg_launch_us": round(cms * 1e3 / n_conv, 2), "conv_ms_per_frame": round(cms, 3),
                 "other_ms_per_frame": round(float(np.mean(other_ms)), 3),
@@ -226,7 +248,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "PyramidBox-%s %dx%d synthetic u8 frames, batch=1 per GPU, decode+NMS+IoU-tracker "
                                    "on device" % ("Res50" if args.arch == "res50" else "MobileNetV2-try3", H, W),
-                       "frames_per_step": world, "frames_in_flight_per_gpu": NF, "autotuned": bool(args.autotune), "parallelism": "frame-parallel x%d%s" % (
+                       "frames_per_step": world, "frames_in_flight_per_gpu": NF, "kernel_plan": plan_src, "parallelism": "frame-parallel x%d%s" % (
                            world, ", RCCL all-gather of box lists" if world > 1 else ""),
                        "weights": "seeded synthetic (seed 0)", "detections_last_frame": n_cand_last,
                        "tracks": len(tracks), "gpu_ms_per_step_events": round(gpu_ms / args.steps, 4),

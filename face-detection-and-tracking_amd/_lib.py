@@ -80,6 +80,8 @@ SIGNATURES = {
     "fdt_model_num_priors": (C.c_int, [_vp, _c_int_p]),
     "fdt_model_get_tensor": (C.c_int, [_vp, C.c_char_p, _vp, C.c_longlong, _c_i64_p]),
     "fdt_model_autotune": (C.c_int, [_vp, C.c_int]),
+    "fdt_model_export_plan": (C.c_int, [_vp, C.c_char_p, C.c_int, _c_int_p]),
+    "fdt_model_import_plan": (C.c_int, [_vp, C.c_char_p]),
     "fdt_model_profile_enable": (C.c_int, [_vp, C.c_int]),
     "fdt_model_profile_read": (C.c_int, [_vp, C.c_int, C.c_char_p, _vp, _vp, _c_int_p]),
     "fdt_model_flops": (C.c_int, [_vp, _c_f64_p]),

@@ -191,6 +191,18 @@ class DetectorNet:
         """Measure every (tile, split-K) variant per conv layer at the last forward's shape, keep the best."""
         _lib.check(_lib.lib().fdt_model_autotune(self._h, int(iters)))
 
+    def export_plan(self):
+        """Text form of the current per-layer kernel plan (see fdt_model_export_plan)."""
+        L = _lib.lib()
+        need = C.c_int(0)
+        _lib.check(L.fdt_model_export_plan(self._h, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value)
+        _lib.check(L.fdt_model_export_plan(self._h, buf, need.value, C.byref(need)))
+        return buf.value.decode()
+
+    def import_plan(self, text):
+        _lib.check(_lib.lib().fdt_model_import_plan(self._h, text.encode()))
+
     def flops_per_frame(self):
         f = C.c_double(0)
         _lib.check(_lib.lib().fdt_model_flops(self._h, C.byref(f)))

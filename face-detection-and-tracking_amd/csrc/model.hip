@@ -304,7 +304,7 @@ struct Builder {
     if (hint != m->hints.end() && m->hB == B && m->hH == m->tensors[0].H && m->hW == m->tensors[0].W &&
         conv_supported(kind, (ConvTile)hint->second.first)) {
       op.tile = (ConvTile)hint->second.first;
-      ksplit = hint->second.second;
+      ksplit = std::max(1, std::min(hint->second.second, ceil_div(in.C, g.kc)));
     } else {
       choose(kind, Ctot, in.C, Ho, Wo, B, o.up_t >= 0, op.tile, ksplit);
     }
@@ -1329,6 +1329,52 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   for (auto& op : m->ops)
     if (op.type == OP_CONV) op.ca.ws = op.needs_ws ? m->d_convws : nullptr;
   // re-run the forward once so every activation is consistent with the final plan
+  return FDT_OK;
+}
+
+// Plan hints as text: one "layer tile split" line per conv layer, first line "shape B H W".
+extern "C" int fdt_model_export_plan(fdt_model* m, char* buf, int buflen, int* needed) {
+  FDT_REQUIRE(m && needed, FDT_ERR_ARG, "fdt_model_export_plan: bad argument");
+  FDT_REQUIRE(m->pB > 0, FDT_ERR_STATE, "fdt_model_export_plan: no plan yet");
+  std::string out = "shape " + std::to_string(m->pB) + " " + std::to_string(m->pH) + " " + std::to_string(m->pW) + "\n";
+  for (auto& op : m->ops)
+    if (op.type == OP_CONV)
+      out += op.name + " " + std::to_string((int)op.tile) + " " + std::to_string(op.ca.ksplit) + "\n";
+  *needed = (int)out.size() + 1;
+  if (buf && buflen >= *needed) memcpy(buf, out.c_str(), out.size() + 1);
+  return FDT_OK;
+}
+
+extern "C" int fdt_model_import_plan(fdt_model* m, const char* text) {
+  FDT_REQUIRE(m && text, FDT_ERR_ARG, "fdt_model_import_plan: bad argument");
+  std::map<std::string, std::pair<int, int>> hints;
+  int B = 0, H = 0, W = 0;
+  const char* p = text;
+  while (*p) {
+    const char* e = strchr(p, '\n');
+    std::string line = e ? std::string(p, e - p) : std::string(p);
+    p = e ? e + 1 : p + line.size();
+    if (line.empty()) continue;
+    char name[256];
+    int a = 0, b = 0, c = 0;
+    if (sscanf(line.c_str(), "shape %d %d %d", &a, &b, &c) == 3) {
+      B = a; H = b; W = c;
+    } else if (sscanf(line.c_str(), "%255s %d %d", name, &a, &b) == 3) {
+      FDT_REQUIRE(a >= 0 && a < CONV_TILE_COUNT && b >= 1 && b <= 4096, FDT_ERR_ARG,
+                  "fdt_model_import_plan: bad entry '%s'", line.c_str());
+      hints[name] = {a, b};
+    } else {
+      set_error("fdt_model_import_plan: cannot parse '%s'", line.c_str());
+      return FDT_ERR_ARG;
+    }
+  }
+  FDT_REQUIRE(B > 0 && H > 0 && W > 0, FDT_ERR_ARG, "fdt_model_import_plan: missing shape line");
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  m->free_plan();          // the next forward at this shape builds the plan from the hints
+  m->hints = std::move(hints);
+  m->hB = B;
+  m->hH = H;
+  m->hW = W;
   return FDT_OK;
 }
 

@@ -178,6 +178,10 @@ int fdt_model_get_tensor(fdt_model* m, const char* name, float* out, long long m
  * that shape.  Results stay within the f32 tolerance but are re-associated (not bitwise) vs the
  * untuned plan.                                                                                  */
 int fdt_model_autotune(fdt_model* m, int iters);
+/* Persist / restore the per-layer kernel choice as text ("shape B H W" then "layer tile split" lines)
+ * so a tuned plan is reproducible across processes.  export: *needed = bytes incl. NUL; buf may be NULL. */
+int fdt_model_export_plan(fdt_model* m, char* buf, int buflen, int* needed);
+int fdt_model_import_plan(fdt_model* m, const char* text);
 /* per-op timing of the next forwards (HIP events around every launch on the model stream).
  * fdt_model_profile_read: fills up to max entries; returns count in *n.                      */
 int fdt_model_profile_enable(fdt_model* m, int on);
