@@ -219,19 +219,33 @@ def main():
                 "algorithmic_gflop_per_frame": round(flops / 1e9, 3)}
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample ---------------------------
-    cpu = None
+    cpu, parity = None, None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         from oracle import postproc as opp
         from oracle import pyramidbox as opb
         ncores = torch.get_num_threads()
         ref_trk = opp.IouTracker(0.4, 0.6, 5)
-        times = []
+        times, ref_dets, gpu_dets = [], [], []
         for i in range(args.cpu_frames):
             t1 = time.perf_counter()
             y = opb.detect_frame(sd, frames_h[i % args.unique_frames], args.arch)
+            det_ref = opp.unpack_detections(y, W, H, 0.4)
             with np.errstate(all="ignore"):
-                ref_trk.step(opp.unpack_detections(y, W, H, 0.4))
+                ref_trk.step(det_ref)
             times.append(time.perf_counter() - t1)
+            # parity of the same frames on the GPU path (checker only; not timed)
+            yg = net(frames_h[i % args.unique_frames]).numpy()
+            ref_dets.append(det_ref)
+            gpu_dets.append(opp.unpack_detections(yg, W, H, 0.4))
+        ap, n_truth, n_pred = opp.ap_against_reference(gpu_dets, ref_dets, 0.5)
+        iou_def = 0.0
+        for g, r in zip(gpu_dets, ref_dets):
+            if g.shape == r.shape and r.shape[0]:
+                with np.errstate(all="ignore"):
+                    iou_def = max(iou_def, float((1 - opp.calculate_iou(r[:, :4].astype(np.float64),
+                                                                         g[:, :4].astype(np.float64)).max(1)).max()))
+        parity = {"ap_vs_cpu_ref": round(ap, 6), "ref_boxes": n_truth, "gpu_boxes": n_pred,
+                  "max_iou_deficit": float("%.3g" % iou_def), "frames": len(ref_dets)}
         per = float(np.mean(times[1:])) if len(times) > 1 else times[0]
         cpu = {"value": round(1.0 / per, 4), "unit": "frames/s", "cores": ncores, "kind": "port",
                "sample": "%d frames of the same %dx%d workload after 1 warm-up (oracle/: torch-CPU convs + numpy "
@@ -261,6 +275,7 @@ def main():
                        "device": pkg.device_name(local_rank)},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "parity": parity,
         }
         print(json.dumps(line))
     if world > 1:

@@ -269,3 +269,35 @@ class IouTracker:
                                  if t['max_score'] > self.sigma_h
                                  and len(t['bboxes']) >= self.t_min]   # :174-175
         return self.tracks_finished
+
+
+# --------------------------------------------------------------------------- PR metric
+def gen_tp_fp(tf_conf):
+    """Restates reference draw_curve/draw_pr_roc.py:5-19 (the explicit loop)."""
+    _, M = tf_conf.shape
+    true_pos, false_pos = np.zeros(M), np.zeros(M)
+    for i in range(1, M + 1):
+        true_pos[i - 1] = np.count_nonzero(tf_conf[0, :i])
+        false_pos[i - 1] = i - true_pos[i - 1]
+    return true_pos, false_pos
+
+
+def ap_against_reference(pred_list, ref_list, iou_thresh=0.5):
+    """"mAP vs CPU ref" (SURVEY.md 8(d)): treat the CPU-reference detections of every frame as ground
+    truth, match the candidate detections with calc_pr semantics (calc_performance.py:77-92), sort by
+    score (My_test.py:169) and integrate the PR curve of draw_pr_roc.py:28-31.
+    pred_list / ref_list: per frame arrays [n,5] (x1,y1,x2,y2,score)."""
+    tf_conf = np.zeros((2, 0))
+    truth_num = 0
+    for pred, ref in zip(pred_list, ref_list):
+        truth = np.column_stack((ref[:, 0], ref[:, 1], ref[:, 2] - ref[:, 0], ref[:, 3] - ref[:, 1]))
+        with np.errstate(all="ignore"):
+            tf, tn = calc_pr(np.asarray(pred, dtype=np.float64), truth.astype(np.float64), iou_thresh)
+        tf_conf = np.hstack((tf_conf, tf))
+        truth_num += tn
+    tf_conf = tf_conf[:, np.argsort(tf_conf[1, :], kind="stable")[::-1]]
+    tp, fp = gen_tp_fp(tf_conf)
+    recall = tp / max(truth_num, 1)
+    precision = tp / np.maximum(tp + fp, 1)
+    r = np.concatenate([[0.0], recall])
+    return float(np.sum((r[1:] - r[:-1]) * precision)), int(truth_num), int(tf_conf.shape[1])

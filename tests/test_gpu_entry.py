@@ -58,3 +58,29 @@ def test_track_device_resident_equals_host_and_oracle(entry, synth, tmp_path):
     entry.save_tracks(t_dev, p)
     back = np.load(p, allow_pickle=True).tolist()
     assert back == t_dev and set(back[0]) == {"bboxes", "max_score", "start_frame"}
+
+
+def test_my_test_evaluation_harness(synth):
+    """Config-1 plumbing (reference My_test.py): per-image priorbox reset, threshold-0 row walk (all
+    2x750 zero-padded rows pass), calc_pr accumulation; PR data == oracle's on the same detections."""
+    mt = M("My_test")
+    pr = M("draw_curve.draw_pr_roc")
+    net = M("pyramid").build_sfd('test', 640, 2)
+    net.load_state_dict(synth.make_state_dict("res50", seed=0, conf_shift=-3.0))
+    mt.net, mt.net_name, mt.threshold = net, 'repo', 0.0
+    frames = synth.make_frames(2, 96, 128, seed=3)
+    det = mt.detect_face(frames[0])
+    assert det.shape == (1500, 5)                      # SURVEY.md 3.3 quirk: 2 x 750 rows at threshold 0
+    mt.threshold = 0.5
+    samples = []
+    for f in frames:
+        d = mt.detect_face(f)
+        truth = np.column_stack((d[:3, 0], d[:3, 1], d[:3, 2] - d[:3, 0], d[:3, 3] - d[:3, 1]))
+        samples.append((f, truth))
+    data = mt.evaluate(samples, 0.5)
+    assert data.shape[0] == 2 and data[1, -1] == 6 and data[0, -1] == 0
+    rec, prec, fp = pr.pr_roc(data)
+    tp_o, fp_o = opp.gen_tp_fp(data[:, :-1])
+    assert np.array_equal(fp, fp_o) and np.array_equal(rec, tp_o / 6)
+    assert rec[-1] == 1.0 and 0 < pr.average_precision(data) <= 1.0
+    net.close()
