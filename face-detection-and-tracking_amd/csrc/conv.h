@@ -17,6 +17,7 @@ enum ConvKind {
   CONV_7x7_S2,      // pad 3 (Res50 stem)
   CONV_7x7_S4,      // pad 3 (FaceBox conv1)
   CONV_5x5_S2,      // pad 2 (FaceBox conv2)
+  CONV_3x3_S1_WINO, // same arithmetic class as CONV_3x3_S1, computed with Winograd F(2x2,3x3)
   CONV_KIND_COUNT
 };
 
@@ -36,6 +37,14 @@ enum ConvTile {
   TILE_128x128WR3,
   TILE_128x64WR3,
   TILE_128x32R3,
+  // Winograd tiles (only valid with CONV_3x3_S1_WINO): <2x2 blocks> x <couts>
+  TILE_WINO_64x64,     // 16x16 px,  64 ch
+  TILE_WINO_64x64R3,
+  TILE_WINO_128x32,    // 16x32 px,  32 ch
+  TILE_WINO_128x32R3,
+  TILE_WINO_32x128,    //  8x16 px, 128 ch
+  TILE_WINO_32x128R3,
+  TILE_WINO_64x64W,    //  8x32 px,  64 ch
   CONV_TILE_COUNT
 };
 
@@ -43,7 +52,10 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2 };
 
 struct ConvGeom {   // static description of one kernel class
   int kh, kw, stride, dil, pad, kc;   // kc = input channels per LDS stage
+  int wino;                           // 1: weights are stored Winograd-transformed (16 taps)
 };
+// The kind a layer's arithmetic belongs to (CONV_3x3_S1_WINO -> CONV_3x3_S1).
+ConvKind conv_base_kind(ConvKind k);
 ConvGeom conv_geom(ConvKind k);
 int tile_bm(ConvTile t);
 int tile_bn(ConvTile t);

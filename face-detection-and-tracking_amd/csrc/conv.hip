@@ -24,6 +24,7 @@
 //  * Fused epilogue: + bias (folded BN), + residual, + bilinear-upsampled coarser map, ReLU/ReLU6,
 //    direct write into a channel slice of the destination (kills torch.cat / permute).
 #include "conv_kernel.h"
+#include "conv_wino.h"
 
 namespace fdt {
 namespace {
@@ -108,6 +109,7 @@ struct Table {
     conv_fill_3x3_s1_d2(e[CONV_3x3_S1_D2]);
     conv_fill_3x3_s2(e[CONV_3x3_S2]);
     conv_fill_stems(e[CONV_7x7_S2], e[CONV_7x7_S4], e[CONV_5x5_S2]);
+    conv_fill_wino(e[CONV_3x3_S1_WINO]);
   }
 };
 
@@ -117,17 +119,22 @@ Table& table() {
 }
 
 const ConvGeom kGeoms[CONV_KIND_COUNT] = {
-    {1, 1, 1, 1, 0, 16}, {1, 1, 2, 1, 0, 16}, {3, 3, 1, 1, 1, 4}, {3, 3, 1, 2, 2, 4},
-    {3, 3, 2, 1, 1, 4},  {7, 7, 2, 1, 3, 2},  {7, 7, 4, 1, 3, 2}, {5, 5, 2, 1, 2, 2},
+    {1, 1, 1, 1, 0, 16, 0}, {1, 1, 2, 1, 0, 16, 0}, {3, 3, 1, 1, 1, 4, 0}, {3, 3, 1, 2, 2, 4, 0},
+    {3, 3, 2, 1, 1, 4, 0},  {7, 7, 2, 1, 3, 2, 0},  {7, 7, 4, 1, 3, 2, 0}, {5, 5, 2, 1, 2, 2, 0},
+    {3, 3, 1, 1, 1, 8, 1},
 };
 const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum ConvTile)
     {128, 128, 8, 16}, {128, 64, 8, 16}, {128, 32, 8, 16}, {64, 64, 8, 8},   {64, 128, 8, 8},
     {128, 128, 4, 32}, {128, 64, 4, 32}, {128, 128, 8, 16}, {128, 64, 8, 16}, {64, 64, 8, 8},
-    {64, 128, 8, 8},   {128, 128, 4, 32}, {128, 64, 4, 32}, {128, 32, 8, 16}};
+    {64, 128, 8, 8},   {128, 128, 4, 32}, {128, 64, 4, 32}, {128, 32, 8, 16},
+    // Winograd: BM in pixels = 4 x blocks
+    {256, 64, 16, 16}, {256, 64, 16, 16}, {512, 32, 16, 32}, {512, 32, 16, 32}, {128, 128, 8, 16},
+    {128, 128, 8, 16}, {256, 64, 8, 32}};
 
 }  // namespace
 
 ConvGeom conv_geom(ConvKind k) { return kGeoms[k]; }
+ConvKind conv_base_kind(ConvKind k) { return k == CONV_3x3_S1_WINO ? CONV_3x3_S1 : k; }
 int tile_bm(ConvTile t) { return kTileDims[t][0]; }
 int tile_bn(ConvTile t) { return kTileDims[t][1]; }
 int tile_th(ConvTile t) { return kTileDims[t][2]; }
@@ -138,7 +145,7 @@ bool conv_supported(ConvKind kind, ConvTile tile) { return table().e[kind][tile]
 void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKind kind, ConvTile tile,
                   std::vector<float>& out) {
   const ConvGeom g = conv_geom(kind);
-  const int taps = g.kh * g.kw, BN = tile_bn(tile), KC = g.kc;
+  const int ktaps = g.kh * g.kw, taps = g.wino ? 16 : ktaps, BN = tile_bn(tile), KC = g.kc;
   const int n_tiles = (Cout + BN - 1) / BN;
   const int nstages = (Cin + KC - 1) / KC;
   const size_t wszp = ((size_t)KC * taps * BN + 1023) / 1024 * 1024;   // Layout::WSZP
@@ -148,9 +155,29 @@ void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKin
     const int nt = co / BN, n = co % BN;
     for (int ci = 0; ci < Cin; ++ci) {
       const int s = ci / KC, c = ci % KC;
-      const float* src = w + ((size_t)co * Cin + ci) * taps;
+      const float* src = w + ((size_t)co * Cin + ci) * ktaps;
       float* dst = out.data() + ((size_t)nt * nstages + s) * wszp + ((size_t)c * taps) * BN + n;
-      for (int t = 0; t < taps; ++t) dst[(size_t)t * BN] = src[t] * sc;
+      if (!g.wino) {
+        for (int t = 0; t < taps; ++t) dst[(size_t)t * BN] = src[t] * sc;
+      } else {
+        // U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], in f64 with one rounding to f32
+        double gk[3][3], tmp[4][3], U[4][4];
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) gk[i][j] = (double)src[i * 3 + j] * (double)sc;
+        for (int j = 0; j < 3; ++j) {
+          tmp[0][j] = gk[0][j];
+          tmp[1][j] = 0.5 * (gk[0][j] + gk[1][j] + gk[2][j]);
+          tmp[2][j] = 0.5 * (gk[0][j] - gk[1][j] + gk[2][j]);
+          tmp[3][j] = gk[2][j];
+        }
+        for (int i = 0; i < 4; ++i) {
+          U[i][0] = tmp[i][0];
+          U[i][1] = 0.5 * (tmp[i][0] + tmp[i][1] + tmp[i][2]);
+          U[i][2] = 0.5 * (tmp[i][0] - tmp[i][1] + tmp[i][2]);
+          U[i][3] = tmp[i][2];
+        }
+        for (int t = 0; t < 16; ++t) dst[(size_t)t * BN] = (float)U[t >> 2][t & 3];
+      }
     }
   }
 }
@@ -224,7 +251,7 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
   int kind = -1;
   for (int k = 0; k < CONV_KIND_COUNT; ++k) {
     const ConvGeom g = conv_geom((ConvKind)k);
-    if (g.kh == ksize && g.kw == ksize && g.stride == stride && g.pad == pad && g.dil == dil) kind = k;
+    if (!g.wino && g.kh == ksize && g.kw == ksize && g.stride == stride && g.pad == pad && g.dil == dil) kind = k;
   }
   FDT_REQUIRE(kind >= 0, FDT_ERR_ARG, "fdt_conv2d: no kernel class for k=%d stride=%d pad=%d dil=%d", ksize,
               stride, pad, dil);
@@ -243,6 +270,7 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
     for (int t = 0; t < CONV_TILE_COUNT && tile < 0; ++t)
       if (conv_supported((ConvKind)kind, (ConvTile)t)) tile = t;
   }
+  if (kind == CONV_3x3_S1 && tile >= TILE_WINO_64x64 && tile < CONV_TILE_COUNT) kind = CONV_3x3_S1_WINO;
   FDT_REQUIRE(tile >= 0 && tile < CONV_TILE_COUNT && conv_supported((ConvKind)kind, (ConvTile)tile), FDT_ERR_ARG,
               "fdt_conv2d: kernel (kind %d, tile %d) not instantiated", kind, tile);
   a.ksplit = ksplit > 0 ? ksplit : 1;

@@ -1,0 +1,229 @@
+// conv_wino.h -- Winograd F(2x2,3x3) variant of the 3x3 / stride 1 / pad 1 convolution on the f32 matrix
+// cores: 16 multiplies per 2x2 output block instead of 36 (2.25x fewer MFMA FLOPs), exact-arithmetic
+// equivalent of nn.Conv2d(k=3, s=1, p=1) up to f32 rounding of the transforms.
+//
+//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A          (per 2x2 output block, per output channel)
+//
+//  * The 16 element-wise products over input channels are 16 independent GEMMs
+//    D_t[cout][block] = sum_c U_t[cout][c] * V_t[c][block], t = 0..15, run on v_mfma_f32_32x32x2_f32
+//    exactly like conv_kernel: weights (pre-transformed on the host, U = G g G^T) are the A operand,
+//    image blocks the B operand.
+//  * Input transform on the fly: the raw (2*TTH+2) x (2*TTW+2) patch of KC channels is staged once per
+//    stage by LDS-DMA (same zero-word trick for padding); each lane (= one 2x2 output block) reads its
+//    4x4 window with 8 ds_read_b64 and forms the 16 V_t values with 32 VALU adds -- the MFMA B operands.
+//    No transformed copy of the activations ever exists in memory.
+//  * All 16 accumulators of a wave's 32-cout x 32-block tile stay in registers (256 VGPRs, one wave per
+//    SIMD: this kernel trades occupancy for 2.25x less matrix work; 16 independent MFMAs per k-pair give
+//    the in-wave parallelism that other waves would otherwise provide).
+//  * Output transform in registers (all 16 D_t of one (cout, block) sit in ONE lane): 24 adds, then
+//    bias / residual / ReLU and one 8-byte store per row of the 2x2 block.
+#pragma once
+#include "conv_kernel.h"
+
+namespace fdt {
+namespace {
+
+template <int TTH_, int TTW_, int WM_, int WN_, int KC_, int NBUF_>
+struct WinoTile {
+  static constexpr int TTH = TTH_, TTW = TTW_, WM = WM_, WN = WN_, KC = KC_, NBUF = NBUF_;
+  static constexpr int BMT = TTH * TTW;        // 2x2 output blocks per workgroup
+  static constexpr int BN = WN * 32;           // output channels per workgroup
+  static constexpr int PH = 2 * TTH + 2, PW = 2 * TTW + 2;
+  static constexpr int XPLANE = PH * PW;
+  static constexpr int XSZ = KC * XPLANE;
+  static constexpr int XSZP = (XSZ + 255) / 256 * 256;
+  static constexpr int WSZ = KC * 16 * BN;
+  static constexpr int WSZP = (WSZ + 1023) / 1024 * 1024;
+  static constexpr int STAGE = XSZP + WSZP;
+  static constexpr int NX = XSZP / 256, NW = WSZP / 1024;
+  static constexpr int LOADS = NX + NW;
+  static constexpr size_t LDS_BYTES = (size_t)NBUF * STAGE * sizeof(float);
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024;
+  static_assert(WM * WN == 4 && WM * 32 == BMT, "4 waves, 32 blocks per wave row");
+  static_assert(KC % 2 == 0 && NX <= 32 && LOADS < 64, "staging limits");
+  static_assert((PW % 2) == 0 && (XPLANE % 2) == 0, "8-byte aligned window reads");
+};
+
+template <class T>
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / T::WN, wn = wave % T::WN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  constexpr int TH = 2 * T::TTH, TW = 2 * T::TTW;          // output pixels per workgroup
+  const int tiles_x = (a.Wout + TW - 1) / TW;
+  const int oy0 = (blockIdx.x / tiles_x) * TH;
+  const int ox0 = (blockIdx.x % tiles_x) * TW;
+  const int n_tile = blockIdx.y;
+  const int b = blockIdx.z / a.ksplit;
+  const int ks = blockIdx.z - b * a.ksplit;
+
+  const int HW = a.Hin * a.Win;                             // stride 1, pad 1: Hout == Hin
+  const float* in_b = a.in + (long long)b * a.Cin * HW;
+  const int nstages = (a.Cin + T::KC - 1) / T::KC;
+  const float* w_t = a.w + (long long)n_tile * nstages * T::WSZP;
+  const int s_begin = (int)((long long)nstages * ks / a.ksplit);
+  const int s_end = (int)((long long)nstages * (ks + 1) / a.ksplit);
+
+  int goff[T::NX];
+  unsigned okmask = 0;
+#pragma unroll
+  for (int k = 0; k < T::NX; ++k) {
+    int e = tid + 256 * k;
+    int c = e / T::XPLANE;
+    int r = e - c * T::XPLANE;
+    int yy = r / T::PW, xx = r - yy * T::PW;
+    int gy = oy0 - 1 + yy, gx = ox0 - 1 + xx;
+    bool ok = (e < T::XSZ) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+    goff[k] = ok ? (c * HW + gy * a.Win + gx) : 0;
+    if (ok) okmask |= (1u << k);
+  }
+
+#define FDT_WSTAGE(s_, buf_)                                                                  \
+  {                                                                                           \
+    const int c0_ = (s_) * T::KC;                                                             \
+    const float* src_ = in_b + (long long)c0_ * HW;                                           \
+    const int crem_ = a.Cin - c0_;                                                            \
+    float* X_ = smem + (buf_) * T::STAGE + wave * 64;                                         \
+    _Pragma("unroll") for (int k = 0; k < T::NX; ++k) {                                       \
+      const int c_ = (tid + 256 * k) / T::XPLANE;                                             \
+      const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                    \
+      glds4(ok_ ? src_ + goff[k] : g_zero_pad, X_ + 256 * k);                                 \
+    }                                                                                         \
+    const float* wsrc_ = w_t + (long long)(s_) * T::WSZP + tid * 4;                           \
+    float* W_ = smem + (buf_) * T::STAGE + T::XSZP + wave * 256;                              \
+    _Pragma("unroll") for (int k = 0; k < T::NW; ++k) glds16(wsrc_ + 1024 * k, W_ + 1024 * k); \
+  }
+
+  // this lane's 2x2 output block inside the workgroup patch
+  const int q = wm * 32 + l31;
+  const int ty = q / T::TTW, tx = q % T::TTW;
+  const int xo = half * T::XPLANE + (2 * ty) * T::PW + 2 * tx;          // top-left of the 4x4 window
+  const int wo = T::XSZP + half * 16 * T::BN + wn * 32 + l31;
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  const int nst = s_end - s_begin;
+#pragma unroll
+  for (int p = 0; p < T::NBUF - 1; ++p)
+    if (p < nst) FDT_WSTAGE(s_begin + p, p);
+  int cur = 0, nxt = T::NBUF - 1;
+  for (int it = 0; it < nst; ++it) {
+    if (T::NBUF >= 3 && it + 1 < nst)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::LOADS) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + T::NBUF - 1 < nst) FDT_WSTAGE(s_begin + it + T::NBUF - 1, nxt);
+    const float* S = smem + cur * T::STAGE;
+#pragma unroll
+    for (int cp = 0; cp < T::KC / 2; ++cp) {
+      // raw 4x4 window d[i][j] of channel 2*cp + half
+      float d[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float2 lo = *reinterpret_cast<const float2*>(S + xo + (2 * cp) * T::XPLANE + i * T::PW);
+        const float2 hi = *reinterpret_cast<const float2*>(S + xo + (2 * cp) * T::XPLANE + i * T::PW + 2);
+        d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+      }
+      // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+      float t_[4][4], v[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t_[0][j] = d[0][j] - d[2][j];
+        t_[1][j] = d[1][j] + d[2][j];
+        t_[2][j] = d[2][j] - d[1][j];
+        t_[3][j] = d[1][j] - d[3][j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i][0] = t_[i][0] - t_[i][2];
+        v[i][1] = t_[i][1] + t_[i][2];
+        v[i][2] = t_[i][2] - t_[i][1];
+        v[i][3] = t_[i][1] - t_[i][3];
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float u = S[wo + ((2 * cp) * 16 + t) * T::BN];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(u, v[t >> 2][t & 3], acc[t], 0, 0, 0);
+      }
+    }
+    cur = (cur + 1 == T::NBUF) ? 0 : cur + 1;
+    nxt = (nxt + 1 == T::NBUF) ? 0 : nxt + 1;
+  }
+#undef FDT_WSTAGE
+
+  // ---- output transform + epilogue: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1] -----------------------------
+  const int HWo = a.Hout * a.Wout;
+  const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
+  const bool raw = a.ws != nullptr;
+  float* dst_b = raw ? a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWo
+                     : a.out + ((long long)b * a.out_ctot + a.out_coff) * HWo;
+  const float* res_b = (!raw && a.res) ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWo : nullptr;
+  const bool row0 = oy < a.Hout, row1 = oy + 1 < a.Hout;
+  const bool col0 = ox < a.Wout, col1 = ox + 1 < a.Wout;
+  const bool vec2 = (a.Wout % 2 == 0);          // ox is even -> both columns in range and 8-byte aligned
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = n_tile * T::BN + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    float s0[4], s1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s0[j] = acc[0 * 4 + j][r] + acc[1 * 4 + j][r] + acc[2 * 4 + j][r];
+      s1[j] = acc[1 * 4 + j][r] - acc[2 * 4 + j][r] - acc[3 * 4 + j][r];
+    }
+    float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
+    float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+    if (co < a.Cout && col0) {
+      const long long base = (long long)co * HWo + (long long)oy * a.Wout + ox;
+      if (!raw) {
+        const float bv = a.bias ? a.bias[co] : 0.0f;
+        y00 += bv; y01 += bv; y10 += bv; y11 += bv;
+        if (res_b) {
+          if (row0) { y00 += res_b[base]; if (col1) y01 += res_b[base + 1]; }
+          if (row1) { y10 += res_b[base + a.Wout]; if (col1) y11 += res_b[base + a.Wout + 1]; }
+        }
+        if (a.act == ACT_RELU) {
+          y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f);
+        } else if (a.act == ACT_RELU6) {
+          y00 = fminf(fmaxf(y00, 0.f), 6.f); y01 = fminf(fmaxf(y01, 0.f), 6.f);
+          y10 = fminf(fmaxf(y10, 0.f), 6.f); y11 = fminf(fmaxf(y11, 0.f), 6.f);
+        }
+      }
+      if (vec2) {
+        if (row0) *reinterpret_cast<float2*>(dst_b + base) = make_float2(y00, y01);
+        if (row1) *reinterpret_cast<float2*>(dst_b + base + a.Wout) = make_float2(y10, y11);
+      } else {
+        if (row0) { dst_b[base] = y00; if (col1) dst_b[base + 1] = y01; }
+        if (row1) { dst_b[base + a.Wout] = y10; if (col1) dst_b[base + a.Wout + 1] = y11; }
+      }
+    }
+  }
+}
+
+//                           TTH TTW WM WN KC NBUF      patch (px)  couts
+using W_64x64    = WinoTile<8, 8, 2, 2, 8, 2>;     //  16 x 16     64
+using W_64x64R3  = WinoTile<8, 8, 2, 2, 8, 3>;
+using W_128x32   = WinoTile<8, 16, 4, 1, 8, 2>;    //  16 x 32     32
+using W_128x32R3 = WinoTile<8, 16, 4, 1, 8, 3>;
+using W_32x128   = WinoTile<4, 8, 1, 4, 8, 2>;     //   8 x 16    128
+using W_64x64W   = WinoTile<4, 16, 2, 2, 8, 3>;    //   8 x 32     64  (wide rows)
+
+template <class T>
+KernelEntry wino_entry() {
+  return KernelEntry{conv_wino_kernel<T>, T::LDS_BYTES};
+}
+
+}  // namespace
+
+void conv_fill_wino(void* row);
+
+}  // namespace fdt

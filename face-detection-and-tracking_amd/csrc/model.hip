@@ -85,7 +85,8 @@ struct fdt_model {
     int Cout = 0, Cin = 0;
   };
   std::map<std::string, HostW> host_w;                      // per conv layer, kept for re-tiling
-  std::map<std::string, std::pair<int, int>> hints;         // autotuned (tile, split) per layer
+  struct Hint { int kind, tile, split; };
+  std::map<std::string, Hint> hints;                        // autotuned (kernel class, tile, split) per layer
   int hB = 0, hH = 0, hW = 0;                               // shape the hints were tuned for
   std::vector<void*> plan_allocs;
   std::vector<std::pair<int, int>> levels;  // (H, W) of each detection source
@@ -302,9 +303,12 @@ struct Builder {
     int ksplit = 1;
     auto hint = m->hints.find(name);
     if (hint != m->hints.end() && m->hB == B && m->hH == m->tensors[0].H && m->hW == m->tensors[0].W &&
-        conv_supported(kind, (ConvTile)hint->second.first)) {
-      op.tile = (ConvTile)hint->second.first;
-      ksplit = std::max(1, std::min(hint->second.second, ceil_div(in.C, g.kc)));
+        conv_base_kind((ConvKind)hint->second.kind) == kind &&
+        conv_supported((ConvKind)hint->second.kind, (ConvTile)hint->second.tile)) {
+      kind = (ConvKind)hint->second.kind;     // e.g. the Winograd implementation of a 3x3/s1 layer
+      op.kind = kind;
+      op.tile = (ConvTile)hint->second.tile;
+      ksplit = std::max(1, std::min(hint->second.split, ceil_div(in.C, conv_geom(kind).kc)));
     } else {
       choose(kind, Ctot, in.C, Ho, Wo, B, o.up_t >= 0, op.tile, ksplit);
     }
@@ -1250,21 +1254,24 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   int rc = FDT_OK;
   for (auto& op : m->ops) {
     if (op.type != OP_CONV) continue;
-    const ConvGeom g = conv_geom(op.kind);
-    const int nstages = ceil_div(op.ca.Cin, g.kc);
-    struct Cand { int tile, split; float ms; };
+    struct Cand { int kind, tile, split; float ms; };
     std::vector<Cand> cands;
     long long ws_need = 0;
-    for (int t = 0; t < CONV_TILE_COUNT; ++t) {
-      if (!conv_supported(op.kind, (ConvTile)t)) continue;
-      for (int split = 1; split <= 64; split *= 2) {
-        if (split > 1 && (split > nstages / 2 || nstages < 8)) break;
-        ConvArgs a = op.ca;
-        a.ksplit = split;
-        long long wsf = conv_ws_floats(a);
-        if (wsf > kMaxWsFloats) break;
-        ws_need = std::max(ws_need, wsf);
-        cands.push_back({t, split, 0.f});
+    const ConvKind base = conv_base_kind(op.kind);
+    for (int k = 0; k < CONV_KIND_COUNT; ++k) {
+      if (conv_base_kind((ConvKind)k) != base) continue;    // e.g. direct and Winograd 3x3/s1
+      const int nstages = ceil_div(op.ca.Cin, conv_geom((ConvKind)k).kc);
+      for (int t = 0; t < CONV_TILE_COUNT; ++t) {
+        if (!conv_supported((ConvKind)k, (ConvTile)t)) continue;
+        for (int split = 1; split <= 64; split *= 2) {
+          if (split > 1 && (split > nstages / 2 || nstages < 8)) break;
+          ConvArgs a = op.ca;
+          a.ksplit = split;
+          long long wsf = conv_ws_floats(a);
+          if (wsf > kMaxWsFloats) break;
+          ws_need = std::max(ws_need, wsf);
+          cands.push_back({k, t, split, 0.f});
+        }
       }
     }
     float* tmp_ws = nullptr;
@@ -1273,10 +1280,10 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
       rc = FDT_ERR_HIP;
       break;
     }
-    Cand best{(int)op.tile, op.ca.ksplit, 1e30f};
+    Cand best{(int)op.kind, (int)op.tile, op.ca.ksplit, 1e30f};
     for (auto& c : cands) {
       DevW dw;
-      rc = Builder::device_weights(m, op.name, op.kind, (ConvTile)c.tile, dw);
+      rc = Builder::device_weights(m, op.name, (ConvKind)c.kind, (ConvTile)c.tile, dw);
       if (rc != FDT_OK) break;
       ConvArgs a = op.ca;
       a.w = dw.w;
@@ -1286,7 +1293,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
       float best_ms = 1e30f;
       for (int it = 0; it < iters + 1 && rc == FDT_OK; ++it) {
         (void)hipEventRecord(e0, st);
-        rc = launch_conv(op.kind, (ConvTile)c.tile, a, st);
+        rc = launch_conv((ConvKind)c.kind, (ConvTile)c.tile, a, st);
         (void)hipEventRecord(e1, st);
         if (hipEventSynchronize(e1) != hipSuccess) { set_error("autotune: kernel failed"); rc = FDT_ERR_HIP; }
         float ms = 0;
@@ -1300,14 +1307,15 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
     if (tmp_ws) (void)hipFree(tmp_ws);
     if (rc != FDT_OK) break;
     DevW dw;
-    rc = Builder::device_weights(m, op.name, op.kind, (ConvTile)best.tile, dw);
+    rc = Builder::device_weights(m, op.name, (ConvKind)best.kind, (ConvTile)best.tile, dw);
     if (rc != FDT_OK) break;
+    op.kind = (ConvKind)best.kind;
     op.tile = (ConvTile)best.tile;
     op.ca.ksplit = best.split;
     op.ca.w = dw.w;
     op.ca.bias = dw.bias;
     op.needs_ws = best.split > 1 || op.ca.up;
-    m->hints[op.name] = {best.tile, best.split};
+    m->hints[op.name] = {best.kind, best.tile, best.split};
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
@@ -1332,14 +1340,15 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   return FDT_OK;
 }
 
-// Plan hints as text: one "layer tile split" line per conv layer, first line "shape B H W".
+// Plan hints as text: one "layer kind tile split" line per conv layer, first line "shape B H W".
 extern "C" int fdt_model_export_plan(fdt_model* m, char* buf, int buflen, int* needed) {
   FDT_REQUIRE(m && needed, FDT_ERR_ARG, "fdt_model_export_plan: bad argument");
   FDT_REQUIRE(m->pB > 0, FDT_ERR_STATE, "fdt_model_export_plan: no plan yet");
   std::string out = "shape " + std::to_string(m->pB) + " " + std::to_string(m->pH) + " " + std::to_string(m->pW) + "\n";
   for (auto& op : m->ops)
     if (op.type == OP_CONV)
-      out += op.name + " " + std::to_string((int)op.tile) + " " + std::to_string(op.ca.ksplit) + "\n";
+      out += op.name + " " + std::to_string((int)op.kind) + " " + std::to_string((int)op.tile) + " " +
+             std::to_string(op.ca.ksplit) + "\n";
   *needed = (int)out.size() + 1;
   if (buf && buflen >= *needed) memcpy(buf, out.c_str(), out.size() + 1);
   return FDT_OK;
@@ -1347,7 +1356,7 @@ extern "C" int fdt_model_export_plan(fdt_model* m, char* buf, int buflen, int* n
 
 extern "C" int fdt_model_import_plan(fdt_model* m, const char* text) {
   FDT_REQUIRE(m && text, FDT_ERR_ARG, "fdt_model_import_plan: bad argument");
-  std::map<std::string, std::pair<int, int>> hints;
+  std::map<std::string, fdt_model::Hint> hints;
   int B = 0, H = 0, W = 0;
   const char* p = text;
   while (*p) {
@@ -1359,10 +1368,10 @@ extern "C" int fdt_model_import_plan(fdt_model* m, const char* text) {
     int a = 0, b = 0, c = 0;
     if (sscanf(line.c_str(), "shape %d %d %d", &a, &b, &c) == 3) {
       B = a; H = b; W = c;
-    } else if (sscanf(line.c_str(), "%255s %d %d", name, &a, &b) == 3) {
-      FDT_REQUIRE(a >= 0 && a < CONV_TILE_COUNT && b >= 1 && b <= 4096, FDT_ERR_ARG,
-                  "fdt_model_import_plan: bad entry '%s'", line.c_str());
-      hints[name] = {a, b};
+    } else if (sscanf(line.c_str(), "%255s %d %d %d", name, &a, &b, &c) == 4) {
+      FDT_REQUIRE(a >= 0 && a < CONV_KIND_COUNT && b >= 0 && b < CONV_TILE_COUNT && c >= 1 && c <= 4096,
+                  FDT_ERR_ARG, "fdt_model_import_plan: bad entry '%s'", line.c_str());
+      hints[name] = {a, b, c};
     } else {
       set_error("fdt_model_import_plan: cannot parse '%s'", line.c_str());
       return FDT_ERR_ARG;

@@ -178,7 +178,7 @@ int fdt_model_get_tensor(fdt_model* m, const char* name, float* out, long long m
  * that shape.  Results stay within the f32 tolerance but are re-associated (not bitwise) vs the
  * untuned plan.                                                                                  */
 int fdt_model_autotune(fdt_model* m, int iters);
-/* Persist / restore the per-layer kernel choice as text ("shape B H W" then "layer tile split" lines)
+/* Persist / restore the per-layer kernel choice as text ("shape B H W" then "layer kind tile split" lines)
  * so a tuned plan is reproducible across processes.  export: *needed = bytes incl. NUL; buf may be NULL. */
 int fdt_model_export_plan(fdt_model* m, char* buf, int buflen, int* needed);
 int fdt_model_import_plan(fdt_model* m, const char* text);

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 KINDS = {  # name: (k, stride, pad, dil)
     "1x1s1": (1, 1, 0, 1), "1x1s2": (1, 2, 0, 1), "3x3s1": (3, 1, 1, 1), "3x3d2": (3, 1, 2, 2),
     "3x3s2": (3, 2, 1, 1), "7x7s2": (7, 2, 3, 1), "7x7s4": (7, 4, 3, 1), "5x5s2": (5, 2, 2, 1)}
-N_TILES = 14
+N_TILES = 21      # 14 direct tiles + 7 Winograd F(2x2,3x3) tiles (3x3 s1 only)
 
 
 def lib():
@@ -94,6 +94,27 @@ def test_fused_epilogues(tile, W):
             rc, got = run_conv(x, w, b, 1, 1, 0, 1, tile=tile, split=split, **kw)
             assert rc == 0, lib().lib().fdt_last_error()
             assert rel_err(got, reference(x, w, b, 1, 1, 0, 1, **kw)) < 1e-5, (tile, W, split, list(kw))
+
+
+@pytest.mark.parametrize("tile", range(14, 21))
+@pytest.mark.parametrize("shape", [(64, 40, 48, 96), (37, 31, 45, 70)])
+def test_winograd_variants(tile, shape):
+    """Winograd F(2x2,3x3): 2.25x fewer multiplies, same result up to f32 rounding of the transforms
+    (tolerance 3x the direct kernel's), incl. odd sizes, residual, ReLU and split-K."""
+    Cin, H, W, Cout = shape
+    rng = np.random.default_rng(tile * 7 + H)
+    x = rng.standard_normal((2, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((2, Cout, H, W)).astype(np.float32)
+    for kw in (dict(act=0), dict(res=res, act=1)):
+        exp = reference(x, w, b, 3, 1, 1, 1, **kw)
+        for split in (1, 2):
+            rc, got = run_conv(x, w, b, 3, 1, 1, 1, tile=tile, split=split, **kw)
+            if rc != 0 and b"not instantiated" in lib().lib().fdt_last_error():
+                pytest.skip("variant needs more LDS than a CU has")
+            assert rc == 0, lib().lib().fdt_last_error()
+            assert rel_err(got, exp) < 3e-5, (tile, shape, split, rel_err(got, exp))
 
 
 def test_deep_reduction_split_k_is_deterministic():

@@ -10,11 +10,12 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lib = importlib.import_module("face-detection-and-tracking_amd._lib")
-KIND = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2"]
+KIND = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2", "3x3wino"]
 TILE = ["128x128", "128x64", "128x32", "64x64", "64x128", "128x128W", "128x64W", "128x128R3", "128x64R3",
-        "64x64R3", "64x128R3", "128x128WR3", "128x64WR3", "128x32R3"]
-GEOM = {0: (1, 1), 1: (1, 2), 2: (3, 1), 3: (3, 1), 4: (3, 2), 5: (7, 2), 6: (7, 4), 7: (5, 2)}
-KC = {0: 16, 1: 16, 2: 4, 3: 4, 4: 4, 5: 2, 6: 2, 7: 2}
+        "64x64R3", "64x128R3", "128x128WR3", "128x64WR3", "128x32R3", "w64x64", "w64x64R3", "w128x32", "w128x32R3",
+        "w32x128", "w32x128R3", "w64x64W"]
+GEOM = {0: (1, 1), 1: (1, 2), 2: (3, 1), 3: (3, 1), 4: (3, 2), 5: (7, 2), 6: (7, 4), 7: (5, 2), 8: (3, 1)}
+KC = {0: 16, 1: 16, 2: 4, 3: 4, 4: 4, 5: 2, 6: 2, 7: 2, 8: 8}
 
 
 def bench(kind, tile, split, cin, h, w, cout, res=0, up=0, iters=20, B=1):
@@ -50,7 +51,9 @@ if __name__ == "__main__":
         a = list(map(int, sys.argv[1:]))
         sweep(a[0], a[1], a[2], a[3], a[4], a[5] if len(a) > 5 else 0)
     else:
-        shapes = [(2, 256, 256, 256, 256, 0), (0, 64, 256, 256, 256, 1), (0, 256, 256, 256, 64, 0),
+        shapes = [(8, 256, 256, 256, 256, 0), (8, 512, 128, 128, 512, 0), (8, 1024, 64, 64, 1024, 0),
+                  (8, 64, 256, 256, 64, 0), (8, 128, 128, 128, 128, 0), (8, 256, 64, 64, 256, 0),
+                  (8, 512, 32, 32, 512, 0), (8, 2048, 32, 32, 256, 0), (2, 256, 256, 256, 256, 0), (0, 64, 256, 256, 256, 1), (0, 256, 256, 256, 64, 0),
                   (2, 64, 256, 256, 64, 0), (0, 512, 128, 128, 128, 0), (0, 128, 128, 128, 512, 1),
                   (2, 128, 128, 128, 128, 0), (0, 1024, 64, 64, 256, 0), (0, 256, 64, 64, 1024, 1),
                   (2, 256, 64, 64, 256, 0), (0, 2048, 32, 32, 512, 0), (0, 512, 32, 32, 2048, 1),

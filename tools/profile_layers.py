@@ -11,9 +11,10 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-KIND = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2"]
+KIND = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2", "3x3wino"]
 TILE = ["128x128", "128x64", "128x32", "64x64", "64x128", "128x128W", "128x64W", "128x128R3", "128x64R3",
-        "64x64R3", "64x128R3", "128x128WR3", "128x64WR3", "128x32R3"]
+        "64x64R3", "64x128R3", "128x128WR3", "128x64WR3", "128x32R3", "w64x64", "w64x64R3", "w128x32", "w128x32R3",
+        "w32x128", "w32x128R3", "w64x64W"]
 
 
 def main():
@@ -35,8 +36,13 @@ def main():
         net.priorbox = layers.PriorBoxLayer(a.size, a.size, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256))
     net.load_state_dict(synth.make_state_dict(a.arch, 0))
     frames = synth.make_frames(a.batch, a.size, a.size, seed=1234)
+    import os
+    plan = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "face-detection-and-tracking_amd",
+                        "tuned", "%s_%dx%d_b%d.plan" % (a.arch, a.size, a.size, a.batch))
+    if a.autotune == 1 and os.path.exists(plan):
+        net.import_plan(open(plan).read())
     net(frames)
-    if a.autotune:
+    if a.autotune == 2 or (a.autotune == 1 and not os.path.exists(plan)):
         net.autotune(3)
         net(frames)
     net.profile(True)
