@@ -99,7 +99,7 @@ __global__ void splitk_reduce_kernel(const ConvArgs a) {
 
 struct Table {
   KernelEntry e[CONV_KIND_COUNT][CONV_TILE_COUNT];
-  bool attr_set[CONV_KIND_COUNT][CONV_TILE_COUNT];
+  bool attr_set[16][CONV_KIND_COUNT][CONV_TILE_COUNT];   // per device: the attribute is per (function, device)
   Table() {
     memset(e, 0, sizeof(e));
     memset(attr_set, 0, sizeof(attr_set));
@@ -207,10 +207,13 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a, hipStream_t st)
   if (a.res) FDT_REQUIRE(a.res_coff + a.Cout <= a.res_ctot, FDT_ERR_ARG, "launch_conv: bad residual slice");
   if (a.up) FDT_REQUIRE(a.up_h * 2 >= a.Hout && a.up_w * 2 >= a.Wout && a.up_h >= 1 && a.up_w >= 1,
                         FDT_ERR_ARG, "launch_conv: upsample source too small");
-  if (!table().attr_set[kind][tile]) {
+  int dev = 0;
+  FDT_HIP(hipGetDevice(&dev));
+  dev &= 15;
+  if (!table().attr_set[dev][kind][tile]) {
     FDT_HIP(hipFuncSetAttribute((const void*)ke.fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)ke.lds));
-    table().attr_set[kind][tile] = true;
+    table().attr_set[dev][kind][tile] = true;
   }
   const int nstages = ceil_div(a.Cin, g.kc);
   FDT_REQUIRE(a.ksplit >= 1 && a.ksplit <= nstages, FDT_ERR_ARG,

@@ -104,8 +104,6 @@ struct fdt_model {
   // profiling
   bool profile = false;
   std::vector<hipEvent_t> ev;
-  std::vector<float> prof_ms;
-  int prof_runs = 0;
 
   ~fdt_model() {
     free_plan();
@@ -885,8 +883,6 @@ int make_plan(fdt_model* m, int B, int H, int W) {
   // profiling events
   for (auto e : m->ev) (void)hipEventDestroy(e);
   m->ev.clear();
-  m->prof_ms.assign(m->ops.size() + 1, 0.f);
-  m->prof_runs = 0;
   return FDT_OK;
 }
 
@@ -1390,8 +1386,6 @@ extern "C" int fdt_model_import_plan(fdt_model* m, const char* text) {
 extern "C" int fdt_model_profile_enable(fdt_model* m, int on) {
   FDT_REQUIRE(m, FDT_ERR_ARG, "fdt_model_profile_enable: null handle");
   m->profile = on != 0;
-  std::fill(m->prof_ms.begin(), m->prof_ms.end(), 0.f);
-  m->prof_runs = 0;
   return FDT_OK;
 }
 
