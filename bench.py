@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=0, help="frame height (default: --size)")
+    ap.add_argument("--width", type=int, default=0, help="frame width (default: --size)")
     ap.add_argument("--arch", default="res50", choices=["res50", "try3"])
     ap.add_argument("--unique-frames", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-baseline sample (0 = skip)")
@@ -82,7 +84,8 @@ def main():
     par = importlib.import_module("face-detection-and-tracking_amd.parallel")
     lib = pkg._lib
 
-    H = W = args.size
+    H = args.height or args.size
+    W = args.width or args.size
     sd = synth.make_state_dict(args.arch, seed=0)
     NF = max(1, args.inflight)
     nets = []
@@ -97,7 +100,7 @@ def main():
         n.cuda(); n.eval()
         n._sync_attributes(H, W)
         plan_file = os.path.join(ROOT, "face-detection-and-tracking_amd", "tuned",
-                                 "%s_%dx%d_b1.plan" % (args.arch, H, W))
+                                 "%s_%dx%d_b1.plan" % (args.arch, W, H))
         if args.autotune == 1 and os.path.exists(plan_file):
             n.import_plan(open(plan_file).read())      # committed result of an earlier autotune on MI355X
             plan_src = "tuned/" + os.path.basename(plan_file)
@@ -254,7 +257,7 @@ def main():
     if rank == 0:
         frames = args.steps * world
         line = {
-            "metric": "frames/sec (detect+track) at %dx%d" % (H, W),
+            "metric": "frames/sec (detect+track) at %dx%d" % (W, H),
             "value": round(frames / dt, 3),
             "unit": "frames/s",
             "n_gpus": world,
@@ -267,7 +270,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "PyramidBox-%s %dx%d synthetic u8 frames, batch=1 per GPU, decode+NMS+IoU-tracker "
-                                   "on device" % ("Res50" if args.arch == "res50" else "MobileNetV2-try3", H, W),
+                                   "on device" % ("Res50" if args.arch == "res50" else "MobileNetV2-try3", W, H),
                        "frames_per_step": world, "frames_in_flight_per_gpu": NF, "kernel_plan": plan_src, "parallelism": "frame-parallel x%d%s" % (
                            world, ", RCCL all-gather of box lists" if world > 1 else ""),
                        "weights": "seeded synthetic (seed 0)", "detections_last_frame": n_cand_last,
