@@ -72,6 +72,8 @@ SIGNATURES = {
     "fdt_model_set_detect": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float, C.c_int]),
     "fdt_model_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "fdt_model_forward_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "fdt_model_forward_resized": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
+                                            _vp]),
     "fdt_model_forward_raw": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "fdt_model_detect_facebox": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                            _vp, _vp, _vp]),

@@ -153,6 +153,23 @@ class DetectorNet:
 
     forward = __call__
 
+    def forward_resized(self, frames, size):
+        """frames: uint8 [B,SH,SW,3] (or [SH,SW,3]) raw BGR frames; size = (W, H) network input.  The
+        cv2.resize(image, (W, H)) of reference iouTracke_cal.py:123 and the mean subtraction run on the
+        GPU (parity with cv2 itself is unpinned: cv2 is not available to the build)."""
+        x = np.ascontiguousarray(frames, dtype=np.uint8)
+        if x.ndim == 3:
+            x = x[None]
+        B, SH, SW, _ = x.shape
+        W, H = int(size[0]), int(size[1])
+        self._sync_attributes(H, W)
+        out = np.empty((B, 2, self.detect.top_k, 5), dtype=np.float32)
+        counts = np.zeros((B, 2), dtype=np.int32)
+        _lib.check(_lib.lib().fdt_model_forward_resized(self._h, _lib.ptr(x), 0, B, SH, SW, H, W, _lib.ptr(out),
+                                                        _lib.ptr(counts), None))
+        self.last_counts = counts
+        return torch.from_numpy(out)
+
     # ---- debugging / parity helpers ------------------------------------------------------------
     def forward_raw(self, x):
         """(loc [B,P,4], softmaxed conf [B,P,2]) without Detect."""

@@ -96,6 +96,8 @@ struct fdt_model {
   void* d_ws = nullptr;
   DetectPlan dplan;
   unsigned char* d_frames_u8 = nullptr;
+  unsigned char* d_src_u8 = nullptr;   // un-resized source frames (host entry point of the resize ingest)
+  size_t src_bytes = 0;
   float *d_fb_boxes = nullptr, *d_fb_probs = nullptr;
   double flops_per_frame = 0;
   long long ws_floats = 0;   // split-K / fused-upsample workspace shared by all layers
@@ -112,6 +114,7 @@ struct fdt_model {
       if (kv.second.bias) (void)hipFree(kv.second.bias);
     }
     for (auto e : ev) (void)hipEventDestroy(e);
+    if (d_src_u8) (void)hipFree(d_src_u8);
     if (stream) (void)hipStreamDestroy(stream);
   }
   void free_plan() {
@@ -936,7 +939,8 @@ int run_ops(fdt_model* m, int B, hipStream_t st) {
 }
 
 int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int format, int B, int H, int W,
-                 bool run_detect, float* out_dev, int* counts_dev, hipStream_t user_stream) {
+                 bool run_detect, float* out_dev, int* counts_dev, hipStream_t user_stream, int src_h = 0,
+                 int src_w = 0) {
   FDT_REQUIRE(m && frames, FDT_ERR_ARG, "fdt_model_forward: null argument");
   FDT_REQUIRE(m->finalized, FDT_ERR_STATE, "fdt_model_forward: call fdt_model_finalize first");
   FDT_REQUIRE(B >= 1 && H >= 1 && W >= 1, FDT_ERR_ARG, "fdt_model_forward: bad shape");
@@ -949,7 +953,26 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
   if (fresh && st != m->stream) FDT_HIP(hipStreamSynchronize(m->stream));   // priors were built there
   const hipMemcpyKind kind = frames_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   float* x = m->tensors[0].d;
-  if (format == FDT_FRAME_U8_HWC_BGR) {
+  if (format == FDT_FRAME_U8_HWC_BGR && src_h > 0 && (src_h != H || src_w != W)) {
+    // device-side ingest: cv2.resize(frame, (W, H)) + mean subtraction in one kernel
+    const unsigned char* src = (const unsigned char*)frames;
+    const size_t bytes = (size_t)B * src_h * src_w * 3;
+    if (!frames_on_device) {
+      if (bytes > m->src_bytes) {
+        if (m->d_src_u8) (void)hipFree(m->d_src_u8);
+        m->d_src_u8 = nullptr;
+        m->src_bytes = 0;
+        FDT_HIP(hipMalloc((void**)&m->d_src_u8, bytes));
+        m->src_bytes = bytes;
+      }
+      FDT_HIP(hipMemcpyAsync(m->d_src_u8, frames, bytes, kind, st));
+      src = m->d_src_u8;
+    }
+    if (m->arch == FDT_ARCH_FACEBOX)
+      FDT_TRY(launch_resize_preprocess(src, B, src_h, src_w, H, W, 0.f, 0.f, 0.f, 255.0f, x, st));
+    else
+      FDT_TRY(launch_resize_preprocess(src, B, src_h, src_w, H, W, 104.f, 117.f, 123.f, 1.0f, x, st));
+  } else if (format == FDT_FRAME_U8_HWC_BGR) {
     const unsigned char* src = (const unsigned char*)frames;
     if (!frames_on_device) {
       FDT_HIP(hipMemcpyAsync(m->d_frames_u8, frames, (size_t)B * H * W * 3, kind, st));
@@ -1143,6 +1166,22 @@ extern "C" int fdt_model_forward(fdt_model* m, const void* frames, int format, i
   FDT_REQUIRE(m && m->arch != FDT_ARCH_FACEBOX, FDT_ERR_ARG,
               "fdt_model_forward: FaceBox has no Detect layer; use fdt_model_detect_facebox");
   FDT_TRY(forward_impl(m, frames, false, format, B, H, W, true, nullptr, nullptr, nullptr));
+  FDT_HIP(hipMemcpyAsync(out, m->d_out, (size_t)B * 2 * m->top_k * 5 * 4, hipMemcpyDeviceToHost, m->stream));
+  if (counts) FDT_HIP(hipMemcpyAsync(counts, m->d_counts, (size_t)B * 2 * 4, hipMemcpyDeviceToHost, m->stream));
+  FDT_HIP(hipStreamSynchronize(m->stream));
+  return FDT_OK;
+}
+
+extern "C" int fdt_model_forward_resized(fdt_model* m, const void* frames, int frames_on_device, int B,
+                                         int src_h, int src_w, int H, int W, float* out, int* counts,
+                                         void* stream) {
+  FDT_REQUIRE(m && out && src_h >= 1 && src_w >= 1, FDT_ERR_ARG, "fdt_model_forward_resized: bad argument");
+  FDT_REQUIRE(m->arch != FDT_ARCH_FACEBOX, FDT_ERR_ARG, "fdt_model_forward_resized: use fdt_model_detect_facebox");
+  if (frames_on_device)
+    return forward_impl(m, frames, true, FDT_FRAME_U8_HWC_BGR, B, H, W, true, out, counts, (hipStream_t)stream,
+                        src_h, src_w);
+  FDT_TRY(forward_impl(m, frames, false, FDT_FRAME_U8_HWC_BGR, B, H, W, true, nullptr, nullptr, nullptr, src_h,
+                       src_w));
   FDT_HIP(hipMemcpyAsync(out, m->d_out, (size_t)B * 2 * m->top_k * 5 * 4, hipMemcpyDeviceToHost, m->stream));
   if (counts) FDT_HIP(hipMemcpyAsync(counts, m->d_counts, (size_t)B * 2 * 4, hipMemcpyDeviceToHost, m->stream));
   FDT_HIP(hipStreamSynchronize(m->stream));

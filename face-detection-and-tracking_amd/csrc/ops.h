@@ -10,6 +10,11 @@ namespace fdt {
 int launch_preprocess(const unsigned char* frames, int B, int H, int W, float m0, float m1, float m2,
                       float scale, float* out, hipStream_t st);
 
+// cv2.resize(frame, (W, H)) [INTER_LINEAR, 8UC3] fused with the ingest above: iouTracke_cal.py:123 +
+// :40-46, FACEBOX/My_test_facebox.py:13-15.  frames: [B][SH][SW][3] u8.
+int launch_resize_preprocess(const unsigned char* frames, int B, int SH, int SW, int H, int W, float m0,
+                             float m1, float m2, float div, float* out, hipStream_t st);
+
 // F.max_pool2d(x, 3, stride, 1)  (pyramid.py:230 stride 2; FACEBOX/networks.py:46 stride 1).
 // relu_in: apply ReLU to the input on the fly.  crelu: input has C channels, output 2C =
 // maxpool(relu(cat[x,-x])) (FACEBOX/networks.py:92-98).

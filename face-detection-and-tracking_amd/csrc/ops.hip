@@ -22,6 +22,53 @@ __global__ void preprocess_kernel(const unsigned char* __restrict__ in, int H, i
   o[2 * hw] = v2;
 }
 
+// cv2.resize(src, (W, H)) with INTER_LINEAR on 8UC3, fused with the mean-subtract / NCHW ingest.
+// Restates OpenCV's generic 8-bit path (imgproc/resize.cpp: resizeGeneric_ with HResizeLinear and
+// VResizeLinear<uchar,int,short>): source coordinate (d + 0.5) * scale - 0.5, edge clamp, coefficients
+// quantised to 1/2048 (INTER_RESIZE_COEF_BITS = 11), horizontal pass in int, vertical pass
+// ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.  cv2 is absent from the build image, so
+// agreement with cv2 itself is UNPINNED; the kernel is bit-exact against oracle/ingest.py.
+__device__ __forceinline__ void resize_coef(int d, double scale, int ssize, int& s0, int& s1, int& a0, int& a1) {
+  float f = (float)((d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) { f = 0.f; s = 0; }
+  if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+  s0 = s;
+  s1 = s + 1 < ssize ? s + 1 : s;
+  // saturate_cast<short>(v * 2048): round half to even like cvRound
+  a0 = (int)rintf((1.f - f) * 2048.f);
+  a1 = (int)rintf(f * 2048.f);
+}
+
+__global__ void resize_preprocess_kernel(const unsigned char* __restrict__ in, int SH, int SW, int H, int W,
+                                         double scale_y, double scale_x, float m0, float m1, float m2,
+                                         float div, float* __restrict__ out) {
+  const int b = blockIdx.z;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= W) return;
+  int sx0, sx1, ax0, ax1, sy0, sy1, by0, by1;
+  resize_coef(x, scale_x, SW, sx0, sx1, ax0, ax1);
+  resize_coef(y, scale_y, SH, sy0, sy1, by0, by1);
+  const unsigned char* src = in + (long long)b * SH * SW * 3;
+  const unsigned char* r0 = src + (long long)sy0 * SW * 3;
+  const unsigned char* r1 = src + (long long)sy1 * SW * 3;
+  const float mean[3] = {m0, m1, m2};
+  const long long hw = (long long)H * W;
+  float* o = out + (long long)b * 3 * hw + (long long)y * W + x;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    int h0 = r0[sx0 * 3 + c] * ax0 + r0[sx1 * 3 + c] * ax1;
+    int h1 = r1[sx0 * 3 + c] * ax0 + r1[sx1 * 3 + c] * ax1;
+    int v = ((((by0 * (h0 >> 4)) >> 16) + ((by1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    float f = (float)v - mean[c];
+    if (div != 1.0f) f /= div;
+    o[c * hw] = f;
+  }
+}
+
 __global__ void maxpool3_kernel(const float* __restrict__ in, int C, int H, int W, int stride, int crelu,
                                 float* __restrict__ out, int Ho, int Wo) {
   const int ox = blockIdx.x * blockDim.x + threadIdx.x;
@@ -138,6 +185,16 @@ int launch_preprocess(const unsigned char* frames, int B, int H, int W, float m0
                       float scale, float* out, hipStream_t st) {
   dim3 grid((unsigned)ceil_div_ll((long long)H * W, 256), B);
   hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, st, frames, H, W, m0, m1, m2, scale, out);
+  FDT_LAUNCH_CHECK();
+  return FDT_OK;
+}
+
+int launch_resize_preprocess(const unsigned char* frames, int B, int SH, int SW, int H, int W, float m0,
+                             float m1, float m2, float div, float* out, hipStream_t st) {
+  FDT_REQUIRE(H <= 65535 && B <= 65535, FDT_ERR_ARG, "resize: grid too large");
+  dim3 grid(ceil_div(W, 64), H, B);
+  hipLaunchKernelGGL(resize_preprocess_kernel, grid, dim3(64), 0, st, frames, SH, SW, H, W, (double)SH / H,
+                     (double)SW / W, m0, m1, m2, div, out);
   FDT_LAUNCH_CHECK();
   return FDT_OK;
 }

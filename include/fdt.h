@@ -157,6 +157,13 @@ int fdt_model_forward(fdt_model* m, const void* frames, int format, int B, int H
                       float* out, int* counts);
 int fdt_model_forward_dev(fdt_model* m, const void* frames_dev, int format, int B, int H, int W,
                           float* out_dev, int* counts_dev, void* stream);
+/* Device-side frame ingest: frames are B raw u8 BGR HWC images of src_h x src_w;
+ * they are resized on the GPU to W x H like cv2.resize(image, (W, H)) (INTER_LINEAR, 8-bit fixed-point
+ * path; iouTracke_cal.py:123) and mean-subtracted in the same kernel, then the forward runs as in
+ * fdt_model_forward.  frames_on_device != 0: device pointers for frames/out/counts, async on `stream`.
+ * Agreement with cv2 itself is unpinned (cv2 is not available to the build); see DESIGN.md.        */
+int fdt_model_forward_resized(fdt_model* m, const void* frames, int frames_on_device, int B, int src_h,
+                              int src_w, int H, int W, float* out, int* counts, void* stream);
 /* Network output without Detect: loc [B,P,4], conf [B,P,2].  PyramidBox: conf is softmaxed
  * (pyramid.py:332).  FaceBox.forward (FACEBOX/networks.py:87-116): conf is the raw conf_preds.       */
 int fdt_model_forward_raw(fdt_model* m, const void* frames, int format, int B, int H, int W,

@@ -84,3 +84,21 @@ def test_my_test_evaluation_harness(synth):
     assert np.array_equal(fp, fp_o) and np.array_equal(rec, tp_o / 6)
     assert rec[-1] == 1.0 and 0 < pr.average_precision(data) <= 1.0
     net.close()
+
+
+def test_device_side_resize_ingest(entry, synth):
+    """8(f)-1: cv2.resize(frame,(W,H)) + mean-subtract on the GPU.  Bit-exact vs the oracle's restatement of
+    OpenCV's 8-bit INTER_LINEAR path (parity with cv2 itself is unpinned: cv2 is not available)."""
+    from oracle import ingest
+    rng = np.random.default_rng(12)
+    src = rng.integers(0, 256, (270, 480, 3), dtype=np.uint8)          # 1080p / 4
+    small = ingest.resize_linear_u8(src, 160, 128)
+    assert small.shape == (128, 160, 3)
+    y_ref = entry.net(small).numpy()                   # resize on the host (oracle), ingest on the GPU
+    stem_ref = entry.net.get_tensor("input")
+    y = entry.net.forward_resized(src, (160, 128)).numpy()
+    assert np.array_equal(entry.net.get_tensor("input"), stem_ref)    # the resized+mean-subtracted tensor: bit-exact
+    assert np.array_equal(y, y_ref)
+    # identity size goes through the same kernel and must be the identity
+    y_id = entry.net.forward_resized(small, (160, 128)).numpy()
+    assert np.array_equal(y_id, y_ref)
