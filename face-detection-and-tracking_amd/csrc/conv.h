@@ -45,6 +45,11 @@ enum ConvTile {
   TILE_WINO_32x128,    //  8x16 px, 128 ch
   TILE_WINO_32x128R3,
   TILE_WINO_64x64W,    //  8x32 px,  64 ch
+  // 8-wave Winograd (two waves per SIMD, 8 accumulators each)
+  TILE_WINO8_64x64,
+  TILE_WINO8_64x64R3,
+  TILE_WINO8_128x32R3,
+  TILE_WINO8_64x64W,
   CONV_TILE_COUNT
 };
 

@@ -129,7 +129,9 @@ const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum 
     {64, 128, 8, 8},   {128, 128, 4, 32}, {128, 64, 4, 32}, {128, 32, 8, 16},
     // Winograd: BM in pixels = 4 x blocks
     {256, 64, 16, 16}, {256, 64, 16, 16}, {512, 32, 16, 32}, {512, 32, 16, 32}, {128, 128, 8, 16},
-    {128, 128, 8, 16}, {256, 64, 8, 32}};
+    {128, 128, 8, 16}, {256, 64, 8, 32},
+    // 8-wave Winograd
+    {256, 64, 16, 16}, {256, 64, 16, 16}, {512, 32, 16, 32}, {256, 64, 8, 32}};
 
 }  // namespace
 
@@ -224,7 +226,7 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a, hipStream_t st)
   const int tiles = ceil_div(a.Hout, tile_th(tile)) * ceil_div(a.Wout, tile_tw(tile));
   dim3 grid(tiles, ceil_div(a.Cout, tile_bn(tile)), a.B * a.ksplit);
   FDT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, FDT_ERR_ARG, "launch_conv: grid too large");
-  hipLaunchKernelGGL(ke.fn, grid, dim3(256), ke.lds, st, a);
+  hipLaunchKernelGGL(ke.fn, grid, dim3(ke.threads), ke.lds, st, a);
   FDT_LAUNCH_CHECK();
   if (a.ws) {
     const long long total = (long long)a.B * a.Cout * a.Hout * a.Wout;

@@ -334,6 +334,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
 struct KernelEntry {
   void (*fn)(const ConvArgs);
   size_t lds;
+  int threads = 256;
 };
 
 //                     TH  TW  BN  WM WN NBUF
@@ -354,7 +355,7 @@ using T_128x32R3   = Tile<8, 16, 32, 4, 1, 3>;
 
 template <class G, class T>
 KernelEntry entry() {
-  return KernelEntry{conv_kernel<G, T>, Layout<G, T>::LDS_BYTES};
+  return KernelEntry{conv_kernel<G, T>, Layout<G, T>::LDS_BYTES, 256};
 }
 
 template <class G>

@@ -31,7 +31,7 @@ struct WinoTile {
   static constexpr int PH = 2 * TTH + 2, PW = 2 * TTW + 2;
   static constexpr int XPLANE = PH * PW;
   static constexpr int XSZ = KC * XPLANE;
-  static constexpr int XSZP = (XSZ + 255) / 256 * 256;
+  static constexpr int XSZP = (XSZ + 511) / 512 * 512;   // whole LDS-DMA wave-instructions for 4 or 8 waves
   static constexpr int WSZ = KC * 16 * BN;
   static constexpr int WSZP = (WSZ + 1023) / 1024 * 1024;
   static constexpr int STAGE = XSZP + WSZP;
@@ -209,6 +209,191 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 8-wave form: the 16 transform positions are split between two waves that share one SIMD -- waves 0-3
+// own rows 0,1 of the 4x4 position grid, waves 4-7 rows 2,3 -- so each wave carries 8 accumulators
+// (128 AGPRs) and TWO waves per SIMD hide each other's LDS / LDS-DMA / barrier latency.  Same workgroup
+// tile, same LDS stage and DMA traffic as the 4-wave form; the two halves of the (linear) output
+// transform meet through LDS once, in the epilogue.
+template <class T>
+__global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(T::XSZP % 512 == 0 && T::WSZP % 2048 == 0, "8-wave staging granularity");
+  constexpr int NX2 = T::XSZP / 512, NW2 = T::WSZP / 2048, LOADS2 = NX2 + NW2;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int th = wave >> 2;                                  // which half of the position grid
+  const int w3 = wave & 3;
+  const int wm = w3 / T::WN, wn = w3 % T::WN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  constexpr int TH = 2 * T::TTH, TW = 2 * T::TTW;
+  const int tiles_x = (a.Wout + TW - 1) / TW;
+  const int oy0 = (blockIdx.x / tiles_x) * TH;
+  const int ox0 = (blockIdx.x % tiles_x) * TW;
+  const int n_tile = blockIdx.y;
+  const int b = blockIdx.z / a.ksplit;
+  const int ks = blockIdx.z - b * a.ksplit;
+
+  const int HW = a.Hin * a.Win;
+  const float* in_b = a.in + (long long)b * a.Cin * HW;
+  const int nstages = (a.Cin + T::KC - 1) / T::KC;
+  const float* w_t = a.w + (long long)n_tile * nstages * T::WSZP;
+  const int s_begin = (int)((long long)nstages * ks / a.ksplit);
+  const int s_end = (int)((long long)nstages * (ks + 1) / a.ksplit);
+
+  int goff[NX2];
+  unsigned okmask = 0;
+#pragma unroll
+  for (int k = 0; k < NX2; ++k) {
+    int e = tid + 512 * k;
+    int c = e / T::XPLANE;
+    int r = e - c * T::XPLANE;
+    int yy = r / T::PW, xx = r - yy * T::PW;
+    int gy = oy0 - 1 + yy, gx = ox0 - 1 + xx;
+    bool ok = (e < T::XSZ) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+    goff[k] = ok ? (c * HW + gy * a.Win + gx) : 0;
+    if (ok) okmask |= (1u << k);
+  }
+
+#define FDT_W2STAGE(s_, buf_)                                                                  \
+  {                                                                                            \
+    const int c0_ = (s_) * T::KC;                                                              \
+    const float* src_ = in_b + (long long)c0_ * HW;                                            \
+    const int crem_ = a.Cin - c0_;                                                             \
+    float* X_ = smem + (buf_) * T::STAGE + wave * 64;                                          \
+    _Pragma("unroll") for (int k = 0; k < NX2; ++k) {                                          \
+      const int c_ = (tid + 512 * k) / T::XPLANE;                                              \
+      const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                     \
+      glds4(ok_ ? src_ + goff[k] : g_zero_pad, X_ + 512 * k);                                  \
+    }                                                                                          \
+    const float* wsrc_ = w_t + (long long)(s_) * T::WSZP + tid * 4;                            \
+    float* W_ = smem + (buf_) * T::STAGE + T::XSZP + wave * 256;                               \
+    _Pragma("unroll") for (int k = 0; k < NW2; ++k) glds16(wsrc_ + 2048 * k, W_ + 2048 * k);   \
+  }
+
+  const int q = wm * 32 + l31;
+  const int ty = q / T::TTW, tx = q % T::TTW;
+  const int xo = half * T::XPLANE + (2 * ty) * T::PW + 2 * tx;
+  const int wo = T::XSZP + half * 16 * T::BN + th * 8 * T::BN + wn * 32 + l31;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  const int nst = s_end - s_begin;
+#pragma unroll
+  for (int p = 0; p < T::NBUF - 1; ++p)
+    if (p < nst) FDT_W2STAGE(s_begin + p, p);
+  int cur = 0, nxt = T::NBUF - 1;
+  for (int it = 0; it < nst; ++it) {
+    if (T::NBUF >= 3 && it + 1 < nst)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS2) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + T::NBUF - 1 < nst) FDT_W2STAGE(s_begin + it + T::NBUF - 1, nxt);
+    const float* S = smem + cur * T::STAGE;
+#pragma unroll
+    for (int cp = 0; cp < T::KC / 2; ++cp) {
+      float d[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float2 lo = *reinterpret_cast<const float2*>(S + xo + (2 * cp) * T::XPLANE + i * T::PW);
+        const float2 hi = *reinterpret_cast<const float2*>(S + xo + (2 * cp) * T::XPLANE + i * T::PW + 2);
+        d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+      }
+      // the two rows of B^T d this wave needs: th = 0: (d0 - d2, d1 + d2); th = 1: (d2 - d1, d1 - d3)
+      float ra[4], rb[4], v[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ra[j] = th ? (d[2][j] - d[1][j]) : (d[0][j] - d[2][j]);
+        rb[j] = th ? (d[1][j] - d[3][j]) : (d[1][j] + d[2][j]);
+      }
+      v[0][0] = ra[0] - ra[2]; v[0][1] = ra[1] + ra[2]; v[0][2] = ra[2] - ra[1]; v[0][3] = ra[1] - ra[3];
+      v[1][0] = rb[0] - rb[2]; v[1][1] = rb[1] + rb[2]; v[1][2] = rb[2] - rb[1]; v[1][3] = rb[1] - rb[3];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float u = S[wo + ((2 * cp) * 16 + t) * T::BN];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(u, v[t >> 2][t & 3], acc[t], 0, 0, 0);
+      }
+    }
+    cur = (cur + 1 == T::NBUF) ? 0 : cur + 1;
+    nxt = (nxt + 1 == T::NBUF) ? 0 : nxt + 1;
+  }
+#undef FDT_W2STAGE
+
+  // ---- output transform: each half contributes linearly; halves meet through LDS ------------------------
+  //   th 0 (rows 0,1): s0 = M0 + M1, s1 = M1          th 1 (rows 2,3): s0 = M2, s1 = -M2 - M3
+  __syncthreads();                       // ring is dead; reuse it as the exchange buffer
+  float* E = smem + (long long)w3 * (16 * 4 * 64);
+  const int HWo = a.Hout * a.Wout;
+  const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
+  const bool raw = a.ws != nullptr;
+  float* dst_b = raw ? a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWo
+                     : a.out + ((long long)b * a.out_ctot + a.out_coff) * HWo;
+  const float* res_b = (!raw && a.res) ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWo : nullptr;
+  const bool row0 = oy < a.Hout, row1 = oy + 1 < a.Hout;
+  const bool col0 = ox < a.Wout, col1 = ox + 1 < a.Wout;
+  const bool vec2 = (a.Wout % 2 == 0);
+  float yp[16][4];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float s0[4], s1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s0[j] = th ? acc[j][r] : (acc[j][r] + acc[4 + j][r]);
+      s1[j] = th ? (-acc[j][r] - acc[4 + j][r]) : acc[4 + j][r];
+    }
+    yp[r][0] = s0[0] + s0[1] + s0[2];
+    yp[r][1] = s0[1] - s0[2] - s0[3];
+    yp[r][2] = s1[0] + s1[1] + s1[2];
+    yp[r][3] = s1[1] - s1[2] - s1[3];
+  }
+  if (th) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) E[(r * 4 + k) * 64 + lane] = yp[r][k];
+  }
+  __syncthreads();
+  if (th) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = n_tile * T::BN + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    float y00 = yp[r][0] + E[(r * 4 + 0) * 64 + lane], y01 = yp[r][1] + E[(r * 4 + 1) * 64 + lane];
+    float y10 = yp[r][2] + E[(r * 4 + 2) * 64 + lane], y11 = yp[r][3] + E[(r * 4 + 3) * 64 + lane];
+    if (co < a.Cout && col0) {
+      const long long base = (long long)co * HWo + (long long)oy * a.Wout + ox;
+      if (!raw) {
+        const float bv = a.bias ? a.bias[co] : 0.0f;
+        y00 += bv; y01 += bv; y10 += bv; y11 += bv;
+        if (res_b) {
+          if (row0) { y00 += res_b[base]; if (col1) y01 += res_b[base + 1]; }
+          if (row1) { y10 += res_b[base + a.Wout]; if (col1) y11 += res_b[base + a.Wout + 1]; }
+        }
+        if (a.act == ACT_RELU) {
+          y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f);
+        } else if (a.act == ACT_RELU6) {
+          y00 = fminf(fmaxf(y00, 0.f), 6.f); y01 = fminf(fmaxf(y01, 0.f), 6.f);
+          y10 = fminf(fmaxf(y10, 0.f), 6.f); y11 = fminf(fmaxf(y11, 0.f), 6.f);
+        }
+      }
+      if (vec2) {
+        if (row0) *reinterpret_cast<float2*>(dst_b + base) = make_float2(y00, y01);
+        if (row1) *reinterpret_cast<float2*>(dst_b + base + a.Wout) = make_float2(y10, y11);
+      } else {
+        if (row0) { dst_b[base] = y00; if (col1) dst_b[base + 1] = y01; }
+        if (row1) { dst_b[base + a.Wout] = y10; if (col1) dst_b[base + a.Wout + 1] = y11; }
+      }
+    }
+  }
+}
+
 //                           TTH TTW WM WN KC NBUF      patch (px)  couts
 using W_64x64    = WinoTile<8, 8, 2, 2, 8, 2>;     //  16 x 16     64
 using W_64x64R3  = WinoTile<8, 8, 2, 2, 8, 3>;
@@ -219,7 +404,12 @@ using W_64x64W   = WinoTile<4, 16, 2, 2, 8, 3>;    //   8 x 32     64  (wide row
 
 template <class T>
 KernelEntry wino_entry() {
-  return KernelEntry{conv_wino_kernel<T>, T::LDS_BYTES};
+  return KernelEntry{conv_wino_kernel<T>, T::LDS_BYTES, 256};
+}
+template <class T>
+KernelEntry wino2_entry() {
+  constexpr size_t ex = 4 * 16 * 4 * 64 * sizeof(float);   // epilogue exchange buffer
+  return KernelEntry{conv_wino2_kernel<T>, T::LDS_BYTES > ex ? T::LDS_BYTES : ex, 512};
 }
 
 }  // namespace

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 KINDS = {  # name: (k, stride, pad, dil)
     "1x1s1": (1, 1, 0, 1), "1x1s2": (1, 2, 0, 1), "3x3s1": (3, 1, 1, 1), "3x3d2": (3, 1, 2, 2),
     "3x3s2": (3, 2, 1, 1), "7x7s2": (7, 2, 3, 1), "7x7s4": (7, 4, 3, 1), "5x5s2": (5, 2, 2, 1)}
-N_TILES = 21      # 14 direct tiles + 7 Winograd F(2x2,3x3) tiles (3x3 s1 only)
+N_TILES = 25      # 14 direct tiles + 11 Winograd F(2x2,3x3) tiles (3x3 s1 only)
 
 
 def lib():
@@ -96,7 +96,7 @@ def test_fused_epilogues(tile, W):
             assert rel_err(got, reference(x, w, b, 1, 1, 0, 1, **kw)) < 1e-5, (tile, W, split, list(kw))
 
 
-@pytest.mark.parametrize("tile", range(14, 21))
+@pytest.mark.parametrize("tile", range(14, 25))
 @pytest.mark.parametrize("shape", [(64, 40, 48, 96), (37, 31, 45, 70)])
 def test_winograd_variants(tile, shape):
     """Winograd F(2x2,3x3): 2.25x fewer multiplies, same result up to f32 rounding of the transforms
