@@ -18,6 +18,7 @@ enum ConvKind {
   CONV_7x7_S4,      // pad 3 (FaceBox conv1)
   CONV_5x5_S2,      // pad 2 (FaceBox conv2)
   CONV_3x3_S1_WINO, // same arithmetic class as CONV_3x3_S1, computed with Winograd F(2x2,3x3)
+  CONV_3x3_D2_WINO, // same arithmetic class as CONV_3x3_S1_D2 (dilation 2), Winograd on the parity sub-lattices
   CONV_KIND_COUNT
 };
 

