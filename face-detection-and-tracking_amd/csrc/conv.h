@@ -19,6 +19,8 @@ enum ConvKind {
   CONV_5x5_S2,      // pad 2 (FaceBox conv2)
   CONV_3x3_S1_WINO, // same arithmetic class as CONV_3x3_S1, computed with Winograd F(2x2,3x3)
   CONV_3x3_D2_WINO, // same arithmetic class as CONV_3x3_S1_D2 (dilation 2), Winograd on the parity sub-lattices
+  CONV_1x1_S1_K32,  // CONV_1x1_S1 with 32 / 64 input channels per LDS stage (fewer, longer stages for the
+  CONV_1x1_S1_K64,  // small-tile, deep-K layers)
   CONV_KIND_COUNT
 };
 

@@ -111,6 +111,7 @@ struct Table {
     conv_fill_stems(e[CONV_7x7_S2], e[CONV_7x7_S4], e[CONV_5x5_S2]);
     conv_fill_wino(e[CONV_3x3_S1_WINO]);
     conv_fill_wino_d2(e[CONV_3x3_D2_WINO]);
+    conv_fill_1x1_s1_deep(e[CONV_1x1_S1_K32], e[CONV_1x1_S1_K64]);
   }
 };
 
@@ -122,7 +123,7 @@ Table& table() {
 const ConvGeom kGeoms[CONV_KIND_COUNT] = {
     {1, 1, 1, 1, 0, 16, 0}, {1, 1, 2, 1, 0, 16, 0}, {3, 3, 1, 1, 1, 4, 0}, {3, 3, 1, 2, 2, 4, 0},
     {3, 3, 2, 1, 1, 4, 0},  {7, 7, 2, 1, 3, 2, 0},  {7, 7, 4, 1, 3, 2, 0}, {5, 5, 2, 1, 2, 2, 0},
-    {3, 3, 1, 1, 1, 8, 1},  {3, 3, 1, 2, 2, 8, 1},
+    {3, 3, 1, 1, 1, 8, 1},  {3, 3, 1, 2, 2, 8, 1},  {1, 1, 1, 1, 0, 32, 0},  {1, 1, 1, 1, 0, 64, 0},
 };
 const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum ConvTile)
     {128, 128, 8, 16}, {128, 64, 8, 16}, {128, 32, 8, 16}, {64, 64, 8, 8},   {64, 128, 8, 8},
@@ -138,7 +139,13 @@ const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum 
 
 ConvGeom conv_geom(ConvKind k) { return kGeoms[k]; }
 ConvKind conv_base_kind(ConvKind k) {
-  return k == CONV_3x3_S1_WINO ? CONV_3x3_S1 : (k == CONV_3x3_D2_WINO ? CONV_3x3_S1_D2 : k);
+  switch (k) {
+    case CONV_3x3_S1_WINO: return CONV_3x3_S1;
+    case CONV_3x3_D2_WINO: return CONV_3x3_S1_D2;
+    case CONV_1x1_S1_K32:
+    case CONV_1x1_S1_K64: return CONV_1x1_S1;
+    default: return k;
+  }
 }
 int tile_bm(ConvTile t) { return kTileDims[t][0]; }
 int tile_bn(ConvTile t) { return kTileDims[t][1]; }
@@ -259,7 +266,9 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
   int kind = -1;
   for (int k = 0; k < CONV_KIND_COUNT; ++k) {
     const ConvGeom g = conv_geom((ConvKind)k);
-    if (!g.wino && g.kh == ksize && g.kw == ksize && g.stride == stride && g.pad == pad && g.dil == dil) kind = k;
+    if (conv_base_kind((ConvKind)k) == (ConvKind)k && g.kh == ksize && g.kw == ksize && g.stride == stride &&
+        g.pad == pad && g.dil == dil)
+      kind = k;
   }
   FDT_REQUIRE(kind >= 0, FDT_ERR_ARG, "fdt_conv2d: no kernel class for k=%d stride=%d pad=%d dil=%d", ksize,
               stride, pad, dil);
@@ -277,6 +286,13 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
       if (conv_supported((ConvKind)kind, (ConvTile)t) && (Cout > 64 || tile_bn((ConvTile)t) <= 64)) tile = t;
     for (int t = 0; t < CONV_TILE_COUNT && tile < 0; ++t)
       if (conv_supported((ConvKind)kind, (ConvTile)t)) tile = t;
+  }
+  if (tile >= 100) {   // explicit implementation variant: tile = variant_kind * 100 + tile
+    const int alt = tile / 100;
+    tile %= 100;
+    FDT_REQUIRE(alt < CONV_KIND_COUNT && conv_base_kind((ConvKind)alt) == (ConvKind)kind, FDT_ERR_ARG,
+                "fdt_conv2d: kernel class %d does not implement this convolution", alt);
+    kind = alt;
   }
   if (kind == CONV_3x3_S1 && tile >= TILE_WINO_64x64 && tile < CONV_TILE_COUNT) kind = CONV_3x3_S1_WINO;
   if (kind == CONV_3x3_S1_D2 && tile >= TILE_WINO_64x64 && tile < CONV_TILE_COUNT) kind = CONV_3x3_D2_WINO;

@@ -378,6 +378,8 @@ void fill_row(KernelEntry* row) {
 
 using G_1x1_S1 = Geom<1, 1, 1, 1, 0, 16>;
 using G_1x1_S2 = Geom<1, 1, 2, 1, 0, 16>;
+using G_1x1_S1_K32 = Geom<1, 1, 1, 1, 0, 32>;
+using G_1x1_S1_K64 = Geom<1, 1, 1, 1, 0, 64>;
 using G_3x3_S1 = Geom<3, 3, 1, 1, 1, 4>;
 using G_3x3_S1_D2 = Geom<3, 3, 1, 2, 2, 4>;
 using G_3x3_S2 = Geom<3, 3, 2, 1, 1, 4>;
@@ -390,6 +392,7 @@ using G_5x5_S2 = Geom<5, 5, 2, 1, 2, 2>;
 // one per conv_inst_*.hip
 void conv_fill_1x1_s1(void* row);
 void conv_fill_1x1_s2(void* row);
+void conv_fill_1x1_s1_deep(void* row_k32, void* row_k64);
 void conv_fill_3x3_s1(void* row);
 void conv_fill_3x3_s1_d2(void* row);
 void conv_fill_3x3_s2(void* row);

@@ -118,6 +118,28 @@ def test_winograd_variants(tile, shape):
             assert rel_err(got, exp) < 3e-5, (tile, shape, split, rel_err(got, exp))
 
 
+@pytest.mark.parametrize("variant", [10, 11])      # CONV_1x1_S1_K32 / _K64: 32 / 64 channels per LDS stage
+def test_deep_stage_1x1_variants(variant):
+    rng = np.random.default_rng(variant)
+    tested = 0
+    for (Cin, H, W, Cout) in ((200, 24, 32, 72), (70, 19, 21, 40)):
+        x = rng.standard_normal((2, Cin, H, W)).astype(np.float32)
+        w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+        b = rng.standard_normal(Cout).astype(np.float32)
+        res = rng.standard_normal((2, Cout, H, W)).astype(np.float32)
+        exp = reference(x, w, b, 1, 1, 0, 1, res=res, act=1)
+        for tile in range(14):
+            for split in (1, 2):
+                rc, got = run_conv(x, w, b, 1, 1, 0, 1, res=res, act=1, tile=variant * 100 + tile, split=split)
+                if rc != 0:
+                    msg = lib().lib().fdt_last_error()
+                    assert b"not instantiated" in msg or b"bad split-K" in msg, msg
+                    continue
+                tested += 1
+                assert rel_err(got, exp) < 1e-5, (variant, tile, split, rel_err(got, exp))
+    assert tested >= 8
+
+
 def test_deep_reduction_split_k_is_deterministic():
     rng = np.random.default_rng(5)
     x = rng.standard_normal((1, 512, 16, 16)).astype(np.float32)
