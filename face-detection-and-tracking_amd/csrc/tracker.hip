@@ -1,9 +1,9 @@
 // Device-resident IoU tracker: the inline tracker of reference iouTracke_cal.py:113-156 (per frame) and
-// :174-177 (finalise) as one single-wave kernel per frame plus an event log that the host replays.
+// :174-177 (finalise) as one single-workgroup kernel per frame plus an event log that the host replays.
 //
-// Why a single wave: the association is strictly sequential over the active tracks (greedy, order
-// dependent, iouTracke_cal.py:129-148); per track it is an arg-max over <= a few hundred f64 IoUs, which
-// one wave64 does with lane-strided IoUs and six __shfl_xor steps -- no barrier, no LDS traffic.
+// Why one workgroup: the association is strictly sequential over the active tracks (greedy, order
+// dependent, iouTracke_cal.py:129-148); see track_step_kernel for how the per-track arg-max is hoisted
+// out of the sequential part.
 // Nothing syncs with the host per frame: detections are read straight from the Detect output on the
 // same stream, the active set lives in HBM, and each frame appends {dets, det->track id, finished ids}
 // to a log that is copied back only at finish()/flush.
@@ -62,22 +62,43 @@ __device__ __forceinline__ bool better(double av, int ai, double bv, int bi) {
   return ai < bi;
 }
 
-// One frame.  Launch <<<1, 64>>>.  `dets_in` (f64 [n_in,5]) xor `det_out` (f32 [C,top_k,5]) is given.
-__global__ __launch_bounds__(64) void track_step_kernel(
+constexpr int TRK_THREADS = 1024;             // one workgroup of 16 waves per frame
+constexpr int TRK_LDS_PER_SLOT = 72;          // bytes of LDS per detection/track slot (see the carve-up below)
+
+// One frame.  Launch <<<1, TRK_THREADS, M * TRK_LDS_PER_SLOT>>>.  `dets_in` (f64 [n_in,5]) xor `det_out`
+// (f32 [C,top_k,5]) is given.
+//
+// The greedy loop of iouTracke_cal.py:129-148 is sequential over the tracks, but its expensive part is not:
+//   phase 1 (16 waves, one track per wave at a time): arg-max of the track's IoU row over ALL detections;
+//   phase 2 (wave 0, in track order): if that detection is still free it is also the arg-max over the
+//     remaining list (deleting other rows cannot change the first maximum), so the track takes it with a
+//     few LDS reads; only when an earlier track has taken it is the row re-evaluated over the free ones.
+// Detections, the per-track results and the det->track map live in LDS for the whole kernel.
+__global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
     TrkState* __restrict__ st, ActiveSet cur, ActiveSet nxt, int M, double sigma_iou, double sigma_h,
     int t_min, const double* __restrict__ dets_in, int n_in, const float* __restrict__ det_out,
     int num_classes, int top_k, float fw, float fh, float score_thr, char* __restrict__ log,
     long long log_cap) {
-  extern __shared__ int smem[];
-  int* det_tid = smem;                       // [M]  track id that took det j, -1 while free
-  const int lane = threadIdx.x;
+  extern __shared__ double smem_d[];
+  double* dbox = smem_d;                     // [M][4] this frame's boxes
+  double* dscore = dbox + (size_t)M * 4;     // [M]
+  double* best_v = dscore + M;               // [M] per active track: best IoU over all detections ...
+  double* tmaxs = best_v + M;                // [M] ... and the track's max_score
+  int* best_i = (int*)(tmaxs + M);           // [M] ... its arg-max
+  int* tlens = best_i + M;                   // [M]
+  int* tids = tlens + M;                     // [M]
+  volatile int* det_tid = tids + M;          // [M] track id that took det j, -1 while free
+  __shared__ int s_first_fail;
+  __shared__ int s_counts[3];                // n_upd, n_fin, n_new
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = TRK_THREADS / 64;
   const int frame = st->frame_num + 1;       // iouTracke_cal.py:118 (1-based)
 
   // ---- record header + this frame's detections -------------------------------------------------
-  long long cursor = st->log_cursor;
-  long long rec_max = 16 + (long long)M * (40 + 4 + 4) + 8;
-  if (cursor + rec_max > log_cap) {
-    if (lane == 0) st->overflow = 1;
+  const long long cursor = st->log_cursor;
+  const long long rec_max = 16 + (long long)M * (40 + 4 + 4) + 8;
+  if (cursor + rec_max > log_cap) {          // uniform over the block
+    if (tid == 0) st->overflow = 1;
     return;
   }
   int* hdr = (int*)(log + cursor);
@@ -88,51 +109,57 @@ __global__ __launch_bounds__(64) void track_step_kernel(
     // score >= thr (f32 compare), box = row[1:5] * (w,h,w,h) in f32, then widen.
     for (int c = 0; c < num_classes; ++c) {
       const float* plane = det_out + (long long)c * top_k * 5;
-      int first_fail = top_k;
-      for (int j = lane; j < top_k; j += 64)
-        if (!(plane[j * 5] >= score_thr)) { first_fail = j; break; }
-      for (int o = 32; o > 0; o >>= 1) {
-        int other = __shfl_xor(first_fail, o, 64);
-        first_fail = other < first_fail ? other : first_fail;
-      }
-      int cnt = first_fail;
+      if (tid == 0) s_first_fail = top_k;
+      __syncthreads();
+      for (int j = tid; j < top_k; j += TRK_THREADS)
+        if (!(plane[j * 5] >= score_thr)) atomicMin(&s_first_fail, j);
+      __syncthreads();
+      int cnt = s_first_fail;
       if (n + cnt > M) cnt = M - n;
-      for (int j = lane; j < cnt; j += 64) {
+      for (int j = tid; j < cnt; j += TRK_THREADS) {
         const float* r = plane + j * 5;
+        const double b0 = (double)(r[1] * fw), b1 = (double)(r[2] * fh);
+        const double b2 = (double)(r[3] * fw), b3 = (double)(r[4] * fh), sc = (double)r[0];
         double* d = dets + (long long)(n + j) * 5;
-        d[0] = (double)(r[1] * fw);
-        d[1] = (double)(r[2] * fh);
-        d[2] = (double)(r[3] * fw);
-        d[3] = (double)(r[4] * fh);
-        d[4] = (double)r[0];
+        d[0] = b0; d[1] = b1; d[2] = b2; d[3] = b3; d[4] = sc;
+        double* l = dbox + (size_t)(n + j) * 4;
+        l[0] = b0; l[1] = b1; l[2] = b2; l[3] = b3;
+        dscore[n + j] = sc;
       }
       n += cnt;
+      __syncthreads();
     }
     if (n == 0) {   // :73-74 dummy row np.array([[0,0,0,0,0.4]]) (f64)
-      if (lane == 0) { dets[0] = 0; dets[1] = 0; dets[2] = 0; dets[3] = 0; dets[4] = 0.4; }
+      if (tid == 0) {
+        dets[0] = 0; dets[1] = 0; dets[2] = 0; dets[3] = 0; dets[4] = 0.4;
+        dbox[0] = 0; dbox[1] = 0; dbox[2] = 0; dbox[3] = 0; dscore[0] = 0.4;
+      }
       n = 1;
     }
   } else {
     n = n_in < M ? n_in : M;
-    for (int j = lane; j < n * 5; j += 64) dets[j] = dets_in[j];
+    for (int j = tid; j < n; j += TRK_THREADS) {
+      const double* r = dets_in + (long long)j * 5;
+      double* d = dets + (long long)j * 5;
+      double* l = dbox + (size_t)j * 4;
+      for (int k = 0; k < 4; ++k) { d[k] = r[k]; l[k] = r[k]; }
+      d[4] = r[4];
+      dscore[j] = r[4];
+    }
   }
   int* tid_log = (int*)(log + cursor + 16 + (long long)n * 40);
   int* fin_log = tid_log + n;
-  for (int j = lane; j < n; j += 64) det_tid[j] = -1;
-  __syncthreads();   // single wave: orders the global/LDS writes above for the reads below
+  for (int j = tid; j < n; j += TRK_THREADS) det_tid[j] = -1;
+  __syncthreads();
 
-  // ---- greedy association, sequential over the active tracks (:129-148) -------------------------
+  // ---- phase 1: every track's arg-max over all detections, tracks spread over the waves --------
   const int T = st->n_active;
-  int n_alive = n;
-  int n_upd = 0, n_fin = 0;
-  for (int t = 0; t < T; ++t) {
-    if (n_alive == 0) break;                 // :130 has no else: remaining tracks vanish
-    double tb[4] = {cur.box[t * 4 + 0], cur.box[t * 4 + 1], cur.box[t * 4 + 2], cur.box[t * 4 + 3]};
+  for (int t = wave; t < T; t += NW) {
+    const double tb[4] = {cur.box[t * 4 + 0], cur.box[t * 4 + 1], cur.box[t * 4 + 2], cur.box[t * 4 + 3]};
     double bv = 0.0;
     int bi = -1;
     for (int j = lane; j < n; j += 64) {
-      if (det_tid[j] != -1) continue;
-      double v = iou64(dets + (long long)j * 5, tb);
+      double v = iou64(dbox + (size_t)j * 4, tb);
       if (better(v, j, bv, bi)) { bv = v; bi = j; }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -140,66 +167,104 @@ __global__ __launch_bounds__(64) void track_step_kernel(
       int oi = __shfl_xor(bi, o, 64);
       if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
     }
-    const double tmax = cur.max_score[t];
-    const int tlen = cur.len[t];
-    const int tidv = cur.id[t];
-    if (bv > sigma_iou) {                    // :134 strict; NaN -> unmatched
-      if (lane == 0) {
-        const double* d = dets + (long long)bi * 5;
-        nxt.box[n_upd * 4 + 0] = d[0];
-        nxt.box[n_upd * 4 + 1] = d[1];
-        nxt.box[n_upd * 4 + 2] = d[2];
-        nxt.box[n_upd * 4 + 3] = d[3];
-        nxt.max_score[n_upd] = (d[4] > tmax) ? d[4] : tmax;   // max(track, det)  :141
-        nxt.len[n_upd] = tlen + 1;
-        nxt.id[n_upd] = tidv;
-        det_tid[bi] = tidv;
-      }
-      ++n_upd;
-      --n_alive;
-      __syncthreads();
-    } else if (tmax > sigma_h && tlen > t_min) {   // :146
-      if (lane == 0) fin_log[n_fin] = tidv;
-      ++n_fin;
+    if (lane == 0) {
+      best_v[t] = bv;
+      best_i[t] = bi;
+      tmaxs[t] = cur.max_score[t];
+      tlens[t] = cur.len[t];
+      tids[t] = cur.id[t];
     }
-  }
-
-  // ---- remaining detections start new tracks, in detection order (:150-155) ---------------------
-  const int next_id = st->next_id;
-  int n_new = 0;
-  for (int base = 0; base < n; base += 64) {
-    int j = base + lane;
-    bool fresh = (j < n) && det_tid[j] == -1;
-    unsigned long long bal = __ballot(fresh);
-    if (fresh) {
-      int r = n_new + __popcll(bal & ((1ull << lane) - 1ull));
-      int slot = n_upd + r;
-      const double* d = dets + (long long)j * 5;
-      nxt.box[slot * 4 + 0] = d[0];
-      nxt.box[slot * 4 + 1] = d[1];
-      nxt.box[slot * 4 + 2] = d[2];
-      nxt.box[slot * 4 + 3] = d[3];
-      nxt.max_score[slot] = d[4];
-      nxt.len[slot] = 1;
-      nxt.id[slot] = next_id + r;
-      det_tid[j] = next_id + r;
-    }
-    n_new += __popcll(bal);
   }
   __syncthreads();
-  for (int j = lane; j < n; j += 64) tid_log[j] = det_tid[j];
-  if (lane == 0) {
-    hdr[0] = n;
-    hdr[1] = n_fin;
-    hdr[2] = frame;
-    hdr[3] = 0;
-    long long rec = 16 + (long long)n * 40 + (long long)(n + n_fin) * 4;
-    rec = (rec + 7) & ~7ll;
-    st->log_cursor = cursor + rec;
-    st->n_active = n_upd + n_new;
-    st->next_id = next_id + n_new;
-    st->frame_num = frame;
+
+  if (wave == 0) {
+    // ---- phase 2: greedy association in track order (:129-148), one wave -----------------------
+    int n_alive = n;
+    int n_upd = 0, n_fin = 0;
+    for (int t = 0; t < T; ++t) {
+      if (n_alive == 0) break;               // :130 has no else: remaining tracks vanish
+      double bv = best_v[t];
+      int bi = best_i[t];
+      const double tmax = tmaxs[t];
+      const int tlen = tlens[t];
+      const int tidv = tids[t];
+      if (det_tid[bi] != -1) {               // taken by an earlier track: arg-max over the free rows
+        const double tb[4] = {cur.box[t * 4 + 0], cur.box[t * 4 + 1], cur.box[t * 4 + 2], cur.box[t * 4 + 3]};
+        bv = 0.0;
+        bi = -1;
+        for (int j = lane; j < n; j += 64) {
+          if (det_tid[j] != -1) continue;
+          double v = iou64(dbox + (size_t)j * 4, tb);
+          if (better(v, j, bv, bi)) { bv = v; bi = j; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+          double ov = __shfl_xor(bv, o, 64);
+          int oi = __shfl_xor(bi, o, 64);
+          if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+      }
+      if (bv > sigma_iou) {                  // :134 strict; NaN -> unmatched
+        if (lane == 0) {
+          const double* d = dbox + (size_t)bi * 4;
+          const double sc = dscore[bi];
+          nxt.box[n_upd * 4 + 0] = d[0];
+          nxt.box[n_upd * 4 + 1] = d[1];
+          nxt.box[n_upd * 4 + 2] = d[2];
+          nxt.box[n_upd * 4 + 3] = d[3];
+          nxt.max_score[n_upd] = (sc > tmax) ? sc : tmax;   // max(track, det)  :141
+          nxt.len[n_upd] = tlen + 1;
+          nxt.id[n_upd] = tidv;
+          det_tid[bi] = tidv;
+        }
+        ++n_upd;
+        --n_alive;
+        __builtin_amdgcn_wave_barrier();     // LDS ops of one wave complete in order; keep the compiler honest
+      } else if (tmax > sigma_h && tlen > t_min) {   // :146
+        if (lane == 0) fin_log[n_fin] = tidv;
+        ++n_fin;
+      }
+    }
+
+    // ---- remaining detections start new tracks, in detection order (:150-155) -------------------
+    const int next_id = st->next_id;
+    int n_new = 0;
+    for (int base = 0; base < n; base += 64) {
+      int j = base + lane;
+      bool fresh = (j < n) && det_tid[j] == -1;
+      unsigned long long bal = __ballot(fresh);
+      if (fresh) {
+        int r = n_new + __popcll(bal & ((1ull << lane) - 1ull));
+        int slot = n_upd + r;
+        const double* d = dbox + (size_t)j * 4;
+        nxt.box[slot * 4 + 0] = d[0];
+        nxt.box[slot * 4 + 1] = d[1];
+        nxt.box[slot * 4 + 2] = d[2];
+        nxt.box[slot * 4 + 3] = d[3];
+        nxt.max_score[slot] = dscore[j];
+        nxt.len[slot] = 1;
+        nxt.id[slot] = next_id + r;
+        det_tid[j] = next_id + r;
+      }
+      n_new += __popcll(bal);
+    }
+    if (lane == 0) {
+      s_counts[0] = n_upd;
+      s_counts[1] = n_fin;
+      s_counts[2] = n_new;
+      hdr[0] = n;
+      hdr[1] = n_fin;
+      hdr[2] = frame;
+      hdr[3] = 0;
+      long long rec = 16 + (long long)n * 40 + (long long)(n + n_fin) * 4;
+      rec = (rec + 7) & ~7ll;
+      st->log_cursor = cursor + rec;
+      st->n_active = n_upd + n_new;
+      st->next_id = next_id + n_new;
+      st->frame_num = frame;
+    }
   }
+  __syncthreads();
+  for (int j = tid; j < n; j += TRK_THREADS) tid_log[j] = det_tid[j];
 }
 
 }  // namespace
@@ -303,7 +368,8 @@ int step_common(fdt_tracker* t, const double* dets_dev, int n, const float* det_
                 int w, int h, float thr, hipStream_t st) {
   FDT_REQUIRE(!t->finalized, FDT_ERR_STATE, "fdt_tracker: already finished; call reset");
   if (t->frames_in_log >= t->log_frames) FDT_TRY(flush_log(t));
-  hipLaunchKernelGGL(fdt::track_step_kernel, dim3(1), dim3(64), (size_t)t->M * 4, st, t->d_state,
+  hipLaunchKernelGGL(fdt::track_step_kernel, dim3(1), dim3(fdt::TRK_THREADS), (size_t)t->M * fdt::TRK_LDS_PER_SLOT,
+                     st, t->d_state,
                      t->set[t->cur], t->set[t->cur ^ 1], t->M, t->sigma_iou, t->sigma_h, t->t_min,
                      dets_dev, n, det_out, nc, top_k, (float)w, (float)h, thr, t->d_log, t->log_cap);
   FDT_LAUNCH_CHECK();
@@ -321,6 +387,11 @@ extern "C" fdt_tracker* fdt_tracker_create(double sigma_iou, double sigma_h, int
     set_error("fdt_tracker_create: max_dets and log_frames must be >= 1");
     return nullptr;
   }
+  if ((long long)max_dets * fdt::TRK_LDS_PER_SLOT > 160 * 1024 - 64) {
+    set_error("fdt_tracker_create: max_dets %d does not fit the LDS-resident frame state (limit %d)", max_dets,
+              (160 * 1024 - 64) / fdt::TRK_LDS_PER_SLOT);
+    return nullptr;
+  }
   fdt_tracker* t = new fdt_tracker();
   t->sigma_iou = sigma_iou;
   t->sigma_h = sigma_h;
@@ -335,7 +406,9 @@ extern "C" fdt_tracker* fdt_tracker_create(double sigma_iou, double sigma_h, int
             hipMalloc((void**)&t->d_log, t->log_cap) == hipSuccess &&
             hipMalloc((void**)&t->d_dets_in, (size_t)max_dets * 40) == hipSuccess &&
             hipMalloc(&t->d_sets, per_set * 2) == hipSuccess &&
-            hipMemset(t->d_state, 0, sizeof(fdt::TrkState)) == hipSuccess;
+            hipMemset(t->d_state, 0, sizeof(fdt::TrkState)) == hipSuccess &&
+            hipFuncSetAttribute((const void*)fdt::track_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                max_dets * fdt::TRK_LDS_PER_SLOT) == hipSuccess;
   if (!ok) {
     set_error("fdt_tracker_create: HIP allocation failed: %s", hipGetErrorString(hipGetLastError()));
     fdt_tracker_destroy(t);

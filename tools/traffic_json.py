@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""profiles/<round>/conv_hbm_traffic.json from the two per-kernel PMC summaries (tools/summarize_pmc.py).
+    python tools/traffic_json.py FETCH.csv WRITE.csv LAUNCHES_PER_FRAME OUT.json
+FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 reports half of wide coalesced reads); both counters are KB."""
+import csv
+import json
+import sys
+
+
+def conv_sum(path):
+    n, s = 0, 0.0
+    for r in csv.DictReader(open(path)):
+        if "conv_kernel" in r["Kernel_Name"] or "conv_wino" in r["Kernel_Name"]:
+            n += int(r["Dispatches"])
+            s += float(r["Sum"])
+    return n, s
+
+
+nf, fetch = conv_sum(sys.argv[1])
+nw, write = conv_sum(sys.argv[2])
+assert nf == nw, (nf, nw)
+per_frame = int(sys.argv[3])
+frames = nf / per_frame
+total = (fetch * 2.0 + write) * 1024.0
+json.dump({
+    "kernel": "conv_kernel + conv_wino_kernel + conv_wino2_kernel (all variants of the committed plan)",
+    "dispatches": nf, "frames": frames,
+    "FETCH_SIZE_kb_sum": fetch, "WRITE_SIZE_kb_sum": write, "fetch_correction": 2.0,
+    "hbm_bytes_per_launch": total / nf, "hbm_bytes_per_frame": total / frames,
+    "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 8 --warmup 2 "
+            "--cpu-frames 0 --inflight 1 --profile-frames 1` (committed tuned plan, no autotune dispatches); FETCH_SIZE "
+            "doubled per MI355X_MICROARCH.md (the dword LDS-DMA pattern is not separately calibrated)",
+}, open(sys.argv[4], "w"), indent=1)
