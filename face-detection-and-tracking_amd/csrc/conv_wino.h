@@ -10,7 +10,7 @@
 //    image blocks the B operand.
 //  * Input transform on the fly: the raw (2*TTH+2) x (2*TTW+2) patch of KC channels is staged once per
 //    stage by LDS-DMA (same zero-word trick for padding); each lane (= one 2x2 output block) reads its
-//    4x4 window with 8 ds_read_b64 and forms the 16 V_t values with 32 VALU adds -- the MFMA B operands.
+//    4x4 window with 8 ds_read2_b32 and forms the 16 V_t values with 32 VALU adds -- the MFMA B operands.
 //    No transformed copy of the activations ever exists in memory.
 //  * All 16 accumulators of a wave's 32-cout x 32-block tile stay in registers (256 VGPRs, one wave per
 //    SIMD: this kernel trades occupancy for 2.25x less matrix work; 16 independent MFMAs per k-pair give
@@ -18,6 +18,8 @@
 //  * Output transform in registers (all 16 D_t of one (cout, block) sit in ONE lane): 24 adds, then
 //    bias / residual / ReLU and one 8-byte store per row of the 2x2 block.
 #pragma once
+#include <type_traits>
+
 #include "conv_kernel.h"
 
 namespace fdt {
@@ -130,11 +132,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
       // raw 4x4 window d[i][j] of channel 2*cp + half
       float d[4][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float2 lo = *reinterpret_cast<const float2*>(S + xo + (2 * cp) * T::XPLANE + i * T::PW);
-        const float2 hi = *reinterpret_cast<const float2*>(S + xo + (2 * cp) * T::XPLANE + i * T::PW + 2);
-        d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
-      }
+      for (int i = 0; i < 4; ++i)      // plain float reads (see conv_wino2_kernel: no float2-typed LDS reads)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[i][j] = S[xo + (2 * cp) * T::XPLANE + i * T::PW + j];
       // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
       float t_[4][4], v[4][4];
 #pragma unroll
@@ -300,48 +300,54 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
 #pragma unroll
   for (int p = 0; p < T::NBUF - 1; ++p)
     if (p < nst) FDT_W2STAGE(s_begin + p, p);
-  int cur = 0, nxt = T::NBUF - 1;
-  for (int it = 0; it < nst; ++it) {
-    if (T::NBUF >= 3 && it + 1 < nst)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS2) : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (it + T::NBUF - 1 < nst) FDT_W2STAGE(s_begin + it + T::NBUF - 1, nxt);
-    const float* S = smem + cur * T::STAGE;
+  // The main loop is instantiated once per half of the position grid and selected by ONE wave-uniform
+  // branch: with `th` a compile-time constant the loop body is straight-line code (no per-row branches
+  // or selects), so the scheduler can hoist the next channel pair's LDS reads over the current MFMAs.
+  // Both instances execute the same s_barrier sequence.
+  auto main_loop = [&](auto th_c) {
+    constexpr int TH_ = decltype(th_c)::value;
+    int cur = 0, nxt = T::NBUF - 1;
+    for (int it = 0; it < nst; ++it) {
+      if (T::NBUF >= 3 && it + 1 < nst)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS2) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (it + T::NBUF - 1 < nst) FDT_W2STAGE(s_begin + it + T::NBUF - 1, nxt);
+      const float* S = smem + cur * T::STAGE;
 #pragma unroll
-    for (int cp = 0; cp < T::KC / 2; ++cp) {
-      float d[4][4];
+      for (int cp = 0; cp < T::KC / 2; ++cp) {
+        // rows TH_ .. TH_+2 of the 4x4 (stride D) window.  Plain float reads on purpose: behind a
+        // float2-typed LDS read the compiler's waitcnt pass puts a full s_waitcnt vmcnt(0) (it assumes
+        // the read may alias the LDS-DMA stores in flight), which serialises the ring.
+        float d[3][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (T::D == 1) {
-          const float2 lo = *reinterpret_cast<const float2*>(S + xo + (2 * cp) * T::XPLANE + i * T::PW);
-          const float2 hi = *reinterpret_cast<const float2*>(S + xo + (2 * cp) * T::XPLANE + i * T::PW + 2);
-          d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
-        } else {
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) d[i][j] = S[xo + (2 * cp) * T::XPLANE + (i * T::D) * T::PW + j * T::D];
+          for (int j = 0; j < 4; ++j)
+            d[i][j] = S[xo + (2 * cp) * T::XPLANE + ((i + TH_) * T::D) * T::PW + j * T::D];
+        // the two rows of B^T d this wave needs: TH_ = 0: (d0 - d2, d1 + d2); TH_ = 1: (d2 - d1, d1 - d3)
+        float ra[4], rb[4], v[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ra[j] = TH_ ? (d[1][j] - d[0][j]) : (d[0][j] - d[2][j]);
+          rb[j] = TH_ ? (d[0][j] - d[2][j]) : (d[1][j] + d[2][j]);
+        }
+        v[0][0] = ra[0] - ra[2]; v[0][1] = ra[1] + ra[2]; v[0][2] = ra[2] - ra[1]; v[0][3] = ra[1] - ra[3];
+        v[1][0] = rb[0] - rb[2]; v[1][1] = rb[1] + rb[2]; v[1][2] = rb[2] - rb[1]; v[1][3] = rb[1] - rb[3];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float u = S[wo + ((2 * cp) * 16 + t) * T::BN];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(u, v[t >> 2][t & 3], acc[t], 0, 0, 0);
         }
       }
-      // the two rows of B^T d this wave needs: th = 0: (d0 - d2, d1 + d2); th = 1: (d2 - d1, d1 - d3)
-      float ra[4], rb[4], v[2][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ra[j] = th ? (d[2][j] - d[1][j]) : (d[0][j] - d[2][j]);
-        rb[j] = th ? (d[1][j] - d[3][j]) : (d[1][j] + d[2][j]);
-      }
-      v[0][0] = ra[0] - ra[2]; v[0][1] = ra[1] + ra[2]; v[0][2] = ra[2] - ra[1]; v[0][3] = ra[1] - ra[3];
-      v[1][0] = rb[0] - rb[2]; v[1][1] = rb[1] + rb[2]; v[1][2] = rb[2] - rb[1]; v[1][3] = rb[1] - rb[3];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const float u = S[wo + ((2 * cp) * 16 + t) * T::BN];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(u, v[t >> 2][t & 3], acc[t], 0, 0, 0);
-      }
+      cur = (cur + 1 == T::NBUF) ? 0 : cur + 1;
+      nxt = (nxt + 1 == T::NBUF) ? 0 : nxt + 1;
     }
-    cur = (cur + 1 == T::NBUF) ? 0 : cur + 1;
-    nxt = (nxt + 1 == T::NBUF) ? 0 : nxt + 1;
-  }
+  };
+  if (th) main_loop(std::integral_constant<int, 1>{});
+  else main_loop(std::integral_constant<int, 0>{});
 #undef FDT_W2STAGE
 
   // ---- output transform: each half contributes linearly; halves meet through LDS ------------------------

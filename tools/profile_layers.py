@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--top", type=int, default=200)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--autotune", type=int, default=0)
+    ap.add_argument("--autotune", type=int, default=1, help="1: committed plan (else autotune), 2: autotune, 0: analytic")
     a = ap.parse_args()
     synth = importlib.import_module("face-detection-and-tracking_amd.synth")
     layers = importlib.import_module("face-detection-and-tracking_amd.layers")
