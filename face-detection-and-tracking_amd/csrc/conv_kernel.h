@@ -102,6 +102,8 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
   // Element e = 256*k + tid of the [KC][PH][PW] patch is fetched by lane (tid & 63) of wave (tid >> 6)
   // with its k-th LDS-DMA instruction.  Padding / out-of-image elements read g_zero_pad instead, so
   // the loads are unconditional and nothing is predicated per lane.
+  const float* zpad = g_zero_pad;          // materialised once: as a symbol it is re-fetched through the GOT
+  asm volatile("" : "+s"(zpad));            // (an SMEM load, i.e. a full lgkmcnt(0) wait) inside the main loop
   int goff[L::NX];
   unsigned okmask = 0;
   const bool vecx = L::VECX && (a.Win % 4 == 0);
@@ -141,14 +143,14 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
       _Pragma("unroll") for (int k = 0; k < L::NXV; ++k) {                                  \
         const int c_ = (tid + 256 * k) / (T::BM / 4);                                       \
         const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                \
-        glds16(ok_ ? src_ + goff[k] : g_zero_pad, X_ + 1024 * k);                           \
+        glds16(ok_ ? src_ + goff[k] : zpad, X_ + 1024 * k);                           \
       }                                                                                     \
     } else {                                                                                \
       float* X_ = smem + (buf_) * L::STAGE + wave * 64;                                     \
       _Pragma("unroll") for (int k = 0; k < L::NX; ++k) {                                   \
         const int c_ = (tid + 256 * k) / L::XPLANE;                                         \
         const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                \
-        glds4(ok_ ? src_ + goff[k] : g_zero_pad, X_ + 256 * k);                             \
+        glds4(ok_ ? src_ + goff[k] : zpad, X_ + 256 * k);                             \
       }                                                                                     \
     }                                                                                       \
     const float* wsrc_ = w_t + (long long)(s_) * L::WSZP + tid * 4;                         \

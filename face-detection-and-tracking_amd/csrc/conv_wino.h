@@ -71,6 +71,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
   const int s_begin = (int)((long long)nstages * ks / a.ksplit);
   const int s_end = (int)((long long)nstages * (ks + 1) / a.ksplit);
 
+  const float* zpad = g_zero_pad;          // materialised once: as a symbol it is re-fetched through the GOT
+  asm volatile("" : "+s"(zpad));            // (an SMEM load, i.e. a full lgkmcnt(0) wait) inside the main loop
   int goff[T::NX];
   unsigned okmask = 0;
 #pragma unroll
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
     _Pragma("unroll") for (int k = 0; k < T::NX; ++k) {                                       \
       const int c_ = (tid + 256 * k) / T::XPLANE;                                             \
       const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                    \
-      glds4(ok_ ? src_ + goff[k] : g_zero_pad, X_ + 256 * k);                                 \
+      glds4(ok_ ? src_ + goff[k] : zpad, X_ + 256 * k);                                 \
     }                                                                                         \
     const float* wsrc_ = w_t + (long long)(s_) * T::WSZP + tid * 4;                           \
     float* W_ = smem + (buf_) * T::STAGE + T::XSZP + wave * 256;                              \
@@ -244,6 +246,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   const int s_begin = (int)((long long)nstages * ks / a.ksplit);
   const int s_end = (int)((long long)nstages * (ks + 1) / a.ksplit);
 
+  const float* zpad = g_zero_pad;          // materialised once: as a symbol it is re-fetched through the GOT
+  asm volatile("" : "+s"(zpad));            // (an SMEM load, i.e. a full lgkmcnt(0) wait) inside the main loop
   int goff[NX2];
   unsigned okmask = 0;
 #pragma unroll
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
     _Pragma("unroll") for (int k = 0; k < NX2; ++k) {                                          \
       const int c_ = (tid + 512 * k) / T::XPLANE;                                              \
       const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                     \
-      glds4(ok_ ? src_ + goff[k] : g_zero_pad, X_ + 512 * k);                                  \
+      glds4(ok_ ? src_ + goff[k] : zpad, X_ + 512 * k);                                  \
     }                                                                                          \
     const float* wsrc_ = w_t + (long long)(s_) * T::WSZP + tid * 4;                            \
     float* W_ = smem + (buf_) * T::STAGE + T::XSZP + wave * 256;                               \
@@ -306,44 +310,99 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   // Both instances execute the same s_barrier sequence.
   auto main_loop = [&](auto th_c) {
     constexpr int TH_ = decltype(th_c)::value;
-    int cur = 0, nxt = T::NBUF - 1;
-    for (int it = 0; it < nst; ++it) {
-      if (T::NBUF >= 3 && it + 1 < nst)
+    // LDS operands of one channel pair: rows TH_ .. TH_+2 of the 4x4 (stride D) window and the 8 weights.
+    // Plain float reads on purpose: behind a float2-typed LDS read the compiler's waitcnt pass puts a full
+    // s_waitcnt vmcnt(0) (it assumes the read may alias the LDS-DMA stores in flight), which serialises
+    // the ring.
+    auto lds_operands = [&](const float* S, int cp, float (&d)[3][4], float (&u)[8]) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          d[i][j] = S[xo + (2 * cp) * T::XPLANE + ((i + TH_) * T::D) * T::PW + j * T::D];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) u[t] = S[wo + ((2 * cp) * 16 + t) * T::BN];
+    };
+    auto mac = [&](const float (&d)[3][4], const float (&u)[8]) {
+      // the two rows of B^T d this wave needs: TH_ = 0: (d0 - d2, d1 + d2); TH_ = 1: (d2 - d1, d1 - d3)
+      float ra[4], rb[4], v[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ra[j] = TH_ ? (d[1][j] - d[0][j]) : (d[0][j] - d[2][j]);
+        rb[j] = TH_ ? (d[0][j] - d[2][j]) : (d[1][j] + d[2][j]);
+      }
+      v[0][0] = ra[0] - ra[2]; v[0][1] = ra[1] + ra[2]; v[0][2] = ra[2] - ra[1]; v[0][3] = ra[1] - ra[3];
+      v[1][0] = rb[0] - rb[2]; v[1][1] = rb[1] + rb[2]; v[1][2] = rb[2] - rb[1]; v[1][3] = rb[1] - rb[3];
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[t], v[t >> 2][t & 3], acc[t], 0, 0, 0);
+    };
+    if constexpr (T::NBUF >= 3 && (T::KC / 2) % 2 == 0) {
+      // Ring of three with the workgroup barrier in the MIDDLE of a stage: at the barrier of stage `it` every
+      // wave has finished stage it-1 (its buffer is free for the DMA of stage it+2) and has waited for its
+      // share of stage it+1, so the hand-over it -> it+1 needs no synchronisation at all and the operand
+      // prefetch (one channel pair ahead, registers A/B alternating) runs straight across it.
+      if (nst > 1)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS2) : "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0), visible to the compiler's model (see below)
       __builtin_amdgcn_sched_barrier(0);
-      if (it + T::NBUF - 1 < nst) FDT_W2STAGE(s_begin + it + T::NBUF - 1, nxt);
-      const float* S = smem + cur * T::STAGE;
+      float dA[3][4], uA[8], dB[3][4], uB[8];
+      int cur = 0;
+      lds_operands(smem, 0, dA, uA);
+      for (int it = 0; it < nst; ++it) {
+        const float* S = smem + cur * T::STAGE;
+        const int nb = (cur + 1 == 3) ? 0 : cur + 1;
+        const float* Sn = smem + nb * T::STAGE;
 #pragma unroll
-      for (int cp = 0; cp < T::KC / 2; ++cp) {
-        // rows TH_ .. TH_+2 of the 4x4 (stride D) window.  Plain float reads on purpose: behind a
-        // float2-typed LDS read the compiler's waitcnt pass puts a full s_waitcnt vmcnt(0) (it assumes
-        // the read may alias the LDS-DMA stores in flight), which serialises the ring.
-        float d[3][4];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            d[i][j] = S[xo + (2 * cp) * T::XPLANE + ((i + TH_) * T::D) * T::PW + j * T::D];
-        // the two rows of B^T d this wave needs: TH_ = 0: (d0 - d2, d1 + d2); TH_ = 1: (d2 - d1, d1 - d3)
-        float ra[4], rb[4], v[2][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          ra[j] = TH_ ? (d[1][j] - d[0][j]) : (d[0][j] - d[2][j]);
-          rb[j] = TH_ ? (d[0][j] - d[2][j]) : (d[1][j] + d[2][j]);
+        for (int cp = 0; cp < T::KC / 2; cp += 2) {
+          if (cp == 2 || T::KC / 2 == 2) {
+            if (it + 1 < nst) {
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              __builtin_amdgcn_s_barrier();
+              __builtin_amdgcn_sched_barrier(0);
+              const int fb = (nb + 1 == 3) ? 0 : nb + 1;
+              if (it + 2 < nst) {
+                FDT_W2STAGE(s_begin + it + 2, fb);
+                // The compiler's waitcnt model counts an LDS-DMA load as a pending FLAT access, after which
+                // its next lgkmcnt wait is a full lgkmcnt(0).  Take that wait here, where only operands that
+                // are needed next anyway are in flight, not behind the prefetch issued below.
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+              }
+            }
+          }
+          lds_operands(S, cp + 1, dB, uB);
+          __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of the MFMAs it hides behind
+          mac(dA, uA);
+          if (cp + 2 < T::KC / 2) lds_operands(S, cp + 2, dA, uA);
+          else if (it + 1 < nst) lds_operands(Sn, 0, dA, uA);
+          __builtin_amdgcn_sched_barrier(0);
+          mac(dB, uB);
         }
-        v[0][0] = ra[0] - ra[2]; v[0][1] = ra[1] + ra[2]; v[0][2] = ra[2] - ra[1]; v[0][3] = ra[1] - ra[3];
-        v[1][0] = rb[0] - rb[2]; v[1][1] = rb[1] + rb[2]; v[1][2] = rb[2] - rb[1]; v[1][3] = rb[1] - rb[3];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const float u = S[wo + ((2 * cp) * 16 + t) * T::BN];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(u, v[t >> 2][t & 3], acc[t], 0, 0, 0);
-        }
+        cur = nb;
       }
-      cur = (cur + 1 == T::NBUF) ? 0 : cur + 1;
-      nxt = (nxt + 1 == T::NBUF) ? 0 : nxt + 1;
+    } else {
+      int cur = 0, nxt = T::NBUF - 1;
+      for (int it = 0; it < nst; ++it) {
+        if (T::NBUF >= 3 && it + 1 < nst)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS2) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + T::NBUF - 1 < nst) FDT_W2STAGE(s_begin + it + T::NBUF - 1, nxt);
+        const float* S = smem + cur * T::STAGE;
+#pragma unroll
+        for (int cp = 0; cp < T::KC / 2; ++cp) {
+          float d[3][4], u[8];
+          lds_operands(S, cp, d, u);
+          mac(d, u);
+        }
+        cur = (cur + 1 == T::NBUF) ? 0 : cur + 1;
+        nxt = (nxt + 1 == T::NBUF) ? 0 : nxt + 1;
+      }
     }
   };
   if (th) main_loop(std::integral_constant<int, 1>{});
