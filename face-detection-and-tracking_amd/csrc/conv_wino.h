@@ -25,6 +25,27 @@
 namespace fdt {
 namespace {
 
+
+// ---- LDS operand reads with hand-counted waits --------------------------------------------------------
+// The compiler's waitcnt model treats every LDS-DMA load (global_load ... lds) as a FLAT access that stays
+// pending until a vmcnt(0) it can see; while one is pending, each lgkmcnt wait it inserts is a full
+// lgkmcnt(0) -- which would drain the operand prefetch the moment it is issued.  The main loop of the
+// 8-wave kernel therefore issues its ds_reads itself and waits with an exact count (LDS returns in order).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int O0, int O1>
+__device__ __forceinline__ void lds_read2_b64(f32x4& v, unsigned addr) {      // offsets in units of 8 bytes
+  asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1));
+}
+template <int O0, int O1>
+__device__ __forceinline__ void lds_read2_b32(f32x2& v, unsigned addr) {      // offsets in dwords
+  asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1));
+}
+template <int O0, int O1>
+__device__ __forceinline__ void lds_read2st64_b32(f32x2& v, unsigned addr) {  // offsets in units of 64 dwords
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1));
+}
+
 template <int TTH_, int TTW_, int WM_, int WN_, int KC_, int NBUF_, int D_ = 1>
 struct WinoTile {
   static constexpr int TTH = TTH_, TTW = TTW_, WM = WM_, WN = WN_, KC = KC_, NBUF = NBUF_;
@@ -341,21 +362,89 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
       // Ring of three with the workgroup barrier in the MIDDLE of a stage: at the barrier of stage `it` every
       // wave has finished stage it-1 (its buffer is free for the DMA of stage it+2) and has waited for its
       // share of stage it+1, so the hand-over it -> it+1 needs no synchronisation at all and the operand
-      // prefetch (one channel pair ahead, registers A/B alternating) runs straight across it.
+      // prefetch (one channel pair ahead, register sets A/B alternating) runs straight across it.
+      struct Ops {
+        f32x4 d1[3];          // D = 1: one window row each (ds_read2_b64)
+        f32x2 d2[3][2];       // D = 2: a row is four dwords 8 bytes apart (2 x ds_read2_b32)
+        f32x2 u[4];           // weights of positions (2k, 2k+1)
+      };
+      constexpr int NLD = (T::D == 1 ? 3 : 6) + 4;           // ds instructions per operand set
+      constexpr int ROWB = T::D * T::PW * 4;                  // bytes between window rows
+      static_assert(ROWB % 8 == 0 && (3 * ROWB) / 8 + 1 < 256 && 3 * (ROWB / 4) + 6 < 256, "ds offset fields");
+      static_assert(T::BN % 64 == 0 || 7 * T::BN < 256, "weight offsets fit the ds offset fields");
+      const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+      const unsigned xb = lds0 + (unsigned)xo * 4u, wb = lds0 + (unsigned)wo * 4u;
+      auto load = [&](Ops& o, int buf, int cp) {
+        const unsigned xa = xb + (unsigned)(buf * T::STAGE + 2 * cp * T::XPLANE) * 4u;
+        const unsigned wa = wb + (unsigned)(buf * T::STAGE + 2 * cp * 16 * T::BN) * 4u;
+        if constexpr (T::D == 1) {
+          lds_read2_b64<(TH_ + 0) * ROWB / 8, (TH_ + 0) * ROWB / 8 + 1>(o.d1[0], xa);
+          lds_read2_b64<(TH_ + 1) * ROWB / 8, (TH_ + 1) * ROWB / 8 + 1>(o.d1[1], xa);
+          lds_read2_b64<(TH_ + 2) * ROWB / 8, (TH_ + 2) * ROWB / 8 + 1>(o.d1[2], xa);
+        } else {
+          lds_read2_b32<(TH_ + 0) * ROWB / 4, (TH_ + 0) * ROWB / 4 + 2>(o.d2[0][0], xa);
+          lds_read2_b32<(TH_ + 0) * ROWB / 4 + 4, (TH_ + 0) * ROWB / 4 + 6>(o.d2[0][1], xa);
+          lds_read2_b32<(TH_ + 1) * ROWB / 4, (TH_ + 1) * ROWB / 4 + 2>(o.d2[1][0], xa);
+          lds_read2_b32<(TH_ + 1) * ROWB / 4 + 4, (TH_ + 1) * ROWB / 4 + 6>(o.d2[1][1], xa);
+          lds_read2_b32<(TH_ + 2) * ROWB / 4, (TH_ + 2) * ROWB / 4 + 2>(o.d2[2][0], xa);
+          lds_read2_b32<(TH_ + 2) * ROWB / 4 + 4, (TH_ + 2) * ROWB / 4 + 6>(o.d2[2][1], xa);
+        }
+        if constexpr (T::BN % 64 == 0) {
+          constexpr int Q = T::BN / 64;
+          lds_read2st64_b32<0 * Q, 1 * Q>(o.u[0], wa);
+          lds_read2st64_b32<2 * Q, 3 * Q>(o.u[1], wa);
+          lds_read2st64_b32<4 * Q, 5 * Q>(o.u[2], wa);
+          lds_read2st64_b32<6 * Q, 7 * Q>(o.u[3], wa);
+        } else {
+          lds_read2_b32<0 * T::BN, 1 * T::BN>(o.u[0], wa);
+          lds_read2_b32<2 * T::BN, 3 * T::BN>(o.u[1], wa);
+          lds_read2_b32<4 * T::BN, 5 * T::BN>(o.u[2], wa);
+          lds_read2_b32<6 * T::BN, 7 * T::BN>(o.u[3], wa);
+        }
+      };
+      // wait until at most `newer` ds instructions issued after o's are outstanding; o's registers pass through
+      // the asm so that no use can be scheduled above it
+      auto wait_for = [&](Ops& o, auto newer_c) {
+        constexpr int N_ = decltype(newer_c)::value;
+        if constexpr (T::D == 1)
+          asm volatile("s_waitcnt lgkmcnt(%7)"
+                       : "+v"(o.d1[0]), "+v"(o.d1[1]), "+v"(o.d1[2]), "+v"(o.u[0]), "+v"(o.u[1]), "+v"(o.u[2]),
+                         "+v"(o.u[3])
+                       : "n"(N_));
+        else
+          asm volatile("s_waitcnt lgkmcnt(%10)"
+                       : "+v"(o.d2[0][0]), "+v"(o.d2[0][1]), "+v"(o.d2[1][0]), "+v"(o.d2[1][1]), "+v"(o.d2[2][0]),
+                         "+v"(o.d2[2][1]), "+v"(o.u[0]), "+v"(o.u[1]), "+v"(o.u[2]), "+v"(o.u[3])
+                       : "n"(N_));
+      };
+      auto mac_ops = [&](const Ops& o) {
+        float d[3][4], u[8];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          if constexpr (T::D == 1) {
+            d[i][0] = o.d1[i][0]; d[i][1] = o.d1[i][1]; d[i][2] = o.d1[i][2]; d[i][3] = o.d1[i][3];
+          } else {
+            d[i][0] = o.d2[i][0][0]; d[i][1] = o.d2[i][0][1]; d[i][2] = o.d2[i][1][0]; d[i][3] = o.d2[i][1][1];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { u[2 * k] = o.u[k][0]; u[2 * k + 1] = o.u[k][1]; }
+        mac(d, u);
+      };
+      using N0 = std::integral_constant<int, 0>;
+      using NL = std::integral_constant<int, NLD>;
+
       if (nst > 1)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS2) : "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0), visible to the compiler's model (see below)
       __builtin_amdgcn_sched_barrier(0);
-      float dA[3][4], uA[8], dB[3][4], uB[8];
+      Ops A, B;
       int cur = 0;
-      lds_operands(smem, 0, dA, uA);
+      load(A, 0, 0);
       for (int it = 0; it < nst; ++it) {
-        const float* S = smem + cur * T::STAGE;
         const int nb = (cur + 1 == 3) ? 0 : cur + 1;
-        const float* Sn = smem + nb * T::STAGE;
 #pragma unroll
         for (int cp = 0; cp < T::KC / 2; cp += 2) {
           if (cp == 2 || T::KC / 2 == 2) {
@@ -364,25 +453,23 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
               __builtin_amdgcn_s_barrier();
               __builtin_amdgcn_sched_barrier(0);
               const int fb = (nb + 1 == 3) ? 0 : nb + 1;
-              if (it + 2 < nst) {
-                FDT_W2STAGE(s_begin + it + 2, fb);
-                // The compiler's waitcnt model counts an LDS-DMA load as a pending FLAT access, after which
-                // its next lgkmcnt wait is a full lgkmcnt(0).  Take that wait here, where only operands that
-                // are needed next anyway are in flight, not behind the prefetch issued below.
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-              }
+              if (it + 2 < nst) FDT_W2STAGE(s_begin + it + 2, fb);
             }
           }
-          lds_operands(S, cp + 1, dB, uB);
-          __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of the MFMAs it hides behind
-          mac(dA, uA);
-          if (cp + 2 < T::KC / 2) lds_operands(S, cp + 2, dA, uA);
-          else if (it + 1 < nst) lds_operands(Sn, 0, dA, uA);
-          __builtin_amdgcn_sched_barrier(0);
-          mac(dB, uB);
+          load(B, cur, cp + 1);
+          wait_for(A, NL{});
+          mac_ops(A);
+          // One straight-line path on purpose (after the last stage this reads a stale buffer and the result
+          // is dropped): a second path would meet this one in a PHI, and the copies that resolves into may
+          // be placed in front of the wait, i.e. read registers whose ds_read has not landed yet.
+          if (cp + 2 < T::KC / 2) load(A, cur, cp + 2);
+          else load(A, nb, 0);
+          wait_for(B, NL{});
+          mac_ops(B);
         }
         cur = nb;
       }
+      wait_for(A, N0{});      // drain: A's registers must not be reused while its reads are in flight
     } else {
       int cur = 0, nxt = T::NBUF - 1;
       for (int it = 0; it < nst; ++it) {
