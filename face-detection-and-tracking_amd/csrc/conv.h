@@ -53,6 +53,12 @@ enum ConvTile {
   TILE_WINO8_64x64R3,
   TILE_WINO8_128x32R3,
   TILE_WINO8_64x64W,
+  // ring of FOUR LDS stages (two stages of LDS-DMA in flight behind the one being waited for): 1x1 classes,
+  // whose short stages are bound by load latency rather than by the matrix cores
+  TILE_128x128R4,
+  TILE_128x64R4,
+  TILE_64x64R4,
+  TILE_64x128R4,
   CONV_TILE_COUNT
 };
 

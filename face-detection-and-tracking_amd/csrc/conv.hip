@@ -133,7 +133,9 @@ const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum 
     {256, 64, 16, 16}, {256, 64, 16, 16}, {512, 32, 16, 32}, {512, 32, 16, 32}, {128, 128, 8, 16},
     {128, 128, 8, 16}, {256, 64, 8, 32},
     // 8-wave Winograd
-    {256, 64, 16, 16}, {256, 64, 16, 16}, {512, 32, 16, 32}, {256, 64, 8, 32}};
+    {256, 64, 16, 16}, {256, 64, 16, 16}, {512, 32, 16, 32}, {256, 64, 8, 32},
+    // ring of four
+    {128, 128, 8, 16}, {128, 64, 8, 16}, {64, 64, 8, 8}, {64, 128, 8, 8}};
 
 }  // namespace
 
@@ -294,8 +296,8 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
                 "fdt_conv2d: kernel class %d does not implement this convolution", alt);
     kind = alt;
   }
-  if (kind == CONV_3x3_S1 && tile >= TILE_WINO_64x64 && tile < CONV_TILE_COUNT) kind = CONV_3x3_S1_WINO;
-  if (kind == CONV_3x3_S1_D2 && tile >= TILE_WINO_64x64 && tile < CONV_TILE_COUNT) kind = CONV_3x3_D2_WINO;
+  if (kind == CONV_3x3_S1 && tile >= TILE_WINO_64x64 && tile <= TILE_WINO8_64x64W) kind = CONV_3x3_S1_WINO;
+  if (kind == CONV_3x3_S1_D2 && tile >= TILE_WINO_64x64 && tile <= TILE_WINO8_64x64W) kind = CONV_3x3_D2_WINO;
   FDT_REQUIRE(tile >= 0 && tile < CONV_TILE_COUNT && conv_supported((ConvKind)kind, (ConvTile)tile), FDT_ERR_ARG,
               "fdt_conv2d: kernel (kind %d, tile %d) not instantiated", kind, tile);
   a.ksplit = ksplit > 0 ? ksplit : 1;

@@ -51,7 +51,7 @@ struct Layout {
   static constexpr bool VECX = (G::KH == 1 && G::KW == 1 && G::S == 1 && (XSZ % 1024) == 0);
   static constexpr int NXV = XSZ / 1024;
   static constexpr int LOADS = NX + NW;                  // LDS-DMA wave-instructions per stage
-  static_assert(LOADS < 64, "vmcnt is 6 bits");
+  static_assert((T::NBUF >= 4 ? 2 : 1) * LOADS < 64, "vmcnt is 6 bits");
   static_assert(G::KC % 2 == 0, "k-pairs are two input channels at one tap");
   static_assert(NX <= 32, "okmask is 32 bits");
 };
@@ -188,15 +188,20 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
     if (p < nst) FDT_STAGE(s_begin + p, p);
   int cur = 0, nxt = T::NBUF - 1;
   for (int it = 0; it < nst; ++it) {
-    // leave exactly the newest stage's LDS-DMA instructions in flight (their count differs between
-    // the dword and the dwordx4 staging of X)
-    if (T::NBUF >= 3 && it + 1 < nst) {
-      if (L::VECX && vecx)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NXV + L::NW) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::LOADS) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // leave exactly the newer stages' LDS-DMA instructions in flight: min(NBUF - 2, stages left) of them
+    // (their instruction count differs between the dword and the dwordx4 staging of X)
+    {
+      const int ahead = nst - 1 - it;
+      const bool vx = L::VECX && vecx;
+      if (T::NBUF >= 4 && ahead >= 2) {
+        if (vx) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (L::NXV + L::NW)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L::LOADS) : "memory");
+      } else if (T::NBUF >= 3 && ahead >= 1) {
+        if (vx) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NXV + L::NW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::LOADS) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -354,6 +359,10 @@ using T_64x128R3   = Tile<8, 8, 128, 1, 4, 3>;
 using T_128x128WR3 = Tile<4, 32, 128, 2, 2, 3>;
 using T_128x64WR3  = Tile<4, 32, 64, 2, 2, 3>;
 using T_128x32R3   = Tile<8, 16, 32, 4, 1, 3>;
+using T_128x128R4  = Tile<8, 16, 128, 2, 2, 4>;   // ring of 4 LDS stages
+using T_128x64R4   = Tile<8, 16, 64, 2, 2, 4>;
+using T_64x64R4    = Tile<8, 8, 64, 2, 2, 4>;
+using T_64x128R4   = Tile<8, 8, 128, 1, 4, 4>;
 
 template <class G, class T>
 KernelEntry entry() {

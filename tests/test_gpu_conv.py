@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 KINDS = {  # name: (k, stride, pad, dil)
     "1x1s1": (1, 1, 0, 1), "1x1s2": (1, 2, 0, 1), "3x3s1": (3, 1, 1, 1), "3x3d2": (3, 1, 2, 2),
     "3x3s2": (3, 2, 1, 1), "7x7s2": (7, 2, 3, 1), "7x7s4": (7, 4, 3, 1), "5x5s2": (5, 2, 2, 1)}
-N_TILES = 25      # 14 direct tiles + 11 Winograd F(2x2,3x3) tiles (3x3 s1 only)
+N_TILES = 29      # 14 direct tiles + 11 Winograd F(2x2,3x3) tiles (3x3 s1 only) + 4 ring-of-four tiles (1x1 only)
 
 
 def lib():
@@ -128,7 +128,7 @@ def test_deep_stage_1x1_variants(variant):
         b = rng.standard_normal(Cout).astype(np.float32)
         res = rng.standard_normal((2, Cout, H, W)).astype(np.float32)
         exp = reference(x, w, b, 1, 1, 0, 1, res=res, act=1)
-        for tile in range(14):
+        for tile in list(range(14)) + [25, 26, 27, 28]:
             for split in (1, 2):
                 rc, got = run_conv(x, w, b, 1, 1, 0, 1, res=res, act=1, tile=variant * 100 + tile, split=split)
                 if rc != 0:
