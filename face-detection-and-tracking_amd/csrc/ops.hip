@@ -125,6 +125,105 @@ __global__ void dwconv3_kernel(const float* __restrict__ in, const float* __rest
   out[(long long)bc * Ho * Wo + (long long)oy * Wo + ox] = acc;
 }
 
+// Vector form of the depthwise 3x3 (pyramid_mb2_try3.py:96,113: groups == channels): each thread owns a
+// 4-wide strip of R output rows, walks the (R-1)*S+3 input rows it needs once (16-byte loads plus the one
+// or two halo words) and stores 16 bytes per row.  HBM-bound: in + out bytes, nothing else.  The taps are
+// accumulated in the same (dy, dx) order as dwconv3_kernel, so both forms give identical bits.
+template <int S>
+__global__ __launch_bounds__(256) void dwconv3_vec_kernel(const float* __restrict__ in, const float* __restrict__ w9,
+                                                          const float* __restrict__ bias, int C, int H, int W, int act,
+                                                          float* __restrict__ out, int Ho, int Wo, long long total) {
+  constexpr int R = (S == 1) ? 4 : 2;
+  constexpr int NIR = (R - 1) * S + 3;        // input rows per thread
+  constexpr int NV = 3 * S + 3;               // input columns per thread: S = 1: x-1..x+4, S = 2: 2x-1..2x+7
+  const long long idx0 = blockIdx.x * 256ll + threadIdx.x;
+  const bool live = idx0 < total;
+  const long long idx = live ? idx0 : total - 1;      // every lane stays: neighbours exchange halo words below
+  const int lane = threadIdx.x & 63;
+  const int W4 = Wo >> 2, RG = (Ho + R - 1) / R;
+  const int c4 = (int)(idx % W4);
+  const long long t = idx / W4;
+  const int rg = (int)(t % RG);
+  const int bc = (int)(t / RG);
+  const int c = bc % C;
+  const float* src = in + (long long)bc * H * W;
+  float k[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k[i] = w9[c * 9 + i];
+  const int ox = c4 * 4, oy0 = rg * R, ix0 = ox * S;
+  // The halo words sit in the neighbouring lanes' 16-byte loads (consecutive lanes are consecutive strips of
+  // one row; where the row wraps inside a wave the halo is the zero padding anyway).  Only a wave's first /
+  // last lane in the middle of a row has to fetch its own.
+  const bool left_pad = c4 == 0, right_pad = c4 == W4 - 1;
+  float acc[R][4];
+#pragma unroll
+  for (int o = 0; o < R; ++o)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[o][j] = 0.0f;
+  // all row loads first (independent, all in flight together), halo exchange and arithmetic afterwards
+  float4 A[NIR], Bq[NIR];
+#pragma unroll
+  for (int r = 0; r < NIR; ++r) {
+    const int y = oy0 * S - 1 + r;
+    const float* row = src + (long long)((y >= 0 && y < H) ? y : 0) * W;
+    A[r] = *reinterpret_cast<const float4*>(row + ix0);
+    Bq[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (S == 2) Bq[r] = *reinterpret_cast<const float4*>(row + ix0 + 4);
+  }
+#pragma unroll
+  for (int r = 0; r < NIR; ++r) {
+    const int y = oy0 * S - 1 + r;
+    const bool inside = y >= 0 && y < H;
+    const float* row = src + (long long)(inside ? y : 0) * W;
+    const float4 a = A[r], b = Bq[r];
+    float lft = __shfl_up(S == 1 ? a.w : b.w, 1, 64);
+    if (lane == 0 && !left_pad) lft = row[ix0 - 1];
+    if (left_pad) lft = 0.0f;
+    float v[NV];
+    v[0] = lft;
+    v[1] = a.x; v[2] = a.y; v[3] = a.z; v[4] = a.w;
+    if (S == 1) {
+      float rgt = __shfl_down(a.x, 1, 64);
+      if (lane == 63 && !right_pad) rgt = row[ix0 + 4];
+      if (right_pad) rgt = 0.0f;
+      v[5] = rgt;
+    } else {
+      v[5] = b.x; v[6] = b.y; v[7] = b.z; v[NV - 1] = b.w;
+    }
+    if (!inside) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = 0.0f;
+    }
+#pragma unroll
+    for (int o = 0; o < R; ++o) {
+      const int dy = r - o * S;
+      if (dy < 0 || dy > 2) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[o][j] = fmaf(v[j * S + dx], k[dy * 3 + dx], acc[o][j]);
+    }
+  }
+  if (!live) return;
+  const float bv = bias ? bias[c] : 0.0f;
+#pragma unroll
+  for (int o = 0; o < R; ++o) {
+    const int oy = oy0 + o;
+    if (oy >= Ho) break;
+    float4 y4;
+    float* yp = &y4.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = acc[o][j];
+      if (bias) a += bv;
+      if (act == 1) a = fmaxf(a, 0.0f);
+      else if (act == 2) a = fminf(fmaxf(a, 0.0f), 6.0f);
+      yp[j] = a;
+    }
+    *reinterpret_cast<float4*>(out + (long long)bc * Ho * Wo + (long long)oy * Wo + ox) = y4;
+  }
+}
+
 __device__ __forceinline__ void softmax2(float a, float b, float& pa, float& pb) {
   float m = fmaxf(a, b);
   float ea = expf(a - m), eb = expf(b - m);
@@ -211,6 +310,19 @@ int launch_maxpool3(const float* in, int B, int C, int H, int W, int stride, int
 
 int launch_dwconv3(const float* in, const float* w9, const float* bias, int B, int C, int H, int W,
                    int stride, int act, float* out, int Ho, int Wo, hipStream_t st) {
+  if (Wo % 4 == 0 && W == Wo * stride && (stride == 1 || stride == 2)) {
+    const int R = stride == 1 ? 4 : 2;
+    const long long total = (long long)B * C * ceil_div(Ho, R) * (Wo / 4);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (stride == 1)
+      hipLaunchKernelGGL(dwconv3_vec_kernel<1>, dim3(blocks), dim3(256), 0, st, in, w9, bias, C, H, W, act, out, Ho,
+                         Wo, total);
+    else
+      hipLaunchKernelGGL(dwconv3_vec_kernel<2>, dim3(blocks), dim3(256), 0, st, in, w9, bias, C, H, W, act, out, Ho,
+                         Wo, total);
+    FDT_LAUNCH_CHECK();
+    return FDT_OK;
+  }
   FDT_REQUIRE((long long)B * C <= 65535 && Ho <= 65535, FDT_ERR_ARG, "dwconv: grid too large");
   dim3 grid(ceil_div(Wo, 64), Ho, B * C);
   hipLaunchKernelGGL(dwconv3_kernel, grid, dim3(64), 0, st, in, w9, bias, C, H, W, stride, act, out, Ho, Wo);
