@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--height", type=int, default=0, help="frame height (default: --size)")
     ap.add_argument("--width", type=int, default=0, help="frame width (default: --size)")
     ap.add_argument("--arch", default="res50", choices=["res50", "try3"])
+    ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (one batched forward)")
     ap.add_argument("--unique-frames", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--profile-frames", type=int, default=4)
@@ -88,6 +89,7 @@ def main():
     W = args.width or args.size
     sd = synth.make_state_dict(args.arch, seed=0)
     NF = max(1, args.inflight)
+    B = max(1, args.batch)
     nets = []
     for _ in range(NF):     # one handle (own activations + stream) per frame in flight; weights replicated
         if args.arch == "res50":
@@ -100,13 +102,13 @@ def main():
         n.cuda(); n.eval()
         n._sync_attributes(H, W)
         plan_file = os.path.join(ROOT, "face-detection-and-tracking_amd", "tuned",
-                                 "%s_%dx%d_b1.plan" % (args.arch, W, H))
+                                 "%s_%dx%d_b%d.plan" % (args.arch, W, H, B))
         if args.autotune == 1 and os.path.exists(plan_file):
             n.import_plan(open(plan_file).read())      # committed result of an earlier autotune on MI355X
             plan_src = "tuned/" + os.path.basename(plan_file)
         elif args.autotune:
             # plan-time measurement of every (tile, split-K) variant per layer; outside the timed region
-            n(synth.make_frames(1, H, W, seed=99)[0])
+            n(synth.make_frames(B, H, W, seed=99) if B > 1 else synth.make_frames(1, H, W, seed=99)[0])
             n.autotune(3)
             plan_src = "autotuned at start-up"
             if args.save_plan and not nets:
@@ -119,10 +121,12 @@ def main():
     top_k = net.detect.top_k
 
     # synthetic frames, resident in HBM before the timed region
-    frames_h = synth.make_frames(args.unique_frames, H, W, seed=1234 + rank)
+    U = (max(args.unique_frames, B) + B - 1) // B * B          # whole batches
+    frames_h = synth.make_frames(U, H, W, seed=1234 + rank)
     frames_d = torch.from_numpy(frames_h).to(dev)
-    fps = [par.FrameParallel(rank, world, 2 * top_k * 5, dev) for _ in range(NF)]
-    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    REC = 2 * top_k * 5                                       # one frame's Detect record
+    fps = [par.FrameParallel(rank, world, B * REC, dev) for _ in range(NF)]
+    counts = torch.zeros(2 * B, dtype=torch.int32, device=dev)
     tracker = trk.IouTracker(0.4, 0.6, 5, max_dets=2 * top_k, log_frames=64)
     # non-default torch streams: their handles go through the C ABI, so torch.cuda.Event brackets and the
     # RCCL collective are ordered with the library's launches.  One stream per frame in flight for the
@@ -138,11 +142,11 @@ def main():
 
     def step(i):
         k = i % NF
-        f = frames_d[i % args.unique_frames]
+        f = frames_d[(i * B) % U:(i * B) % U + B]
         fp = fps[k]
         with torch.cuda.stream(det_streams[k]):
             det_streams[k].wait_event(trk_done[k])        # slot k's record was consumed (step i - NF)
-            lib.check(L.fdt_model_forward_dev(nets[k]._h, ctypes.c_void_p(f.data_ptr()), lib.FRAME_U8_HWC_BGR, 1,
+            lib.check(L.fdt_model_forward_dev(nets[k]._h, ctypes.c_void_p(f.data_ptr()), lib.FRAME_U8_HWC_BGR, B,
                                               H, W, ctypes.c_void_p(fp.mine.data_ptr()),
                                               ctypes.c_void_p(counts.data_ptr()), sp_det[k]))
             det_done[k].record(det_streams[k])
@@ -150,8 +154,9 @@ def main():
             trk_stream.wait_event(det_done[k])
             # the one exchange step of the path: fixed-size per-frame box lists, rank order == frame order
             g = fp.exchange()
-            for r in range(world):
-                tracker.step_dev(ctypes.c_void_p(g[r].data_ptr()), 2, top_k, W, H, 0.4, sp_trk)
+            for r in range(world):            # rank order == frame order; B consecutive frames per rank
+                for b in range(B):
+                    tracker.step_dev(ctypes.c_void_p(g[r].data_ptr() + 4 * b * REC), 2, top_k, W, H, 0.4, sp_trk)
             trk_done[k].record(trk_stream)
 
     def sync_all():
@@ -192,8 +197,8 @@ def main():
         net.profile(True)
         conv_ms, other_ms, flops = [], [], 0.0
         for i in range(args.profile_frames + 1):
-            lib.check(L.fdt_model_forward_dev(net._h, ctypes.c_void_p(frames_d[i % args.unique_frames].data_ptr()),
-                                              lib.FRAME_U8_HWC_BGR, 1, H, W, ctypes.c_void_p(mine.data_ptr()),
+            lib.check(L.fdt_model_forward_dev(net._h, ctypes.c_void_p(frames_d[(i * B) % U:].data_ptr()),
+                                              lib.FRAME_U8_HWC_BGR, B, H, W, ctypes.c_void_p(mine.data_ptr()),
                                               ctypes.c_void_p(counts.data_ptr()), stream))
             torch.cuda.synchronize()
             prof = net.profile_read()
@@ -217,9 +222,9 @@ def main():
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "conv_kernel (f32 MFMA implicit GEMM)", "launches_per_frame": n_conv,
-                "avg_launch_us": round(cms * 1e3 / n_conv, 2), "conv_ms_per_frame": round(cms, 3),
-                "other_ms_per_frame": round(float(np.mean(other_ms)), 3),
-                "algorithmic_gflop_per_frame": round(flops / 1e9, 3)}
+                "avg_launch_us": round(cms * 1e3 / n_conv, 2), "conv_ms_per_frame": round(cms / B, 3),
+                "other_ms_per_frame": round(float(np.mean(other_ms)) / B, 3),
+                "algorithmic_gflop_per_frame": round(flops / B / 1e9, 3)}
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample ---------------------------
     cpu, parity = None, None
@@ -231,13 +236,13 @@ def main():
         times, ref_dets, gpu_dets = [], [], []
         for i in range(args.cpu_frames):
             t1 = time.perf_counter()
-            y = opb.detect_frame(sd, frames_h[i % args.unique_frames], args.arch)
+            y = opb.detect_frame(sd, frames_h[i % U], args.arch)
             det_ref = opp.unpack_detections(y, W, H, 0.4)
             with np.errstate(all="ignore"):
                 ref_trk.step(det_ref)
             times.append(time.perf_counter() - t1)
             # parity of the same frames on the GPU path (checker only; not timed)
-            yg = net(frames_h[i % args.unique_frames]).numpy()
+            yg = net(frames_h[i % U]).numpy()
             ref_dets.append(det_ref)
             gpu_dets.append(opp.unpack_detections(yg, W, H, 0.4))
         ap, n_truth, n_pred = opp.ap_against_reference(gpu_dets, ref_dets, 0.5)
@@ -255,7 +260,7 @@ def main():
                          "Detect + tracker), %.2f s/frame" % (max(len(times) - 1, 1), H, W, per)}
 
     if rank == 0:
-        frames = args.steps * world
+        frames = args.steps * world * B
         line = {
             "metric": "frames/sec (detect+track) at %dx%d" % (W, H),
             "value": round(frames / dt, 3),
@@ -269,9 +274,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "PyramidBox-%s %dx%d synthetic u8 frames, batch=1 per GPU, decode+NMS+IoU-tracker "
-                                   "on device" % ("Res50" if args.arch == "res50" else "MobileNetV2-try3", W, H),
-                       "frames_per_step": world, "frames_in_flight_per_gpu": NF, "kernel_plan": plan_src, "parallelism": "frame-parallel x%d%s" % (
+            "config": {"workload": "PyramidBox-%s %dx%d synthetic u8 frames, batch=%d per GPU, decode+NMS+IoU-tracker "
+                                   "on device" % ("Res50" if args.arch == "res50" else "MobileNetV2-try3", W, H, B),
+                       "frames_per_step": world * B, "frames_in_flight_per_gpu": NF, "kernel_plan": plan_src, "parallelism": "frame-parallel x%d%s" % (
                            world, ", RCCL all-gather of box lists" if world > 1 else ""),
                        "weights": "seeded synthetic (seed 0)", "detections_last_frame": n_cand_last,
                        "tracks": len(tracks), "gpu_ms_per_step_events": round(gpu_ms / args.steps, 4),
