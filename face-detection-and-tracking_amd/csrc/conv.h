@@ -21,6 +21,7 @@ enum ConvKind {
   CONV_3x3_D2_WINO, // same arithmetic class as CONV_3x3_S1_D2 (dilation 2), Winograd on the parity sub-lattices
   CONV_1x1_S1_K32,  // CONV_1x1_S1 with 32 / 64 input channels per LDS stage (fewer, longer stages for the
   CONV_1x1_S1_K64,  // small-tile, deep-K layers)
+  CONV_7x7_S2_P1,   // pad 1 (stem of pyramid_mb2_try4.py:16: conv_bn with a 7x7 kernel, padding left at 1)
   CONV_KIND_COUNT
 };
 

@@ -108,7 +108,7 @@ struct Table {
     conv_fill_3x3_s1(e[CONV_3x3_S1]);
     conv_fill_3x3_s1_d2(e[CONV_3x3_S1_D2]);
     conv_fill_3x3_s2(e[CONV_3x3_S2]);
-    conv_fill_stems(e[CONV_7x7_S2], e[CONV_7x7_S4], e[CONV_5x5_S2]);
+    conv_fill_stems(e[CONV_7x7_S2], e[CONV_7x7_S4], e[CONV_5x5_S2], e[CONV_7x7_S2_P1]);
     conv_fill_wino(e[CONV_3x3_S1_WINO]);
     conv_fill_wino_d2(e[CONV_3x3_D2_WINO]);
     conv_fill_1x1_s1_deep(e[CONV_1x1_S1_K32], e[CONV_1x1_S1_K64]);
@@ -124,6 +124,7 @@ const ConvGeom kGeoms[CONV_KIND_COUNT] = {
     {1, 1, 1, 1, 0, 16, 0}, {1, 1, 2, 1, 0, 16, 0}, {3, 3, 1, 1, 1, 4, 0}, {3, 3, 1, 2, 2, 4, 0},
     {3, 3, 2, 1, 1, 4, 0},  {7, 7, 2, 1, 3, 2, 0},  {7, 7, 4, 1, 3, 2, 0}, {5, 5, 2, 1, 2, 2, 0},
     {3, 3, 1, 1, 1, 8, 1},  {3, 3, 1, 2, 2, 8, 1},  {1, 1, 1, 1, 0, 32, 0},  {1, 1, 1, 1, 0, 64, 0},
+    {7, 7, 2, 1, 1, 2, 0},
 };
 const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum ConvTile)
     {128, 128, 8, 16}, {128, 64, 8, 16}, {128, 32, 8, 16}, {64, 64, 8, 8},   {64, 128, 8, 8},

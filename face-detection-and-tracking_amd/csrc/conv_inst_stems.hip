@@ -3,7 +3,7 @@
 
 namespace fdt {
 // stems / FaceBox RDCL: only the tiles their Cout needs
-void conv_fill_stems(void* r72, void* r74, void* r52) {
+void conv_fill_stems(void* r72, void* r74, void* r52, void* r72p1) {
   KernelEntry* a = (KernelEntry*)r72;
   KernelEntry* b = (KernelEntry*)r74;
   KernelEntry* c = (KernelEntry*)r52;
@@ -13,5 +13,8 @@ void conv_fill_stems(void* r72, void* r74, void* r52) {
   b[TILE_128x32] = entry<G_7x7_S4, T_128x32>();
   c[TILE_128x64] = entry<G_5x5_S2, T_128x64>();
   c[TILE_64x64] = entry<G_5x5_S2, T_64x64>();
+  KernelEntry* d = (KernelEntry*)r72p1;
+  d[TILE_128x32] = entry<G_7x7_S2_P1, T_128x32>();
+  d[TILE_128x64] = entry<G_7x7_S2_P1, T_128x64>();
 }
 }  // namespace fdt

@@ -396,6 +396,7 @@ using G_3x3_S1_D2 = Geom<3, 3, 1, 2, 2, 4>;
 using G_3x3_S2 = Geom<3, 3, 2, 1, 1, 4>;
 using G_7x7_S2 = Geom<7, 7, 2, 1, 3, 2>;
 using G_7x7_S4 = Geom<7, 7, 4, 1, 3, 2>;
+using G_7x7_S2_P1 = Geom<7, 7, 2, 1, 1, 2>;
 using G_5x5_S2 = Geom<5, 5, 2, 1, 2, 2>;
 
 }  // namespace
@@ -407,6 +408,6 @@ void conv_fill_1x1_s1_deep(void* row_k32, void* row_k64);
 void conv_fill_3x3_s1(void* row);
 void conv_fill_3x3_s1_d2(void* row);
 void conv_fill_3x3_s2(void* row);
-void conv_fill_stems(void* row_7x7_s2, void* row_7x7_s4, void* row_5x5_s2);
+void conv_fill_stems(void* row_7x7_s2, void* row_7x7_s4, void* row_5x5_s2, void* row_7x7_s2_p1);
 
 }  // namespace fdt

@@ -35,7 +35,7 @@ struct Tensor {
   float* d = nullptr;
 };
 
-enum OpType { OP_CONV, OP_POOL, OP_DW, OP_HEADFIN, OP_MBOXFIN };
+enum OpType { OP_CONV, OP_POOL, OP_DW, OP_HEADFIN, OP_MBOXFIN, OP_PAD };
 
 struct Op {
   OpType type;
@@ -415,6 +415,21 @@ struct Builder {
     return out_t;
   }
 
+  int pad1(const std::string& name, int in_t) {
+    if (rc != FDT_OK) return -1;
+    const Tensor in = m->tensors[in_t];
+    int out_t = new_tensor(name, in.C, in.H + 2, in.W + 2);
+    if (out_t < 0) return -1;
+    Op op;
+    op.type = OP_PAD;
+    op.name = name;
+    op.in_t = in_t;
+    op.out_t = out_t;
+    memset(&op.ca, 0, sizeof(op.ca));
+    m->ops.push_back(op);
+    return out_t;
+  }
+
   // depthwise 3x3 + BN + ReLU6
   int dwconv(const std::string& name, const std::string& bn, int in_t, int stride, int act) {
     if (rc != FDT_OK) return -1;
@@ -646,13 +661,16 @@ struct Builder {
     return conv(p + ".conv." + std::to_string(i), h, oup, CONV_1x1_S1, o);
   }
 
-  void build_try3(int H, int W) {
+  // try3 (pyramid_mb2_try3.py), and its two siblings that differ only in the stem and the smooth layers:
+  //   try5 (pyramid_mb2_try5.py:184-191): smooth_c2/3/4 = InvertedResidual(c, c, 1, t) -> 3x3, smooth_c6 = 1x1 pad 1
+  //   try4 (pyramid_mb2_try4.py:16,184-191): try5 + 7x7/pad-1 stem + smooth_c5 = 1x1 pad 1
+  void build_try3(int H, int W, int variant = 3) {
     int x = new_tensor("input", 3, H, W);
     ConvOpt st;
     st.bn = "features.0.1";
     st.bias = false;
     st.act = ACT_RELU6;
-    int h = conv("features.0.0", x, 32, CONV_3x3_S2, st);
+    int h = conv("features.0.0", x, 32, variant == 4 ? CONV_7x7_S2_P1 : CONV_3x3_S2, st);
     if (h < 0) return;
     m->tensors[h].name = "stem";
     const int cfgs[7][4] = {{1, 16, 1, 1}, {6, 24, 2, 2}, {6, 32, 3, 2}, {6, 64, 4, 2},
@@ -677,14 +695,28 @@ struct Builder {
     m->tensors[c5].name = "c5";
     m->tensors[c6].name = "c6";
     ConvOpt lin;
-    c6 = conv("smooth_c6", c6, 160, CONV_3x3_S1, lin);   // :242-243
-    c5 = conv("smooth_c5", c5, 320, CONV_3x3_S1, lin);
+    if (variant == 3) {
+      c6 = conv("smooth_c6", c6, 160, CONV_3x3_S1, lin);   // :242-243
+    } else {
+      c6 = conv("smooth_c6", pad1("smooth_c6.pad", c6), 160, CONV_1x1_S1, lin);   // Conv2d(160,160,1,padding=1)
+    }
+    if (variant == 4) {
+      c5 = conv("smooth_c5", pad1("smooth_c5.pad", c5), 320, CONV_1x1_S1, lin);   // Conv2d(320,320,1,padding=1)
+    } else {
+      c5 = conv("smooth_c5", c5, 320, CONV_3x3_S1, lin);
+    }
     c4 = ct("conv4_ct_py", c5, c4, 96);                  // :245-247
     c3 = ct("conv3_ct_py", c4, c3, 32);
     c2 = ct("conv2_ct_py", c3, c2, 24);
-    c2 = conv("smooth_c2", c2, 24, CONV_3x3_S1, lin);    // :249-251
-    c3 = conv("smooth_c3", c3, 32, CONV_3x3_S1, lin);
-    c4 = conv("smooth_c4", c4, 96, CONV_3x3_S1, lin);
+    if (variant == 3) {
+      c2 = conv("smooth_c2", c2, 24, CONV_3x3_S1, lin);    // :249-251
+      c3 = conv("smooth_c3", c3, 32, CONV_3x3_S1, lin);
+      c4 = conv("smooth_c4", c4, 96, CONV_3x3_S1, lin);
+    } else {   // nn.Sequential(InvertedResidual(c, c, 1, t), nn.Conv2d(c, c, 3, padding=1))
+      c2 = conv("smooth_c2.1", inverted_residual("smooth_c2.0", c2, 24, 24, 1, 4), 24, CONV_3x3_S1, lin);
+      c3 = conv("smooth_c3.1", inverted_residual("smooth_c3.0", c3, 32, 32, 1, 4), 32, CONV_3x3_S1, lin);
+      c4 = conv("smooth_c4.1", inverted_residual("smooth_c4.0", c4, 96, 96, 1, 2), 96, CONV_3x3_S1, lin);
+    }
     if (rc != FDT_OK) return;
     m->tensors[c2].name = "c2_smooth";
     m->tensors[c3].name = "c3_smooth";
@@ -771,9 +803,9 @@ bool ignored_key(const fdt_model* m, const std::string& k) {
     return k.size() >= n && k.compare(k.size() - n, n, s) == 0;
   };
   if (ends_with("num_batches_tracked")) return true;
-  if (m->arch == FDT_ARCH_RES50 || m->arch == FDT_ARCH_TRY3) {
+  if (m->arch != FDT_ARCH_FACEBOX) {
     if (k.rfind("head_loc.", 0) == 0 || k.rfind("head_conf.", 0) == 0) return true;   // pyramid.py:312-317
-    if (m->arch == FDT_ARCH_TRY3 && (k.rfind("face_loc.5.", 0) == 0 || k.rfind("face_conf.5.", 0) == 0))
+    if (m->arch != FDT_ARCH_RES50 && (k.rfind("face_loc.5.", 0) == 0 || k.rfind("face_conf.5.", 0) == 0))
       return true;
   }
   return false;
@@ -786,6 +818,10 @@ int build_graph(fdt_model* m, int B, int H, int W) {
     bld.build_res50(H, W);
   else if (m->arch == FDT_ARCH_TRY3)
     bld.build_try3(H, W);
+  else if (m->arch == FDT_ARCH_TRY4)
+    bld.build_try3(H, W, 4);
+  else if (m->arch == FDT_ARCH_TRY5)
+    bld.build_try3(H, W, 5);
   else if (m->arch == FDT_ARCH_FACEBOX)
     bld.build_facebox(H, W);
   else {
@@ -909,6 +945,12 @@ int run_ops(fdt_model* m, int B, hipStream_t st) {
         FDT_TRY(launch_maxpool3(in.d, B, in.C, in.H, in.W, op.stride, op.crelu, out.d, out.H, out.W, st));
         break;
       }
+      case OP_PAD: {
+        const Tensor& in = m->tensors[op.in_t];
+        const Tensor& out = m->tensors[op.out_t];
+        FDT_TRY(launch_pad1(in.d, B * in.C, in.H, in.W, out.d, st));
+        break;
+      }
       case OP_DW: {
         const Tensor& in = m->tensors[op.in_t];
         const Tensor& out = m->tensors[op.out_t];
@@ -1003,7 +1045,7 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
 
 // ================================================================================== C ABI
 extern "C" fdt_model* fdt_model_create(int arch, int device) {
-  if (arch != FDT_ARCH_RES50 && arch != FDT_ARCH_TRY3 && arch != FDT_ARCH_FACEBOX) {
+  if (arch < FDT_ARCH_RES50 || arch > FDT_ARCH_TRY5) {
     set_error("fdt_model_create: unknown arch %d", arch);
     return nullptr;
   }
@@ -1018,7 +1060,7 @@ extern "C" fdt_model* fdt_model_create(int arch, int device) {
     set_error("fdt_model_create: stream creation failed");
     return nullptr;
   }
-  if (arch == FDT_ARCH_TRY3) {   // pyramid_mb2_try3.py:216
+  if (arch == FDT_ARCH_TRY3 || arch == FDT_ARCH_TRY4 || arch == FDT_ARCH_TRY5) {   // pyramid_mb2_try3.py:216
     m->conf_t = 0.2f;
     m->nms_t = 0.35f;
   }

@@ -224,6 +224,20 @@ __global__ __launch_bounds__(256) void dwconv3_vec_kernel(const float* __restric
   }
 }
 
+// zero border of one pixel: nn.Conv2d(c, c, kernel_size=1, padding=1) == 1x1 conv of the padded map
+// (pyramid_mb2_try4.py:190-191, pyramid_mb2_try5.py:191)
+__global__ void pad1_kernel(const float* __restrict__ in, int H, int W, float* __restrict__ out, long long total) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= total) return;
+  const int Wo = W + 2, Ho = H + 2;
+  const int x = (int)(i % Wo);
+  const long long t = i / Wo;
+  const int y = (int)(t % Ho);
+  const long long bc = t / Ho;
+  const bool inside = x >= 1 && x <= W && y >= 1 && y <= H;
+  out[i] = inside ? in[(bc * H + (y - 1)) * W + (x - 1)] : 0.0f;
+}
+
 __device__ __forceinline__ void softmax2(float a, float b, float& pa, float& pb) {
   float m = fmaxf(a, b);
   float ea = expf(a - m), eb = expf(b - m);
@@ -326,6 +340,13 @@ int launch_dwconv3(const float* in, const float* w9, const float* bias, int B, i
   FDT_REQUIRE((long long)B * C <= 65535 && Ho <= 65535, FDT_ERR_ARG, "dwconv: grid too large");
   dim3 grid(ceil_div(Wo, 64), Ho, B * C);
   hipLaunchKernelGGL(dwconv3_kernel, grid, dim3(64), 0, st, in, w9, bias, C, H, W, stride, act, out, Ho, Wo);
+  FDT_LAUNCH_CHECK();
+  return FDT_OK;
+}
+
+int launch_pad1(const float* in, int BC, int H, int W, float* out, hipStream_t st) {
+  const long long total = (long long)BC * (H + 2) * (W + 2);
+  hipLaunchKernelGGL(pad1_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, H, W, out, total);
   FDT_LAUNCH_CHECK();
   return FDT_OK;
 }

@@ -139,10 +139,11 @@ def try3_blocks():
     return blocks
 
 
-def try3_schema():
-    """(name, shape, kind) in the order of reference `SFD_mobile.state_dict()`."""
+def try3_schema(variant=3):
+    """(name, shape, kind) in the order of reference `SFD_mobile.state_dict()`; variant 4 / 5 = the try4 / try5
+    siblings (pyramid_mb2_try4.py:16,184-191, pyramid_mb2_try5.py:184-191)."""
     s = []
-    _conv(s, "features.0.0", 3, 32, 3, False)
+    _conv(s, "features.0.0", 3, 32, 7 if variant == 4 else 3, False)
     _bn(s, "features.0.1", 32, stem=True)
     for idx, inp, oup, st, t in try3_blocks():
         _ir(s, "features.%d" % idx, inp, oup, t, st)
@@ -150,8 +151,13 @@ def try3_schema():
     _ct(s, "conv2_ct_py", 32, 24)
     _ct(s, "conv3_ct_py", 96, 32)
     _ct(s, "conv4_ct_py", 320, 96)
-    for n, c in zip(range(2, 7), (24, 32, 96, 320, 160)):
-        _conv(s, "smooth_c%d" % n, c, c, 3, True, kind="conv_w_lin")
+    for n, c, t in zip(range(2, 7), (24, 32, 96, 320, 160), (4, 4, 2, 0, 0)):
+        if variant != 3 and t:
+            _ir(s, "smooth_c%d.0" % n, c, c, t, 1)
+            _conv(s, "smooth_c%d.1" % n, c, c, 3, True, kind="conv_w_lin")
+        else:
+            k = 1 if (variant != 3 and n == 6) or (variant == 4 and n == 5) else 3
+            _conv(s, "smooth_c%d" % n, c, c, k, True, kind="conv_w_lin")
     for n, c in zip(range(2, 7), (24, 32, 96, 320, 160)):
         _ssh(s, "conv%d_SSH" % n, c, 128)
     for i in range(6):
@@ -208,6 +214,8 @@ def make_state_dict(arch="res50", seed=0, conf_shift=None):
         schema, default_shift = res50_schema(), RES50_CONF_SHIFT
     elif arch == "try3":
         schema, default_shift = try3_schema(), TRY3_CONF_SHIFT
+    elif arch in ("try4", "try5"):
+        schema, default_shift = try3_schema(int(arch[3])), TRY3_CONF_SHIFT
     else:
         raise ValueError("unknown arch %r" % (arch,))
     if conf_shift is None:

@@ -34,6 +34,8 @@ extern "C" {
 #define FDT_ARCH_RES50 0    /* pyramid.py:367-374 build_sfd -> SFD(Bottleneck,[3,4,6,3])   */
 #define FDT_ARCH_TRY3 1     /* pyramid_mb2_try3.py:359-366 build_sfd_mobile               */
 #define FDT_ARCH_FACEBOX 2  /* FACEBOX/networks.py:60-116 FaceBox                          */
+#define FDT_ARCH_TRY4 3     /* pyramid_mb2_try4.py:363-370 build_sfd_mobile (7x7 stem)     */
+#define FDT_ARCH_TRY5 4     /* pyramid_mb2_try5.py:363-370 build_sfd_mobile                */
 
 /* frame formats of fdt_model_forward */
 #define FDT_FRAME_U8_HWC_BGR 0 /* raw video frame; mean (104,117,123) is subtracted on device:

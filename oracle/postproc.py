@@ -68,10 +68,12 @@ def feature_sizes(height, width, arch="res50"):
     return out
 
 
-def build_priors(priorbox, height, width, arch="res50"):
-    """cat of priorbox(idx, f_w, f_h) over the sources (reference pyramid.py:275-283)."""
-    return np.concatenate([priorbox(idx, fw, fh)
-                           for idx, (fh, fw) in enumerate(feature_sizes(height, width, arch))], 0)
+def build_priors(priorbox, height, width, arch="res50", sizes=None):
+    """cat of priorbox(idx, f_w, f_h) over the sources (reference pyramid.py:275-283).  `sizes` = the (h, w)
+    of the sources when they do not follow the stride pyramid (try4 / try5: 1x1 convs with padding 1)."""
+    if sizes is None:
+        sizes = feature_sizes(height, width, arch)
+    return np.concatenate([priorbox(idx, fw, fh) for idx, (fh, fw) in enumerate(sizes)], 0)
 
 
 # --------------------------------------------------------------------------- decode

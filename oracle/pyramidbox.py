@@ -159,13 +159,15 @@ def _try3_blocks():
 
 
 @torch.no_grad()
-def try3_forward(sd, x, want=()):
-    """PyramidBox-MobileNetV2 "try3" forward, reference pyramid_mb2_try3.py:218-340."""
+def try3_forward(sd, x, want=(), variant=3):
+    """PyramidBox-MobileNetV2 "try3" forward, reference pyramid_mb2_try3.py:218-340; variant 4 / 5 restate
+    pyramid_mb2_try4.py / pyramid_mb2_try5.py (:221-343), which differ in the stem kernel (try4: 7x7, padding
+    still 1, :16) and in the smooth layers (:184-191)."""
     sd = _t(sd)
     x = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.asarray(x, dtype=np.float32))
     blocks = _try3_blocks()
     t = {}
-    h = F.relu6(_bn(sd, "features.0.1", _conv(sd, "features.0.0", x, 2, 1)))
+    h = F.relu6(_bn(sd, "features.0.1", _conv(sd, "features.0.0", x, 2, 1)))   # padding 1 for 3x3 AND 7x7
     t["stem"] = h
     taps = {}
     for idx, inp, oup, st, tt in blocks:
@@ -174,14 +176,19 @@ def try3_forward(sd, x, want=()):
     c2, c3, c4, c5 = taps[3], taps[6], taps[13], taps[17]             # :229-236
     c6 = _ir(sd, "layer6", c5, 320, 160, 2, 6)                        # :238
     t.update(c2=c2, c3=c3, c4=c4, c5=c5, c6=c6)
-    c6 = _conv(sd, "smooth_c6", c6, 1, 1)                             # :242-243
-    c5 = _conv(sd, "smooth_c5", c5, 1, 1)
+    c6 = _conv(sd, "smooth_c6", c6, 1, 1)                             # :242-243 (try4/5: kernel 1, padding 1)
+    c5 = _conv(sd, "smooth_c5", c5, 1, 1)                             # (try4: kernel 1, padding 1)
     c4 = _ct(sd, "conv4_ct_py", c5, c4)                               # :245-247
     c3 = _ct(sd, "conv3_ct_py", c4, c3)
     c2 = _ct(sd, "conv2_ct_py", c3, c2)
-    c2 = _conv(sd, "smooth_c2", c2, 1, 1)                             # :249-251
-    c3 = _conv(sd, "smooth_c3", c3, 1, 1)
-    c4 = _conv(sd, "smooth_c4", c4, 1, 1)
+    if variant == 3:
+        c2 = _conv(sd, "smooth_c2", c2, 1, 1)                         # :249-251
+        c3 = _conv(sd, "smooth_c3", c3, 1, 1)
+        c4 = _conv(sd, "smooth_c4", c4, 1, 1)
+    else:       # nn.Sequential(InvertedResidual(c, c, 1, t), nn.Conv2d(c, c, 3, padding=1))
+        c2 = _conv(sd, "smooth_c2.1", _ir(sd, "smooth_c2.0", c2, 24, 24, 1, 4), 1, 1)
+        c3 = _conv(sd, "smooth_c3.1", _ir(sd, "smooth_c3.0", c3, 32, 32, 1, 4), 1, 1)
+        c4 = _conv(sd, "smooth_c4.1", _ir(sd, "smooth_c4.0", c4, 96, 96, 1, 2), 1, 1)
     t.update(c2_smooth=c2, c3_smooth=c3, c4_smooth=c4, c5_smooth=c5, c6_smooth=c6)
     sources = [_ssh(sd, "conv2_SSH", c2), _ssh(sd, "conv3_SSH", c3), _ssh(sd, "conv4_SSH", c4),
                _ssh(sd, "conv5_SSH", c5), _ssh(sd, "conv6_SSH", c6)]  # :257-266
@@ -189,7 +196,8 @@ def try3_forward(sd, x, want=()):
         t["src%d" % i] = s
     loc, conf_logits = _heads(sd, sources)     # zip() truncates to 5 sources (:288)
     t["conf_logits"] = conf_logits
-    out = {"loc": loc.numpy(), "conf": torch.softmax(conf_logits, -1).numpy()}
+    out = {"loc": loc.numpy(), "conf": torch.softmax(conf_logits, -1).numpy(),
+           "source_sizes": [(int(s_.shape[2]), int(s_.shape[3])) for s_ in sources]}
     for k in want:
         out[k] = t[k].numpy()
     return out
@@ -206,15 +214,17 @@ def detect_frame(sd, frame_bgr_u8, arch="res50", detect=None, priorbox=None):
     """Full per-frame path: preprocess -> net -> Detect.  Returns [1,2,top_k,5]."""
     x = preprocess(frame_bgr_u8)
     H, W = x.shape[2], x.shape[3]
-    fwd = res50_forward if arch == "res50" else try3_forward
-    o = fwd(sd, x)
+    if arch == "res50":
+        o = res50_forward(sd, x)
+    else:
+        o = try3_forward(sd, x, variant=int(arch[3]))
     if priorbox is None:
         if arch == "res50":
             priorbox = postproc.PriorBoxLayer(W, H)
         else:
             priorbox = postproc.PriorBoxLayer(W, H, stride=[4, 8, 16, 32, 64],
                                               box=(16, 32, 64, 128, 256))
-    priors = postproc.build_priors(priorbox, H, W, arch)
+    priors = postproc.build_priors(priorbox, H, W, arch, sizes=o.get("source_sizes"))
     if detect is None:
         detect = (postproc.Detect(2, 0, 750, 0.3, 0.5) if arch == "res50"
                   else postproc.Detect(2, 0, 750, 0.2, 0.35))

@@ -305,8 +305,8 @@ def _ref_net(arch, sd):
         from pyramid import build_sfd
         net = build_sfd("test", 640, 2)
     else:
-        from pyramid_mb2_try3 import build_sfd_mobile
-        net = build_sfd_mobile("test", 640, 2)
+        mod = {"try3": "pyramid_mb2_try3", "try4": "pyramid_mb2_try4", "try5": "pyramid_mb2_try5"}[arch]
+        net = importlib.import_module(mod).build_sfd_mobile("test", 640, 2)
     ref_keys = list(net.state_dict().keys())
     assert ref_keys == list(sd.keys()), "synthetic schema != reference state_dict keys"
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
@@ -361,6 +361,48 @@ def gen_nets():
             print(key, meta[key])
     out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     save("nets", **out)
+
+
+def gen_nets45():
+    """try4 / try5: the reference modules pyramid_mb2_try4.py / pyramid_mb2_try5.py run on
+    seeded weights and frames; stored: the pre-Detect loc/conf (whole for small inputs, a strided sample at
+    640x480), the Detect rows, the source sizes and three intermediate maps at the smallest size."""
+    from layers import PriorBoxLayer, Detect
+    from oracle import pyramidbox as opb
+    out, meta = {}, {}
+    for arch in ("try4", "try5"):
+        sd = synth.make_state_dict(arch, seed=0)
+        net = _ref_net(arch, sd)
+        for (H, W, seed, ct, nt) in ((64, 64, 17, 0.02, 0.35), (136, 200, 18, 0.02, 0.35), (480, 640, 19, 0.2, 0.35)):
+            frame = synth.make_frames(1, H, W, seed=seed)[0]
+            x = torch.from_numpy(opb.preprocess(frame))
+            net.priorbox = PriorBoxLayer(W, H, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256))
+            net.firstTime = True
+            real = Detect(2, 0, 750, ct, nt)
+            cap = {}
+
+            def spy(loc, conf, priors, _real=real, _cap=cap):
+                _cap["loc"], _cap["conf"], _cap["priors"] = loc.numpy().copy(), conf.numpy().copy(), priors.numpy().copy()
+                return _real(loc, conf, priors)
+            net.detect = spy
+            with torch.no_grad():
+                y = net(x).numpy()
+            key = "%s_%dx%d" % (arch, H, W)
+            n_out = int((y[0, 1, :, 0] > 0).sum())
+            meta[key] = {"H": H, "W": W, "frame_seed": seed, "conf_t": ct, "nms_t": nt, "n_out": n_out,
+                         "n_cand": int((cap["conf"][0, :, 1] > np.float32(ct)).sum()), "P": int(cap["loc"].shape[1]),
+                         "loc_sha": sha(cap["loc"]), "conf_sha": sha(cap["conf"]), "priors_sha": sha(cap["priors"])}
+            out[key + "_out"] = y[0, 1, :max(n_out, 1)]
+            if cap["loc"].shape[1] <= 3000:
+                out[key + "_loc"], out[key + "_conf"], out[key + "_priors"] = cap["loc"], cap["conf"], cap["priors"]
+            else:
+                sel = np.linspace(0, cap["loc"].shape[1] - 1, 1024).astype(np.int64)
+                out[key + "_sel"] = sel
+                out[key + "_loc_s"], out[key + "_conf_s"] = cap["loc"][0, sel], cap["conf"][0, sel]
+                out[key + "_priors_s"] = cap["priors"][sel]
+            print(key, meta[key])
+    out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    save("nets45", **out)
 
 
 # ----------------------------------------------------------------------------- FaceBoxes (real weights)
@@ -424,7 +466,8 @@ def gen_facebox():
     save("facebox", **out)
 
 
-GENS = {"facebox": gen_facebox, "priors": gen_priors, "detect": gen_detect, "iou": gen_iou, "tracker": gen_tracker, "nets": gen_nets}
+GENS = {"facebox": gen_facebox, "priors": gen_priors, "detect": gen_detect, "iou": gen_iou, "tracker": gen_tracker, "nets": gen_nets,
+        "nets45": gen_nets45}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 KINDS = {  # name: (k, stride, pad, dil)
     "1x1s1": (1, 1, 0, 1), "1x1s2": (1, 2, 0, 1), "3x3s1": (3, 1, 1, 1), "3x3d2": (3, 1, 2, 2),
-    "3x3s2": (3, 2, 1, 1), "7x7s2": (7, 2, 3, 1), "7x7s4": (7, 4, 3, 1), "5x5s2": (5, 2, 2, 1)}
+    "3x3s2": (3, 2, 1, 1), "7x7s2": (7, 2, 3, 1), "7x7s4": (7, 4, 3, 1), "5x5s2": (5, 2, 2, 1),
+    "7x7s2p1": (7, 2, 1, 1)}
 N_TILES = 29      # 14 direct tiles + 11 Winograd F(2x2,3x3) tiles (3x3 s1 only) + 4 ring-of-four tiles (1x1 only)
 
 

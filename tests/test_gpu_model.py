@@ -193,3 +193,63 @@ def test_autotuned_plan_keeps_parity(res50, res50_sd, synth):
     n = int((exp[0, 1, :, 0] > 0).sum())
     d_iou, d_sc = match_detections(y[0, 1], exp[0, 1], n)
     assert n > 10 and d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
+
+
+# ------------------------------------------------------------------ try4 / try5
+@pytest.fixture(scope="module", params=["try4", "try5"])
+def try45(request, synth):
+    arch = request.param
+    net = M("pyramid_mb2_" + arch).build_sfd_mobile('test', 640, 2)
+    sd = synth.make_state_dict(arch, seed=0)
+    net.load_state_dict(sd)
+    yield arch, net, sd
+    net.close()
+
+
+@pytest.mark.parametrize("H,W,seed", [(64, 64, 27), (136, 200, 28)])
+def test_try45_stages_vs_oracle(try45, synth, H, W, seed):
+    """7x7/pad-1 stem (try4), InvertedResidual smooth layers, 1x1 convs with padding 1 (sources grow by a
+    zero-padded pixel per side) -- stage tensors, priors (bit-exact) and detections against the oracle."""
+    arch, net, sd = try45
+    frame = synth.make_frames(1, H, W, seed=seed)[0]
+    x = opb.preprocess(frame)
+    PB = M("layers").PriorBoxLayer
+    net.priorbox = PB(W, H, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256)); net.firstTime = True
+    net.detect = M("layers").Detect(2, 0, 750, 0.02, 0.35)
+    y = net(x).numpy()
+    o = opb.try3_forward(sd, x, want=TRY3_STAGES, variant=int(arch[3]))
+    assert [tuple(s) for s in net.source_sizes(H, W)] == [tuple(s) for s in o["source_sizes"]]
+    for st in TRY3_STAGES:
+        got = net.get_tensor(st)
+        assert got.shape == o[st].shape, (st, got.shape, o[st].shape)
+        assert rel_rms(got, o[st]) < STAGE_RTOL, (st, rel_rms(got, o[st]))
+    pri = opp.build_priors(opp.PriorBoxLayer(W, H, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256)),
+                           H, W, arch, sizes=o["source_sizes"])
+    assert np.array_equal(net.priors.numpy(), pri)
+    loc, conf = net.forward_raw(x)
+    assert loc.shape == o["loc"].shape and rel_rms(loc, o["loc"]) < STAGE_RTOL
+    exp = opp.Detect(2, 0, 750, 0.02, 0.35)(o["loc"], o["conf"], pri)
+    n = int((exp[0, 1, :, 0] > 0).sum())
+    d_iou, d_sc = match_detections(y[0, 1], exp[0, 1], n)
+    assert n > 5 and d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
+
+
+@pytest.mark.parametrize("size", ["64x64", "136x200", "480x640"])
+def test_try45_vs_reference_fixture(try45, synth, size):
+    """Final detections vs what the reference modules pyramid_mb2_try4.py / _try5.py produced here
+    (tests/golden/nets45.npz)."""
+    arch, net, _ = try45
+    d, meta = load_npz("nets45")
+    key = "%s_%s" % (arch, size)
+    m = meta[key]
+    H, W = m["H"], m["W"]
+    frame = synth.make_frames(1, H, W, seed=m["frame_seed"])[0]
+    PB = M("layers").PriorBoxLayer
+    net.priorbox = PB(W, H, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256)); net.firstTime = True
+    net.detect = M("layers").Detect(2, 0, 750, m["conf_t"], m["nms_t"])
+    y = net(frame).numpy()
+    assert net.priors.shape[0] == m["P"]
+    exp = d[key + "_out"]
+    d_iou, d_sc = match_detections(y[0, 1], np.vstack([exp, np.zeros((750 - exp.shape[0], 5), np.float32)]),
+                                   m["n_out"])
+    assert d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
