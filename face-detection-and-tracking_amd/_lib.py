@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libfdt_hip.so")
 
 FDT_OK = 0
 FDT_ERR_ARG, FDT_ERR_HIP, FDT_ERR_STATE, FDT_ERR_NAME = -1, -2, -3, -4
-ARCH_RES50, ARCH_TRY3, ARCH_FACEBOX, ARCH_TRY4, ARCH_TRY5 = 0, 1, 2, 3, 4
+ARCH_RES50, ARCH_TRY3, ARCH_FACEBOX, ARCH_TRY4, ARCH_TRY5, ARCH_TRY1, ARCH_TRY2 = 0, 1, 2, 3, 4, 5, 6
 FRAME_U8_HWC_BGR, FRAME_F32_NCHW = 0, 1
 F32, F64 = 0, 1
 

@@ -47,6 +47,7 @@ struct Op {
   ConvArgs ca;
   // pool / dw / finalize
   int in_t = -1, in2_t = -1, out_t = -1, stride = 1, crelu = 0, act = 0;
+  int ksize = 3, pad = 1, dil = 1;   // depthwise geometry
   const float* w = nullptr;
   const float* bias = nullptr;
   int level0 = 0, p_off = 0, anchors = 1;
@@ -275,6 +276,7 @@ struct Builder {
     int up_t = -1;            // coarser map to bilinear-upsample and add
     std::string name2;        // second conv concatenated along Cout (fused loc+conf heads)
     int cout2 = 0;
+    int groups = 1;           // grouped 1x1 (pyramid_mobile_try1.py:185-186): run as the block-diagonal dense conv
   };
 
   int conv(const std::string& name, int in_t, int Cout, ConvKind kind, const ConvOpt& o) {
@@ -337,8 +339,8 @@ struct Builder {
     if (!m->dry) {
       if (rc != FDT_OK) return -1;
       const size_t per = (size_t)in.C * g.kh * g.kw;
-      if (w->v.size() != per * Cout || (b && (int)b->v.size() != Cout) ||
-          (w2 && w2->v.size() != per * o.cout2)) {
+      if (w->v.size() * o.groups != per * Cout || (b && (int)b->v.size() != Cout) ||
+          (w2 && w2->v.size() != per * o.cout2) || in.C % o.groups || Cout % o.groups || (o.groups > 1 && o.cout2)) {
         set_error("weight shape mismatch for layer %s", name.c_str());
         return fail(FDT_ERR_STATE);
       }
@@ -346,6 +348,17 @@ struct Builder {
       fold(o.bn, b, Cout, scale, bias);
       if (rc != FDT_OK) return -1;
       const std::vector<float>* wsrc = &w->v;
+      if (o.groups > 1) {   // zeros outside the diagonal blocks add exact 0.0f to every fmaf chain
+        const size_t cig = in.C / o.groups, cog = Cout / o.groups, kk = (size_t)g.kh * g.kw;
+        wcat.assign(per * Cout, 0.0f);
+        for (int co = 0; co < Cout; ++co) {
+          const size_t gi = co / cog;
+          for (size_t ci = 0; ci < cig; ++ci)
+            for (size_t k = 0; k < kk; ++k)
+              wcat[(size_t)co * per + (gi * cig + ci) * kk + k] = w->v[((size_t)co * cig + ci) * kk + k];
+        }
+        wsrc = &wcat;
+      }
       if (o.cout2) {
         wcat = w->v;
         wcat.insert(wcat.end(), w2->v.begin(), w2->v.end());
@@ -431,13 +444,20 @@ struct Builder {
   }
 
   // depthwise 3x3 + BN + ReLU6
-  int dwconv(const std::string& name, const std::string& bn, int in_t, int stride, int act) {
+  int dwconv(const std::string& name, const std::string& bn, int in_t, int stride, int act, int K = 3, int pad = 1,
+             int dil = 1, bool has_bias = false) {
     if (rc != FDT_OK) return -1;
     const Tensor in = m->tensors[in_t];
-    const int Ho = (in.H - 1) / stride + 1, Wo = (in.W - 1) / stride + 1;
+    const int Ho = (in.H + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+    const int Wo = (in.W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+    if (Ho < 1 || Wo < 1) {
+      set_error("input too small: layer %s would have a %dx%d output", name.c_str(), Ho, Wo);
+      return fail(FDT_ERR_ARG);
+    }
     int out_t = new_tensor(name, in.C, Ho, Wo);
     if (out_t < 0) return -1;
     const HostT* w = get(name + ".weight");
+    const HostT* cb = has_bias ? get(name + ".bias") : nullptr;
     Op op;
     op.type = OP_DW;
     op.name = name;
@@ -445,13 +465,16 @@ struct Builder {
     op.out_t = out_t;
     op.stride = stride;
     op.act = act;
-    op.flops = 2.0 * B * (double)Ho * Wo * in.C * 9;
+    op.ksize = K;
+    op.pad = pad;
+    op.dil = dil;
+    op.flops = 2.0 * B * (double)Ho * Wo * in.C * K * K;
     memset(&op.ca, 0, sizeof(op.ca));
     std::vector<float> scale, bias;
-    fold(bn, nullptr, in.C, scale, bias);
+    fold(bn, cb, in.C, scale, bias);
     if (!m->dry) {
       if (rc != FDT_OK) return -1;
-      if ((int)w->v.size() != in.C * 9) {
+      if ((int)w->v.size() != in.C * K * K) {
         set_error("depthwise weight shape mismatch for %s", name.c_str());
         return fail(FDT_ERR_STATE);
       }
@@ -461,7 +484,7 @@ struct Builder {
       if (it == m->wcache.end()) {
         std::vector<float> ws(w->v);
         for (int c = 0; c < in.C; ++c)
-          for (int k = 0; k < 9; ++k) ws[c * 9 + k] *= scale[c];
+          for (int k = 0; k < K * K; ++k) ws[c * K * K + k] *= scale[c];
         if (hipMalloc((void**)&d.w, ws.size() * 4) != hipSuccess ||
             hipMalloc((void**)&d.bias, bias.size() * 4) != hipSuccess) {
           set_error("hipMalloc failed for %s", name.c_str());
@@ -734,6 +757,120 @@ struct Builder {
     heads(src);   // zip() truncates to the 5 sources (:288): face_*.5 are dead weights
   }
 
+  // ---------------------------------------------------------------- try1 / try2   pyramid_mobile_try{1,2}.py
+  // Mobilenetv2(inp, oup, k, stride, t, padding, dilation, side_way[, bias]) (:103-134): 1x1 expand + BN + ReLU6,
+  // depthwise kxk + BN + ReLU6, 1x1 project + BN, optional identity add.
+  int mbv2(const std::string& p, int x, int inp, int oup, int k, int stride, int t, int pad, int dil, bool side_way,
+           bool dw_bias = false) {
+    ConvOpt o1;
+    o1.bias = false;
+    o1.bn = p + ".bn1";
+    o1.act = ACT_RELU6;
+    int h = conv(p + ".conv1", x, inp * t, CONV_1x1_S1, o1);
+    h = dwconv(p + ".conv2", p + ".bn2", h, stride, ACT_RELU6, k, pad, dil, dw_bias);
+    ConvOpt o3;
+    o3.bias = false;
+    o3.bn = p + ".bn3";
+    if (side_way) o3.res_t = x;
+    return conv(p + ".conv3", h, oup, CONV_1x1_S1, o3);
+  }
+  // Mobilenetv1(cin, cout, k, stride, padding, dilation[, bias]) (:84-99): depthwise + BN + ReLU, 1x1 (no bias)
+  int mbv1(const std::string& p, int x, int cout, int k, int stride, int pad, int dil, bool dw_bias,
+           const ConvOpt& tail) {
+    int h = dwconv(p + ".conv1", p + ".bn", x, stride, ACT_RELU, k, pad, dil, dw_bias);
+    ConvOpt o = tail;
+    o.bias = false;
+    return conv(p + ".conv2", h, cout, CONV_1x1_S1, o);
+  }
+
+  void build_try12(int H, int W, int variant) {
+    int x = new_tensor("input", 3, H, W);
+    ConvOpt st;   // c1 = F.relu(self.bn1(self.conv1_my(x)))  (:232)
+    st.bn = "bn1";
+    st.act = ACT_RELU;
+    int c1 = mbv1("conv1_my", x, 64, 7, 2, 3, 1, false, st);
+    if (c1 < 0) return;
+    m->tensors[c1].name = "stem";
+    int h = pool("pool", c1, 2, 0);
+    struct Blk { int inp, oup, k, stride, t, pad, dil, side; };
+    std::vector<std::vector<Blk>> layers;
+    if (variant == 1) {   // pyramid_mobile_try1.py:160-181
+      layers = {{{64, 64, 3, 1, 2, 1, 1, 1}, {64, 64, 3, 1, 2, 1, 1, 1}, {64, 256, 3, 1, 2, 1, 1, 0}},
+                {{256, 64, 5, 2, 2, 2, 1, 0}, {64, 512, 3, 1, 2, 2, 2, 0}},
+                {{512, 256, 5, 2, 2, 2, 1, 0}, {256, 256, 5, 1, 2, 2, 1, 1}, {256, 1024, 3, 1, 2, 2, 2, 0}},
+                {{1024, 256, 5, 2, 2, 2, 1, 0}, {256, 2048, 3, 1, 2, 1, 1, 0}}};
+    } else {              // pyramid_mobile_try2.py:163-189 (t = 4 by default, 2 in layer3)
+      layers = {{{64, 64, 3, 1, 4, 1, 1, 1}, {64, 64, 3, 1, 4, 1, 1, 1}, {64, 64, 3, 1, 4, 1, 1, 1}},
+                {{64, 64, 3, 2, 4, 1, 1, 0}, {64, 64, 3, 1, 4, 1, 1, 1}, {64, 64, 3, 1, 4, 1, 1, 1},
+                 {64, 128, 3, 1, 4, 1, 1, 0}},
+                {{128, 128, 3, 2, 2, 1, 1, 0}, {128, 128, 3, 1, 2, 1, 1, 1}, {128, 128, 3, 1, 2, 1, 1, 1},
+                 {128, 128, 3, 1, 2, 1, 1, 1}, {128, 128, 3, 1, 2, 1, 1, 1}, {128, 256, 3, 1, 2, 1, 1, 0}},
+                {{256, 256, 3, 2, 4, 1, 1, 0}, {256, 256, 3, 1, 4, 1, 1, 1}, {256, 512, 3, 1, 4, 1, 1, 0}}};
+    }
+    int feats[4];
+    for (int li = 0; li < 4; ++li) {
+      for (size_t bi = 0; bi < layers[li].size(); ++bi) {
+        const Blk& b = layers[li][bi];
+        h = mbv2("layer" + std::to_string(li + 1) + "_my." + std::to_string(bi), h, b.inp, b.oup, b.k, b.stride, b.t,
+                 b.pad, b.dil, b.side != 0);
+        if (rc != FDT_OK) return;
+      }
+      feats[li] = h;
+    }
+    const int t56 = variant == 1 ? 2 : 4;
+    const int c5_in = variant == 1 ? 2048 : 512;
+    int c6 = mbv2("layer5_my", feats[3], c5_in, 512, 3, 2, t56, 1, 1, false, variant == 2);   // :182 / try2 :191
+    int c7 = mbv2("layer6_my", c6, 512, 256, 3, 2, t56, 1, 1, false, variant == 2);
+    if (rc != FDT_OK) return;
+    if (variant == 2) {   // layerN_adj: Conv2d(c, 4c', 1, bias=False) applied after the whole backbone (try2 :255-258)
+      const int adj[4] = {256, 512, 1024, 2048};
+      ConvOpt nb;
+      nb.bias = false;
+      for (int li = 0; li < 4; ++li) feats[li] = conv("layer" + std::to_string(li + 1) + "_adj", feats[li], adj[li],
+                                                      CONV_1x1_S1, nb);
+      if (rc != FDT_OK) return;
+    }
+    const int c2 = feats[0], c3 = feats[1], c4 = feats[2], c5 = feats[3];
+    m->tensors[c2].name = "c2";
+    m->tensors[c3].name = "c3";
+    m->tensors[c4].name = "c4";
+    m->tensors[c5].name = "c5";
+    m->tensors[c6].name = "c6";
+    m->tensors[c7].name = "c7";
+    ConvOpt lin;
+    lin.groups = 4;
+    int c5_lat = conv("latlayer_fc_my", c5, 2048, CONV_1x1_S1, lin);   // groups=4 (:185)
+    lin.groups = 2;
+    int c6_lat = conv("latlayer_c6_my", c6, 512, CONV_1x1_S1, lin);    // groups=2
+    lin.groups = 1;
+    int c7_lat = conv("latlayer_c7_my", c7, 256, CONV_1x1_S1, lin);
+    int c4_f = ct("conv5_ct_py", c5_lat, c4, 1024);
+    int c3_f = ct("conv4_ct_py", c4_f, c3, 512);
+    int c2_f = ct("conv3_ct_py", c3_f, c2, 256);
+    if (rc != FDT_OK) return;
+    m->tensors[c4_f].name = "c4_ct";
+    m->tensors[c3_f].name = "c3_ct";
+    m->tensors[c2_f].name = "c2_ct";
+    ConvOpt none;
+    int c2_s = mbv1("smooth_c3_my", c2_f, 256, 3, 1, 1, 1, variant == 2, none);
+    int c3_s = mbv1("smooth_c4_my", c3_f, 512, 3, 1, 1, 1, variant == 2, none);
+    int c4_s = mbv1("smooth_c5_my", c4_f, 1024, 3, 1, 1, 1, variant == 2, none);
+    if (rc != FDT_OK) return;
+    m->tensors[c2_s].name = "c2_smooth";
+    m->tensors[c3_s].name = "c3_smooth";
+    m->tensors[c4_s].name = "c4_smooth";
+    std::vector<int> src;
+    src.push_back(ssh("conv2_SSH", c2_s, 256));
+    src.push_back(ssh("conv3_SSH", c3_s, 256));
+    src.push_back(ssh("conv4_SSH", c4_s, 256));
+    src.push_back(ssh("conv5_SSH", c5_lat, 256));
+    src.push_back(ssh("conv6_SSH", c6_lat, 256));
+    src.push_back(ssh("conv7_SSH", c7_lat, 256));
+    if (rc != FDT_OK) return;
+    for (size_t i = 0; i < src.size(); ++i) m->tensors[src[i]].name = "src" + std::to_string(i);
+    heads(src);
+  }
+
   // ---------------------------------------------------------------- FaceBox   FACEBOX/networks.py:87-116
   int cbr(const std::string& n, int x, int cout, ConvKind kind, int out_t = -1, int coff = 0) {
     ConvOpt o;   // conv_bn_relu(): Conv2d(bias) -> BatchNorm2d -> ReLU   (networks.py:11-16)
@@ -805,7 +942,8 @@ bool ignored_key(const fdt_model* m, const std::string& k) {
   if (ends_with("num_batches_tracked")) return true;
   if (m->arch != FDT_ARCH_FACEBOX) {
     if (k.rfind("head_loc.", 0) == 0 || k.rfind("head_conf.", 0) == 0) return true;   // pyramid.py:312-317
-    if (m->arch != FDT_ARCH_RES50 && (k.rfind("face_loc.5.", 0) == 0 || k.rfind("face_conf.5.", 0) == 0))
+    if ((m->arch == FDT_ARCH_TRY3 || m->arch == FDT_ARCH_TRY4 || m->arch == FDT_ARCH_TRY5) &&
+        (k.rfind("face_loc.5.", 0) == 0 || k.rfind("face_conf.5.", 0) == 0))
       return true;
   }
   return false;
@@ -822,6 +960,10 @@ int build_graph(fdt_model* m, int B, int H, int W) {
     bld.build_try3(H, W, 4);
   else if (m->arch == FDT_ARCH_TRY5)
     bld.build_try3(H, W, 5);
+  else if (m->arch == FDT_ARCH_TRY1)
+    bld.build_try12(H, W, 1);
+  else if (m->arch == FDT_ARCH_TRY2)
+    bld.build_try12(H, W, 2);
   else if (m->arch == FDT_ARCH_FACEBOX)
     bld.build_facebox(H, W);
   else {
@@ -954,8 +1096,8 @@ int run_ops(fdt_model* m, int B, hipStream_t st) {
       case OP_DW: {
         const Tensor& in = m->tensors[op.in_t];
         const Tensor& out = m->tensors[op.out_t];
-        FDT_TRY(launch_dwconv3(in.d, op.w, op.bias, B, in.C, in.H, in.W, op.stride, op.act, out.d, out.H,
-                               out.W, st));
+        FDT_TRY(launch_dwconv(in.d, op.w, op.bias, B, in.C, in.H, in.W, op.ksize, op.stride, op.pad, op.dil, op.act,
+                              out.d, out.H, out.W, st));
         break;
       }
       case OP_HEADFIN: {
@@ -1045,7 +1187,7 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
 
 // ================================================================================== C ABI
 extern "C" fdt_model* fdt_model_create(int arch, int device) {
-  if (arch < FDT_ARCH_RES50 || arch > FDT_ARCH_TRY5) {
+  if (arch < FDT_ARCH_RES50 || arch > FDT_ARCH_TRY2) {
     set_error("fdt_model_create: unknown arch %d", arch);
     return nullptr;
   }
@@ -1063,6 +1205,10 @@ extern "C" fdt_model* fdt_model_create(int arch, int device) {
   if (arch == FDT_ARCH_TRY3 || arch == FDT_ARCH_TRY4 || arch == FDT_ARCH_TRY5) {   // pyramid_mb2_try3.py:216
     m->conf_t = 0.2f;
     m->nms_t = 0.35f;
+  }
+  if (arch == FDT_ARCH_TRY1) {   // pyramid_mobile_try1.py:220: Detect(num_classes, 0, 750, 0.3, 0.3); try2 keeps (0.3, 0.5)
+    m->conf_t = 0.3f;
+    m->nms_t = 0.3f;
   }
   if (arch == FDT_ARCH_FACEBOX) {   // decode_np(conf_thres=0.35), nms_np(threshold=0.5)  encoderl.py:217,308
     m->conf_t = 0.35f;

@@ -28,6 +28,8 @@ int launch_dwconv3(const float* in, const float* w9, const float* bias, int B, i
 // One detection level: raw head map [B][8][H][W] (ch 0-3 loc, 4-7 conf) -> loc [B][P][4] and
 // softmaxed conf [B][P][2] rows [p_off, p_off+H*W): max-in-out (pyramid.py:291-305), NHWC flatten
 // (:298,:306), nn.Softmax(dim=-1) (:332).
+int launch_dwconv(const float* in, const float* wk, const float* bias, int B, int C, int H, int W, int K,
+                  int stride, int pad, int dil, int act, float* out, int Ho, int Wo, hipStream_t st);
 int launch_pad1(const float* in, int BC, int H, int W, float* out, hipStream_t st);
 int launch_head_finalize(const float* head, int B, int H, int W, int level0, int P, int p_off,
                          float* loc, float* conf, float* logits, hipStream_t st);

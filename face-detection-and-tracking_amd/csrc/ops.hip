@@ -125,6 +125,37 @@ __global__ void dwconv3_kernel(const float* __restrict__ in, const float* __rest
   out[(long long)bc * Ho * Wo + (long long)oy * Wo + ox] = acc;
 }
 
+// Generic depthwise KxK (K in 3/5/7, any stride / padding / dilation): the Mobilenetv1 / Mobilenetv2 blocks of
+// pyramid_mobile_try1.py:84-134 (conv1_my is a 7x7/s2/p3 depthwise on the 3 image channels, layer2-4 use 5x5/s2
+// and 3x3 dilation-2 depthwise).  One thread per output element, taps in (dy, dx) order like dwconv3_kernel.
+__global__ void dwconv_generic_kernel(const float* __restrict__ in, const float* __restrict__ wk,
+                                      const float* __restrict__ bias, int C, int H, int W, int K, int stride, int pad,
+                                      int dil, int act, float* __restrict__ out, int Ho, int Wo, long long total) {
+  const long long idx = blockIdx.x * 256ll + threadIdx.x;
+  if (idx >= total) return;
+  const int ox = (int)(idx % Wo);
+  const long long t = idx / Wo;
+  const int oy = (int)(t % Ho);
+  const int bc = (int)(t / Ho);
+  const int c = bc % C;
+  const float* src = in + (long long)bc * H * W;
+  const float* k = wk + (long long)c * K * K;
+  float acc = 0.0f;
+  for (int dy = 0; dy < K; ++dy) {
+    const int y = oy * stride - pad + dy * dil;
+    if (y < 0 || y >= H) continue;
+    for (int dx = 0; dx < K; ++dx) {
+      const int x = ox * stride - pad + dx * dil;
+      if (x < 0 || x >= W) continue;
+      acc = fmaf(src[(long long)y * W + x], k[dy * K + dx], acc);
+    }
+  }
+  if (bias) acc += bias[c];
+  if (act == 1) acc = fmaxf(acc, 0.0f);
+  else if (act == 2) acc = fminf(fmaxf(acc, 0.0f), 6.0f);
+  out[idx] = acc;
+}
+
 // Vector form of the depthwise 3x3 (pyramid_mb2_try3.py:96,113: groups == channels): each thread owns a
 // 4-wide strip of R output rows, walks the (R-1)*S+3 input rows it needs once (16-byte loads plus the one
 // or two halo words) and stores 16 bytes per row.  HBM-bound: in + out bytes, nothing else.  The taps are
@@ -340,6 +371,16 @@ int launch_dwconv3(const float* in, const float* w9, const float* bias, int B, i
   FDT_REQUIRE((long long)B * C <= 65535 && Ho <= 65535, FDT_ERR_ARG, "dwconv: grid too large");
   dim3 grid(ceil_div(Wo, 64), Ho, B * C);
   hipLaunchKernelGGL(dwconv3_kernel, grid, dim3(64), 0, st, in, w9, bias, C, H, W, stride, act, out, Ho, Wo);
+  FDT_LAUNCH_CHECK();
+  return FDT_OK;
+}
+
+int launch_dwconv(const float* in, const float* wk, const float* bias, int B, int C, int H, int W, int K,
+                  int stride, int pad, int dil, int act, float* out, int Ho, int Wo, hipStream_t st) {
+  if (K == 3 && pad == 1 && dil == 1) return launch_dwconv3(in, wk, bias, B, C, H, W, stride, act, out, Ho, Wo, st);
+  const long long total = (long long)B * C * Ho * Wo;
+  hipLaunchKernelGGL(dwconv_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, wk, bias, C,
+                     H, W, K, stride, pad, dil, act, out, Ho, Wo, total);
   FDT_LAUNCH_CHECK();
   return FDT_OK;
 }

@@ -24,6 +24,7 @@ __all__ = ["res50_schema", "try3_schema", "make_state_dict", "make_frames",
 # of tens of thousands.  Found with tools in tests/golden/.
 RES50_CONF_SHIFT = -6.65
 TRY3_CONF_SHIFT = -4.72
+TRY12_CONF_SHIFT = -3.0
 
 
 def _conv(out, name, cin, cout, k, bias, groups=1, kind="conv_w"):
@@ -171,6 +172,70 @@ def try3_schema(variant=3):
     return s
 
 
+# pyramid_mobile_try1.py:160-181 / pyramid_mobile_try2.py:163-189: (inp, oup, dw kernel, stride, t, pad, dil, side_way)
+TRY1_LAYERS = [[(64, 64, 3, 1, 2, 1, 1, 1), (64, 64, 3, 1, 2, 1, 1, 1), (64, 256, 3, 1, 2, 1, 1, 0)],
+               [(256, 64, 5, 2, 2, 2, 1, 0), (64, 512, 3, 1, 2, 2, 2, 0)],
+               [(512, 256, 5, 2, 2, 2, 1, 0), (256, 256, 5, 1, 2, 2, 1, 1), (256, 1024, 3, 1, 2, 2, 2, 0)],
+               [(1024, 256, 5, 2, 2, 2, 1, 0), (256, 2048, 3, 1, 2, 1, 1, 0)]]
+TRY2_LAYERS = [[(64, 64, 3, 1, 4, 1, 1, 1)] * 3,
+               [(64, 64, 3, 2, 4, 1, 1, 0), (64, 64, 3, 1, 4, 1, 1, 1), (64, 64, 3, 1, 4, 1, 1, 1),
+                (64, 128, 3, 1, 4, 1, 1, 0)],
+               [(128, 128, 3, 2, 2, 1, 1, 0)] + [(128, 128, 3, 1, 2, 1, 1, 1)] * 4 + [(128, 256, 3, 1, 2, 1, 1, 0)],
+               [(256, 256, 3, 2, 4, 1, 1, 0), (256, 256, 3, 1, 4, 1, 1, 1), (256, 512, 3, 1, 4, 1, 1, 0)]]
+
+
+def _mbv2(out, p, inp, oup, k, t, side, dw_bias=False):
+    hid = inp * t
+    _conv(out, p + ".conv1", inp, hid, 1, False)
+    _bn(out, p + ".bn1", hid)
+    _conv(out, p + ".conv2", hid, hid, k, dw_bias, groups=hid)
+    _bn(out, p + ".bn2", hid)
+    _conv(out, p + ".conv3", hid, oup, 1, False, kind="conv_w_lin")
+    _bn(out, p + ".bn3", oup, res=bool(side))
+
+
+def _mbv1(out, p, cin, cout, k, dw_bias=False, stem=False, kind="conv_w"):
+    _conv(out, p + ".conv1", cin, cin, k, dw_bias, groups=cin)
+    _bn(out, p + ".bn", cin, stem=stem)
+    _conv(out, p + ".conv2", cin, cout, 1, False, kind=kind)
+
+
+def try12_schema(variant):
+    """(name, shape, kind) in the order of reference pyramid_mobile_try1.py / _try2.py `SFD_mobile.state_dict()`."""
+    s = []
+    _mbv1(s, "conv1_my", 3, 64, 7, stem=True)
+    _bn(s, "bn1", 64)
+    layers = TRY1_LAYERS if variant == 1 else TRY2_LAYERS
+    adj = (256, 512, 1024, 2048)
+    for li, blocks in enumerate(layers, start=1):
+        for bi, (inp, oup, k, st, t, pad, dil, side) in enumerate(blocks):
+            _mbv2(s, "layer%d_my.%d" % (li, bi), inp, oup, k, t, side)
+        if variant == 2:
+            _conv(s, "layer%d_adj" % li, blocks[-1][1], adj[li - 1], 1, False, kind="conv_w_lin")
+    t56 = 2 if variant == 1 else 4
+    _mbv2(s, "layer5_my", 2048 if variant == 1 else 512, 512, 3, t56, 0, dw_bias=(variant == 2))
+    _mbv2(s, "layer6_my", 512, 256, 3, t56, 0, dw_bias=(variant == 2))
+    for n, c in ((3, 256), (4, 512), (5, 1024)):
+        _mbv1(s, "smooth_c%d_my" % n, c, c, 3, dw_bias=(variant == 2), kind="conv_w_lin")
+    _conv(s, "latlayer_fc_my", 2048, 2048, 1, True, groups=4, kind="conv_w_lin")
+    _conv(s, "latlayer_c6_my", 512, 512, 1, True, groups=2, kind="conv_w_lin")
+    _conv(s, "latlayer_c7_my", 256, 256, 1, True, kind="conv_w_lin")
+    _ct(s, "conv3_ct_py", 512, 256)
+    _ct(s, "conv4_ct_py", 1024, 512)
+    _ct(s, "conv5_ct_py", 2048, 1024)
+    for n, c in zip(range(2, 8), (256, 512, 1024, 2048, 512, 256)):
+        _ssh(s, "conv%d_SSH" % n, c, 256)
+    for i in range(6):
+        _conv(s, "face_loc.%d" % i, 512, 4, 3, True, kind="conv_w_head")
+    for i in range(6):
+        _conv(s, "face_conf.%d" % i, 512, 4, 3, True, kind="conv_w_head")
+    for i in range(5):
+        _conv(s, "head_loc.%d" % i, 512, 4, 3, True, kind="conv_w_head")
+    for i in range(5):
+        _conv(s, "head_conf.%d" % i, 512, 2, 3, True, kind="conv_w_head")
+    return s
+
+
 def _draw(name, shape, kind, seed):
     rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
     if kind == "conv_w":
@@ -216,6 +281,8 @@ def make_state_dict(arch="res50", seed=0, conf_shift=None):
         schema, default_shift = try3_schema(), TRY3_CONF_SHIFT
     elif arch in ("try4", "try5"):
         schema, default_shift = try3_schema(int(arch[3])), TRY3_CONF_SHIFT
+    elif arch in ("try1", "try2"):
+        schema, default_shift = try12_schema(int(arch[3])), TRY12_CONF_SHIFT
     else:
         raise ValueError("unknown arch %r" % (arch,))
     if conf_shift is None:

@@ -36,6 +36,8 @@ extern "C" {
 #define FDT_ARCH_FACEBOX 2  /* FACEBOX/networks.py:60-116 FaceBox                          */
 #define FDT_ARCH_TRY4 3     /* pyramid_mb2_try4.py:363-370 build_sfd_mobile (7x7 stem)     */
 #define FDT_ARCH_TRY5 4     /* pyramid_mb2_try5.py:363-370 build_sfd_mobile                */
+#define FDT_ARCH_TRY1 5     /* pyramid_mobile_try1.py:138-369 SFD_mobile (Mobilenetv1/v2 blocks, 6 sources) */
+#define FDT_ARCH_TRY2 6     /* pyramid_mobile_try2.py:141-398 SFD_mobile (+ layerN_adj 1x1 convs)           */
 
 /* frame formats of fdt_model_forward */
 #define FDT_FRAME_U8_HWC_BGR 0 /* raw video frame; mean (104,117,123) is subtracted on device:

@@ -305,7 +305,8 @@ def _ref_net(arch, sd):
         from pyramid import build_sfd
         net = build_sfd("test", 640, 2)
     else:
-        mod = {"try3": "pyramid_mb2_try3", "try4": "pyramid_mb2_try4", "try5": "pyramid_mb2_try5"}[arch]
+        mod = {"try3": "pyramid_mb2_try3", "try4": "pyramid_mb2_try4", "try5": "pyramid_mb2_try5",
+               "try1": "pyramid_mobile_try1", "try2": "pyramid_mobile_try2"}[arch]
         net = importlib.import_module(mod).build_sfd_mobile("test", 640, 2)
     ref_keys = list(net.state_dict().keys())
     assert ref_keys == list(sd.keys()), "synthetic schema != reference state_dict keys"
@@ -405,6 +406,46 @@ def gen_nets45():
     save("nets45", **out)
 
 
+def gen_nets12():
+    """try1 / try2: reference pyramid_mobile_try1.py / _try2.py on seeded weights and frames."""
+    from layers import PriorBoxLayer, Detect
+    from oracle import pyramidbox as opb
+    out, meta = {}, {}
+    for arch in ("try1", "try2"):
+        sd = synth.make_state_dict(arch, seed=0)
+        net = _ref_net(arch, sd)
+        nms_d = 0.3 if arch == "try1" else 0.5
+        for (H, W, seed, ct, nt) in ((64, 64, 37, 0.02, 0.35), (136, 200, 38, 0.02, 0.35), (480, 640, 39, 0.3, nms_d)):
+            frame = synth.make_frames(1, H, W, seed=seed)[0]
+            x = torch.from_numpy(opb.preprocess(frame))
+            net.priorbox = PriorBoxLayer(W, H)
+            net.firstTime = True
+            real = Detect(2, 0, 750, ct, nt)
+            cap = {}
+
+            def spy(loc, conf, priors, _real=real, _cap=cap):
+                _cap["loc"], _cap["conf"], _cap["priors"] = loc.numpy().copy(), conf.numpy().copy(), priors.numpy().copy()
+                return _real(loc, conf, priors)
+            net.detect = spy
+            with torch.no_grad():
+                y = net(x).numpy()
+            key = "%s_%dx%d" % (arch, H, W)
+            n_out = int((y[0, 1, :, 0] > 0).sum())
+            meta[key] = {"H": H, "W": W, "frame_seed": seed, "conf_t": ct, "nms_t": nt, "n_out": n_out,
+                         "n_cand": int((cap["conf"][0, :, 1] > np.float32(ct)).sum()), "P": int(cap["loc"].shape[1]),
+                         "loc_sha": sha(cap["loc"]), "conf_sha": sha(cap["conf"]), "priors_sha": sha(cap["priors"])}
+            out[key + "_out"] = y[0, 1, :max(n_out, 1)]
+            if cap["loc"].shape[1] <= 3000:
+                out[key + "_loc"], out[key + "_conf"] = cap["loc"], cap["conf"]
+            else:
+                sel = np.linspace(0, cap["loc"].shape[1] - 1, 1024).astype(np.int64)
+                out[key + "_sel"] = sel
+                out[key + "_loc_s"], out[key + "_conf_s"] = cap["loc"][0, sel], cap["conf"][0, sel]
+            print(key, meta[key], "conf range", float(cap["conf"][0, :, 1].min()), float(cap["conf"][0, :, 1].max()))
+    out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    save("nets12", **out)
+
+
 # ----------------------------------------------------------------------------- FaceBoxes (real weights)
 def gen_facebox():
     """Reference FaceBox + DataEncoder with the weights that ship in the reference tree
@@ -467,7 +508,7 @@ def gen_facebox():
 
 
 GENS = {"facebox": gen_facebox, "priors": gen_priors, "detect": gen_detect, "iou": gen_iou, "tracker": gen_tracker, "nets": gen_nets,
-        "nets45": gen_nets45}
+        "nets45": gen_nets45, "nets12": gen_nets12}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

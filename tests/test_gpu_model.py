@@ -253,3 +253,59 @@ def test_try45_vs_reference_fixture(try45, synth, size):
     d_iou, d_sc = match_detections(y[0, 1], np.vstack([exp, np.zeros((750 - exp.shape[0], 5), np.float32)]),
                                    m["n_out"])
     assert d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
+
+
+# ------------------------------------------------------------------ try1 / try2
+TRY12_STAGES = ["stem", "c2", "c3", "c4", "c5", "c6", "c7", "c4_ct", "c3_ct", "c2_ct", "c2_smooth", "c3_smooth",
+                "c4_smooth", "src0", "src1", "src2", "src3", "src4", "src5"]
+
+
+@pytest.fixture(scope="module", params=["try1", "try2"])
+def try12(request, synth):
+    arch = request.param
+    net = M("pyramid_mobile_" + arch).build_sfd_mobile('test', 640, 2)
+    sd = synth.make_state_dict(arch, seed=0)
+    net.load_state_dict(sd)
+    yield arch, net, sd
+    net.close()
+
+
+@pytest.mark.parametrize("H,W,seed", [(64, 64, 47), (136, 200, 48)])
+def test_try12_stages_vs_oracle(try12, synth, H, W, seed):
+    """Mobilenetv1/v2 blocks: 7x7/s2 depthwise stem on the raw image channels, 5x5/s2 and dilated 3x3 depthwise,
+    grouped (4 / 2) 1x1 lateral layers run as block-diagonal dense convs -- stage tensors and detections vs oracle."""
+    arch, net, sd = try12
+    frame = synth.make_frames(1, H, W, seed=seed)[0]
+    x = opb.preprocess(frame)
+    net.priorbox = M("layers").PriorBoxLayer(W, H); net.firstTime = True
+    net.detect = M("layers").Detect(2, 0, 750, 0.02, 0.35)
+    y = net(x).numpy()
+    o = opb.try12_forward(sd, x, want=TRY12_STAGES, variant=int(arch[3]))
+    for st in TRY12_STAGES:
+        got = net.get_tensor(st)
+        assert got.shape == o[st].shape, (st, got.shape, o[st].shape)
+        assert rel_rms(got, o[st]) < STAGE_RTOL, (st, rel_rms(got, o[st]))
+    pri = opp.build_priors(opp.PriorBoxLayer(W, H), H, W)
+    assert np.array_equal(net.priors.numpy(), pri)
+    exp = opp.Detect(2, 0, 750, 0.02, 0.35)(o["loc"], o["conf"], pri)
+    n = int((exp[0, 1, :, 0] > 0).sum())
+    d_iou, d_sc = match_detections(y[0, 1], exp[0, 1], n)
+    assert n > 5 and d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
+
+
+@pytest.mark.parametrize("size", ["64x64", "136x200", "480x640"])
+def test_try12_vs_reference_fixture(try12, synth, size):
+    """Final detections vs what reference pyramid_mobile_try1.py / _try2.py produced here (tests/golden/nets12.npz)."""
+    arch, net, _ = try12
+    d, meta = load_npz("nets12")
+    key = "%s_%s" % (arch, size)
+    m = meta[key]
+    H, W = m["H"], m["W"]
+    frame = synth.make_frames(1, H, W, seed=m["frame_seed"])[0]
+    net.priorbox = M("layers").PriorBoxLayer(W, H); net.firstTime = True
+    net.detect = M("layers").Detect(2, 0, 750, m["conf_t"], m["nms_t"])
+    y = net(frame).numpy()
+    exp = d[key + "_out"]
+    d_iou, d_sc = match_detections(y[0, 1], np.vstack([exp, np.zeros((750 - exp.shape[0], 5), np.float32)]),
+                                   m["n_out"])
+    assert d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
