@@ -250,49 +250,60 @@ __global__ __launch_bounds__(64) void mask_kernel(const float4* __restrict__ sbo
                                                   const int* __restrict__ cand, int K, int Kp,
                                                   float overlap, int facebox,
                                                   unsigned long long* __restrict__ mask) {
-  const int bj = blockIdx.x, bi = blockIdx.y, b = blockIdx.z;
-  if (bj < bi) return;
+  // The grid is capped (launch_* below): each workgroup strides over the 64x64 tiles of the upper triangle that
+  // the image's candidate count really has -- FaceBoxes sizes K for all 21824 anchors (342 x 342 tiles per image),
+  // of which a real frame fills a handful.
+  const int b = blockIdx.z;
   const int n = cand[b];
   const int m = n < K ? n : K;
-  if (bi * 64 >= m || bj * 64 >= m) return;
+  const int mt = (m + 63) >> 6;
   __shared__ float4 cb[64];
   __shared__ float ca[64];
   const int lane = threadIdx.x;
   const long long base = (long long)b * Kp;
-  {
-    int j = bj * 64 + lane;
-    if (j < m) {
-      cb[lane] = sbox[base + j];
-      ca[lane] = sarea[base + j];
+  const int nw = Kp >> 6;
+  for (int bi = blockIdx.y; bi < mt; bi += gridDim.y) {
+    const int i = bi * 64 + lane;
+    float4 bi4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ai = 0.f;
+    if (i < m) {
+      bi4 = sbox[base + i];
+      ai = sarea[base + i];
+    }
+    for (int bj = bi + (blockIdx.x + gridDim.x - bi % gridDim.x) % gridDim.x; bj < mt; bj += gridDim.x) {
+      __syncthreads();
+      {
+        int j = bj * 64 + lane;
+        if (j < m) {
+          cb[lane] = sbox[base + j];
+          ca[lane] = sarea[base + j];
+        }
+      }
+      __syncthreads();
+      if (i >= m) continue;
+      unsigned long long word = 0;
+      const int jmax = (m - bj * 64) < 64 ? (m - bj * 64) : 64;
+      for (int c = 0; c < jmax; ++c) {
+        int j = bj * 64 + c;
+        if (j <= i) continue;
+        float4 bb = cb[c];
+        float xx1 = fmaxf(bb.x, bi4.x);
+        float yy1 = fmaxf(bb.y, bi4.y);
+        float xx2 = fminf(bb.z, bi4.z);
+        float yy2 = fminf(bb.w, bi4.w);
+        float w = xx2 - xx1;
+        float h = yy2 - yy1;
+        w = (w < 0.0f) ? 0.0f : w;
+        h = (h < 0.0f) ? 0.0f : h;
+        float inter = w * h;
+        // box_utils.py:336: (area_j - inter) + area_i;  nms_np (encoderl.py:251): (area_i + area_j) - inter
+        float uni = facebox ? ((ai + ca[c]) - inter) : ((ca[c] - inter) + ai);
+        float iou = inter / uni;
+        if (!(iou < overlap)) word |= (1ull << c);
+      }
+      mask[(base + i) * nw + bj] = word;
     }
   }
-  __syncthreads();
-  const int i = bi * 64 + lane;
-  if (i >= m) return;
-  const float4 bi4 = sbox[base + i];
-  const float ai = sarea[base + i];
-  unsigned long long word = 0;
-  const int jmax = (m - bj * 64) < 64 ? (m - bj * 64) : 64;
-  for (int c = 0; c < jmax; ++c) {
-    int j = bj * 64 + c;
-    if (j <= i) continue;
-    float4 bb = cb[c];
-    float xx1 = fmaxf(bb.x, bi4.x);
-    float yy1 = fmaxf(bb.y, bi4.y);
-    float xx2 = fminf(bb.z, bi4.z);
-    float yy2 = fminf(bb.w, bi4.w);
-    float w = xx2 - xx1;
-    float h = yy2 - yy1;
-    w = (w < 0.0f) ? 0.0f : w;
-    h = (h < 0.0f) ? 0.0f : h;
-    float inter = w * h;
-    // box_utils.py:336: (area_j - inter) + area_i;  nms_np (encoderl.py:251): (area_i + area_j) - inter
-    float uni = facebox ? ((ai + ca[c]) - inter) : ((ca[c] - inter) + ai);
-    float iou = inter / uni;
-    if (!(iou < overlap)) word |= (1ull << c);
-  }
-  const int nw = Kp >> 6;
-  mask[(base + i) * nw + bj] = word;
 }
 
 // Greedy scan over the bit-matrix, one wave per image.  Per 64-row chunk: resolve the chunk serially
@@ -485,7 +496,8 @@ static int run_sorted_nms(const DetectPlan& pl, char* ws, const float* loc, cons
                      score_img_stride, sbox, sarea, sscore, sidx);
   FDT_LAUNCH_CHECK();
   int nw = pl.Kp / 64;
-  hipLaunchKernelGGL(mask_kernel, dim3(nw, nw, pl.B), dim3(64), 0, st, sbox, sarea, cand, pl.K,
+  const int gcap = nw < 80 ? nw : 80;   // 80 x 80 tiles = 5120 candidates in one pass; more are strided over
+  hipLaunchKernelGGL(mask_kernel, dim3(gcap, gcap, pl.B), dim3(64), 0, st, sbox, sarea, cand, pl.K,
                      pl.Kp, overlap, facebox, mask);
   FDT_LAUNCH_CHECK();
   hipLaunchKernelGGL(scan_kernel, dim3(pl.B), dim3(64), (size_t)nw * 8, st, mask, sbox, sscore,
