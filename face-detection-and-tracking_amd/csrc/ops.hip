@@ -97,6 +97,98 @@ __global__ void maxpool3_kernel(const float* __restrict__ in, int C, int H, int 
   out[((long long)b * Cout + co) * Ho * Wo + (long long)oy * Wo + ox] = m;
 }
 
+// Vector form of max_pool2d(kernel 3, padding 1, stride S) with the optional CReLU in front of it
+// (FACEBOX/networks.py:91-93: cat([x, -x]) -> relu -> max_pool).  Same strip layout as dwconv3_vec_kernel; one
+// read of the input plane yields both CReLU planes: max relu(x) = relu(max x), max relu(-x) = relu(-min x).
+template <int S>
+__global__ __launch_bounds__(256) void maxpool3_vec_kernel(const float* __restrict__ in, int C, int H, int W, int crelu,
+                                                           float* __restrict__ out, int Ho, int Wo, long long total) {
+  constexpr int R = (S == 1) ? 4 : 2;
+  constexpr int NIR = (R - 1) * S + 3;
+  constexpr int NV = 3 * S + 3;
+  const long long idx0 = blockIdx.x * 256ll + threadIdx.x;
+  const bool live = idx0 < total;
+  const long long idx = live ? idx0 : total - 1;
+  const int lane = threadIdx.x & 63;
+  const int W4 = Wo >> 2, RG = (Ho + R - 1) / R;
+  const int c4 = (int)(idx % W4);
+  const long long t = idx / W4;
+  const int rg = (int)(t % RG);
+  const int bc = (int)(t / RG);
+  const int b = bc / C, ci = bc - b * C;
+  const float* src = in + (long long)bc * H * W;
+  const int ox = c4 * 4, oy0 = rg * R, ix0 = ox * S;
+  const bool left_pad = c4 == 0, right_pad = c4 == W4 - 1;
+  float mx[R][4], mn[R][4];
+#pragma unroll
+  for (int o = 0; o < R; ++o)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mx[o][j] = -INFINITY; mn[o][j] = INFINITY; }
+  float4 A[NIR], Bq[NIR];
+#pragma unroll
+  for (int r = 0; r < NIR; ++r) {
+    const int y = oy0 * S - 1 + r;
+    const float* row = src + (long long)((y >= 0 && y < H) ? y : 0) * W;
+    A[r] = *reinterpret_cast<const float4*>(row + ix0);
+    Bq[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (S == 2) Bq[r] = *reinterpret_cast<const float4*>(row + ix0 + 4);
+  }
+#pragma unroll
+  for (int r = 0; r < NIR; ++r) {
+    const int y = oy0 * S - 1 + r;
+    const bool inside = y >= 0 && y < H;
+    const float* row = src + (long long)(inside ? y : 0) * W;
+    const float4 a = A[r], bq = Bq[r];
+    float lft = __shfl_up(S == 1 ? a.w : bq.w, 1, 64);
+    if (lane == 0 && !left_pad) lft = row[ix0 - 1];
+    float v[NV];
+    bool ok[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) ok[i] = inside;
+    v[0] = lft;
+    ok[0] = inside && !left_pad;
+    v[1] = a.x; v[2] = a.y; v[3] = a.z; v[4] = a.w;
+    if (S == 1) {
+      float rgt = __shfl_down(a.x, 1, 64);
+      if (lane == 63 && !right_pad) rgt = row[ix0 + 4];
+      v[5] = rgt;
+      ok[5] = inside && !right_pad;
+    } else {
+      v[5] = bq.x; v[6] = bq.y; v[7] = bq.z; v[NV - 1] = bq.w;
+    }
+#pragma unroll
+    for (int o = 0; o < R; ++o) {
+      const int dy = r - o * S;
+      if (dy < 0 || dy > 2) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = j * S + dx;
+          mx[o][j] = ok[q] ? fmaxf(mx[o][j], v[q]) : mx[o][j];
+          mn[o][j] = ok[q] ? fminf(mn[o][j], v[q]) : mn[o][j];
+        }
+    }
+  }
+  if (!live) return;
+  const int Cout = crelu ? 2 * C : C;
+#pragma unroll
+  for (int o = 0; o < R; ++o) {
+    const int oy = oy0 + o;
+    if (oy >= Ho) break;
+    const long long off = (long long)oy * Wo + ox;
+    float* dst = out + ((long long)b * Cout + ci) * Ho * Wo + off;
+    if (crelu) {
+      *reinterpret_cast<float4*>(dst) = make_float4(fmaxf(mx[o][0], 0.f), fmaxf(mx[o][1], 0.f), fmaxf(mx[o][2], 0.f),
+                                                    fmaxf(mx[o][3], 0.f));
+      *reinterpret_cast<float4*>(dst + (long long)C * Ho * Wo) =
+          make_float4(fmaxf(-mn[o][0], 0.f), fmaxf(-mn[o][1], 0.f), fmaxf(-mn[o][2], 0.f), fmaxf(-mn[o][3], 0.f));
+    } else {
+      *reinterpret_cast<float4*>(dst) = make_float4(mx[o][0], mx[o][1], mx[o][2], mx[o][3]);
+    }
+  }
+}
+
 __global__ void dwconv3_kernel(const float* __restrict__ in, const float* __restrict__ w9,
                                const float* __restrict__ bias, int C, int H, int W, int stride, int act,
                                float* __restrict__ out, int Ho, int Wo) {
@@ -345,6 +437,17 @@ int launch_resize_preprocess(const unsigned char* frames, int B, int SH, int SW,
 
 int launch_maxpool3(const float* in, int B, int C, int H, int W, int stride, int crelu, float* out,
                     int Ho, int Wo, hipStream_t st) {
+  if (Wo % 4 == 0 && W == Wo * stride && (stride == 1 || stride == 2)) {
+    const int R = stride == 1 ? 4 : 2;
+    const long long total = (long long)B * C * ceil_div(Ho, R) * (Wo / 4);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (stride == 1)
+      hipLaunchKernelGGL(maxpool3_vec_kernel<1>, dim3(blocks), dim3(256), 0, st, in, C, H, W, crelu, out, Ho, Wo, total);
+    else
+      hipLaunchKernelGGL(maxpool3_vec_kernel<2>, dim3(blocks), dim3(256), 0, st, in, C, H, W, crelu, out, Ho, Wo, total);
+    FDT_LAUNCH_CHECK();
+    return FDT_OK;
+  }
   const int Cout = crelu ? 2 * C : C;
   FDT_REQUIRE((long long)B * Cout <= 65535 && Ho <= 65535, FDT_ERR_ARG, "maxpool: grid too large");
   dim3 grid(ceil_div(Wo, 64), Ho, B * Cout);
