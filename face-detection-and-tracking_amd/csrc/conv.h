@@ -89,7 +89,39 @@ struct ConvArgs {
   int act;
   int ksplit;             // >= 1: split the input-channel reduction over this many workgroups
   float* ws;              // split-K workspace, B*ksplit*Cout*Hout*Wout floats (ksplit > 1)
+  // workgroup -> (spatial tile, output-channel tile) map (FDT_BLOCK_MAP below): map_mode is the caller's choice
+  // (CONV_MAP_*), n_sp / n_ct are filled in by launch_conv
+  int map_mode, n_sp, n_ct;
 };
+
+enum { CONV_MAP_ROWS = 0, CONV_MAP_XCD_SPATIAL = 1, CONV_MAP_XCD_CHANNEL = 2 };
+
+// Workgroup map.  CONV_MAP_ROWS: id = channel_tile * n_sp + spatial_tile (all spatial tiles of one channel tile
+// first; consecutive workgroups land on different XCDs).  The two XCD-aware maps use that workgroups are dealt
+// round-robin over the 8 XCDs (each with its own 4 MB L2): lane8 = id % 8 (which workgroups share an XCD), q = id / 8,
+//   XCD_SPATIAL (activations are the bigger operand): the XCD owns the spatial tiles s = 8*(q / n_ct) + lane8 and walks
+//           the output-channel tiles of one spatial tile back to back -> the input patch is fetched into L2 once;
+//   XCD_CHANNEL (weights are the bigger operand):    the XCD owns the channel tiles n = 8*(q / n_sp) + lane8 and walks
+//           the spatial tiles -> every XCD streams only its 1/8 of the weights.
+// Workgroups decoded outside the tile grid exit at once.  Pure speed: nothing depends on the placement.  Measured on
+// the Res50 graph the XCD-aware maps cut the conv kernels' HBM fetches by a quarter but are not faster on every
+// layer (the MFMA-bound ones lose a little), so the map is a per-layer choice of the autotuner.
+#define FDT_BLOCK_MAP(a_, s_, n_)                                               \
+  int s_, n_;                                                                   \
+  {                                                                             \
+    const int id_ = blockIdx.x, l8_ = id_ & 7, q_ = id_ >> 3;                   \
+    if ((a_).map_mode == CONV_MAP_XCD_SPATIAL) {                                \
+      n_ = q_ % (a_).n_ct;                                                      \
+      s_ = (q_ / (a_).n_ct) * 8 + l8_;                                          \
+    } else if ((a_).map_mode == CONV_MAP_XCD_CHANNEL) {                         \
+      s_ = q_ % (a_).n_sp;                                                      \
+      n_ = (q_ / (a_).n_sp) * 8 + l8_;                                          \
+    } else {                                                                    \
+      s_ = id_ % (a_).n_sp;                                                     \
+      n_ = id_ / (a_).n_sp;                                                     \
+    }                                                                           \
+    if (s_ >= (a_).n_sp || n_ >= (a_).n_ct) return;                             \
+  }
 
 // Workspace floats a split-K launch needs.
 long long conv_ws_floats(const ConvArgs& a);

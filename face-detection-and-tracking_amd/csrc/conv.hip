@@ -206,7 +206,8 @@ double conv_flops(const ConvArgs& a, ConvKind kind) {
   return 2.0 * a.B * (double)a.Hout * a.Wout * a.Cout * a.Cin * g.kh * g.kw;
 }
 
-int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a, hipStream_t st) {
+int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t st) {
+  ConvArgs a = a_in;
   KernelEntry& ke = table().e[kind][tile];
   FDT_REQUIRE(ke.fn, FDT_ERR_ARG, "launch_conv: kernel (kind %d, tile %d) not instantiated", kind, tile);
   const ConvGeom g = conv_geom(kind);
@@ -237,8 +238,15 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a, hipStream_t st)
   FDT_REQUIRE(!(a.ksplit > 1 || a.up) || a.ws, FDT_ERR_ARG, "launch_conv: workspace required");
   FDT_REQUIRE(!a.ws || a.ksplit > 1 || a.up, FDT_ERR_ARG, "launch_conv: unexpected workspace");
   const int tiles = ceil_div(a.Hout, tile_th(tile)) * ceil_div(a.Wout, tile_tw(tile));
-  dim3 grid(tiles, ceil_div(a.Cout, tile_bn(tile)), a.B * a.ksplit);
-  FDT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, FDT_ERR_ARG, "launch_conv: grid too large");
+  const int n_ct = ceil_div(a.Cout, tile_bn(tile));
+  a.n_sp = tiles;
+  a.n_ct = n_ct;
+  FDT_REQUIRE(a.map_mode >= CONV_MAP_ROWS && a.map_mode <= CONV_MAP_XCD_CHANNEL, FDT_ERR_ARG, "launch_conv: bad map mode");
+  const long long gx = a.map_mode == CONV_MAP_XCD_SPATIAL   ? (long long)ceil_div(tiles, 8) * 8 * n_ct
+                       : a.map_mode == CONV_MAP_XCD_CHANNEL ? (long long)ceil_div(n_ct, 8) * 8 * tiles
+                                                            : (long long)tiles * n_ct;
+  FDT_REQUIRE(gx <= 0x7fffffffll && (long long)a.B * a.ksplit <= 65535, FDT_ERR_ARG, "launch_conv: grid too large");
+  dim3 grid((unsigned)gx, 1, a.B * a.ksplit);
   hipLaunchKernelGGL(ke.fn, grid, dim3(ke.threads), ke.lds, st, a);
   FDT_LAUNCH_CHECK();
   if (a.ws) {
@@ -328,6 +336,7 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
     a.up = dup.as<float>(); a.up_h = up_h; a.up_w = up_w;
   }
   if (a.ksplit > 1 || a.up) { FDT_TRY(dws.alloc((size_t)conv_ws_floats(a) * 4)); a.ws = dws.as<float>(); }
+  if (const char* mm = getenv("FDT_CONV_MAP")) a.map_mode = atoi(mm);   // test hook: workgroup map (conv.h CONV_MAP_*)
   FDT_TRY(launch_conv((ConvKind)kind, (ConvTile)tile, a, 0));
   FDT_HIP(hipMemcpy(out, dout.p, n_out * 4, hipMemcpyDeviceToHost));
   return FDT_OK;

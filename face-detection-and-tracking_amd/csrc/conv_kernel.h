@@ -82,10 +82,9 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
   const int half = lane >> 5, l31 = lane & 31;
 
   const int tiles_x = (a.Wout + T::TW - 1) / T::TW;
-  const int tile_id = blockIdx.x;
+  FDT_BLOCK_MAP(a, tile_id, n_tile);
   const int oy0 = (tile_id / tiles_x) * T::TH;
   const int ox0 = (tile_id % tiles_x) * T::TW;
-  const int n_tile = blockIdx.y;
   const int b = blockIdx.z / a.ksplit;
   const int ks = blockIdx.z - b * a.ksplit;
 

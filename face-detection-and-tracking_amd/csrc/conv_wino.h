@@ -79,9 +79,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
 
   constexpr int TH = 2 * T::TTH, TW = 2 * T::TTW;          // output pixels per workgroup
   const int tiles_x = (a.Wout + TW - 1) / TW;
-  const int oy0 = (blockIdx.x / tiles_x) * TH;
-  const int ox0 = (blockIdx.x % tiles_x) * TW;
-  const int n_tile = blockIdx.y;
+  FDT_BLOCK_MAP(a, sp_tile, n_tile);
+  const int oy0 = (sp_tile / tiles_x) * TH;
+  const int ox0 = (sp_tile % tiles_x) * TW;
   const int b = blockIdx.z / a.ksplit;
   const int ks = blockIdx.z - b * a.ksplit;
 
@@ -254,9 +254,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
 
   constexpr int TH = 2 * T::TTH, TW = 2 * T::TTW;
   const int tiles_x = (a.Wout + TW - 1) / TW;
-  const int oy0 = (blockIdx.x / tiles_x) * TH;
-  const int ox0 = (blockIdx.x % tiles_x) * TW;
-  const int n_tile = blockIdx.y;
+  FDT_BLOCK_MAP(a, sp_tile, n_tile);
+  const int oy0 = (sp_tile / tiles_x) * TH;
+  const int ox0 = (sp_tile % tiles_x) * TW;
   const int b = blockIdx.z / a.ksplit;
   const int ks = blockIdx.z - b * a.ksplit;
 

@@ -86,7 +86,7 @@ struct fdt_model {
     int Cout = 0, Cin = 0;
   };
   std::map<std::string, HostW> host_w;                      // per conv layer, kept for re-tiling
-  struct Hint { int kind, tile, split; };
+  struct Hint { int kind, tile, split, map; };
   std::map<std::string, Hint> hints;                        // autotuned (kernel class, tile, split) per layer
   int hB = 0, hH = 0, hW = 0;                               // shape the hints were tuned for
   std::vector<void*> plan_allocs;
@@ -303,7 +303,7 @@ struct Builder {
     op.type = OP_CONV;
     op.name = name;
     op.kind = kind;
-    int ksplit = 1;
+    int ksplit = 1, map_mode = CONV_MAP_ROWS;
     auto hint = m->hints.find(name);
     if (hint != m->hints.end() && m->hB == B && m->hH == m->tensors[0].H && m->hW == m->tensors[0].W &&
         conv_base_kind((ConvKind)hint->second.kind) == kind &&
@@ -312,12 +312,14 @@ struct Builder {
       op.kind = kind;
       op.tile = (ConvTile)hint->second.tile;
       ksplit = std::max(1, std::min(hint->second.split, ceil_div(in.C, conv_geom(kind).kc)));
+      map_mode = hint->second.map;
     } else {
       choose(kind, Ctot, in.C, Ho, Wo, B, o.up_t >= 0, op.tile, ksplit);
     }
     ConvArgs& a = op.ca;
     memset(&a, 0, sizeof(a));
     a.ksplit = ksplit;
+    a.map_mode = map_mode;
     a.B = B;
     a.Cin = in.C;
     a.Hin = in.H;
@@ -1527,6 +1529,32 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
       c.ms = best_ms;
       if (best_ms < best.ms) best = c;
     }
+    // the workgroup map of the winner (conv.h: rows / XCD-spatial / XCD-channel)
+    int best_map = CONV_MAP_ROWS;
+    if (rc == FDT_OK) {
+      DevW dwb;
+      rc = Builder::device_weights(m, op.name, (ConvKind)best.kind, (ConvTile)best.tile, dwb);
+      ConvArgs a = op.ca;
+      a.w = dwb.w;
+      a.bias = dwb.bias;
+      a.ksplit = best.split;
+      a.ws = (best.split > 1 || a.up) ? tmp_ws : nullptr;
+      float map_ms[3] = {1e30f, 1e30f, 1e30f};
+      for (int mm = 0; mm < 3 && rc == FDT_OK; ++mm) {
+        a.map_mode = mm;
+        for (int it = 0; it < iters + 2 && rc == FDT_OK; ++it) {
+          (void)hipEventRecord(e0, st);
+          rc = launch_conv((ConvKind)best.kind, (ConvTile)best.tile, a, st);
+          (void)hipEventRecord(e1, st);
+          if (hipEventSynchronize(e1) != hipSuccess) { set_error("autotune: kernel failed"); rc = FDT_ERR_HIP; }
+          float ms = 0;
+          (void)hipEventElapsedTime(&ms, e0, e1);
+          if (it > 0) map_ms[mm] = std::min(map_ms[mm], ms);
+        }
+      }
+      for (int mm = 1; mm < 3; ++mm)
+        if (map_ms[mm] < 0.98f * map_ms[best_map]) best_map = mm;   // only a clear win leaves the default
+    }
     if (tmp_ws) (void)hipFree(tmp_ws);
     if (rc != FDT_OK) break;
     DevW dw;
@@ -1535,10 +1563,11 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
     op.kind = (ConvKind)best.kind;
     op.tile = (ConvTile)best.tile;
     op.ca.ksplit = best.split;
+    op.ca.map_mode = best_map;
     op.ca.w = dw.w;
     op.ca.bias = dw.bias;
     op.needs_ws = best.split > 1 || op.ca.up;
-    m->hints[op.name] = {best.kind, best.tile, best.split};
+    m->hints[op.name] = {best.kind, best.tile, best.split, best_map};
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
@@ -1571,7 +1600,7 @@ extern "C" int fdt_model_export_plan(fdt_model* m, char* buf, int buflen, int* n
   for (auto& op : m->ops)
     if (op.type == OP_CONV)
       out += op.name + " " + std::to_string((int)op.kind) + " " + std::to_string((int)op.tile) + " " +
-             std::to_string(op.ca.ksplit) + "\n";
+             std::to_string(op.ca.ksplit) + " " + std::to_string(op.ca.map_mode) + "\n";
   *needed = (int)out.size() + 1;
   if (buf && buflen >= *needed) memcpy(buf, out.c_str(), out.size() + 1);
   return FDT_OK;
@@ -1588,13 +1617,15 @@ extern "C" int fdt_model_import_plan(fdt_model* m, const char* text) {
     p = e ? e + 1 : p + line.size();
     if (line.empty()) continue;
     char name[256];
-    int a = 0, b = 0, c = 0;
+    int a = 0, b = 0, c = 0, d = 0, nf = 0;
     if (sscanf(line.c_str(), "shape %d %d %d", &a, &b, &c) == 3) {
       B = a; H = b; W = c;
-    } else if (sscanf(line.c_str(), "%255s %d %d %d", name, &a, &b, &c) == 4) {
-      FDT_REQUIRE(a >= 0 && a < CONV_KIND_COUNT && b >= 0 && b < CONV_TILE_COUNT && c >= 1 && c <= 4096,
+    } else if ((nf = sscanf(line.c_str(), "%255s %d %d %d %d", name, &a, &b, &c, &d)) >= 4) {
+      if (nf == 4) d = CONV_MAP_ROWS;      // plans written before the workgroup map became a choice
+      FDT_REQUIRE(a >= 0 && a < CONV_KIND_COUNT && b >= 0 && b < CONV_TILE_COUNT && c >= 1 && c <= 4096 &&
+                      d >= CONV_MAP_ROWS && d <= CONV_MAP_XCD_CHANNEL,
                   FDT_ERR_ARG, "fdt_model_import_plan: bad entry '%s'", line.c_str());
-      hints[name] = {a, b, c};
+      hints[name] = {a, b, c, d};
     } else {
       set_error("fdt_model_import_plan: cannot parse '%s'", line.c_str());
       return FDT_ERR_ARG;

@@ -81,6 +81,25 @@ def test_every_tile_variant_matches_torch(kind):
     assert tested >= 4
 
 
+@pytest.mark.parametrize("mode", [1, 2])      # conv.h: CONV_MAP_XCD_SPATIAL / CONV_MAP_XCD_CHANNEL
+def test_xcd_aware_workgroup_maps(mode, monkeypatch):
+    """The XCD-aware workgroup -> tile maps (incl. the padding workgroups that exit at once) compute the same
+    convolution as the row-major map."""
+    monkeypatch.setenv("FDT_CONV_MAP", str(mode))
+    rng = np.random.default_rng(mode)
+    for (k, s, p, d, tiles) in ((1, 1, 0, 1, (0, 3, 9, 25)), (3, 1, 1, 1, (1, 3, 24)), (3, 1, 2, 2, (1, 24)), (3, 2, 1, 1, (1,))):
+        for (Cin, H, W, Cout) in ((24, 52, 76, 200), (17, 9, 11, 40)):      # 28 / 1 spatial tiles; 7 / 2 channel tiles
+            x = rng.standard_normal((2, Cin, H, W)).astype(np.float32)
+            w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+            b = rng.standard_normal(Cout).astype(np.float32)
+            exp = reference(x, w, b, k, s, p, d, act=1)
+            for tile in tiles:
+                for split in (1, 2):
+                    rc, got = run_conv(x, w, b, k, s, p, d, act=1, tile=tile, split=split)
+                    assert rc == 0, lib().lib().fdt_last_error()
+                    assert rel_err(got, exp) < 3e-5, (mode, k, tile, split, rel_err(got, exp))
+
+
 @pytest.mark.parametrize("W", [64, 50])       # vector and scalar epilogue
 @pytest.mark.parametrize("tile", [0, 3, 5, 7, 11])
 def test_fused_epilogues(tile, W):
