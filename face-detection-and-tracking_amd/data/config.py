@@ -1,11 +1,3 @@
-"""Only `variance` is read on the inference path (reference data/config.py:4-22,
-layers/functions/detection.py:31)."""
-face = {
-    'feature_maps': [160, 80, 40, 20, 10, 5],
-    'min_dim': 640,
-    'steps': [4, 8, 16, 32, 64, 128],
-    'min_sizes': [16, 32, 64, 128, 256, 512],
-    'variance': [0.1, 0.2],
-    'clip': False,
-    'name': 'v2',
-}
+"""`from data import face` (reference pyramid.py:6).  On the inference path only the box-coding variances are read
+(layers/functions/detection.py:31 -> decode()); the anchor geometry lives in PriorBoxLayer, not in this table."""
+face = dict(name='v2', min_dim=640, variance=[0.1, 0.2], clip=False)

@@ -1,4 +1,6 @@
-from .detection import Detect
-from .prior_box import PriorBoxLayer
+"""`from layers.functions import Detect, PriorBoxLayer` of the reference (layers/functions/__init__.py), backed by the
+HIP post-processing ops (fdt_detect / fdt_priorbox in include/fdt.h)."""
+from .prior_box import PriorBoxLayer  # noqa: F401
+from .detection import Detect  # noqa: F401
 
-__all__ = ['Detect', 'PriorBoxLayer']
+__all__ = ("PriorBoxLayer", "Detect")
