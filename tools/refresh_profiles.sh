@@ -13,6 +13,8 @@ B="python bench.py --steps 48 --warmup 8 --cpu-frames 0"
 timeout -k 10 300 python bench.py --steps 64 --warmup 8 > $OUT/bench_line_res50_1024.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt --output-format csv -- $B > $OUT/bench_under_rocprof.log 2>&1
 cp /tmp/raw/kt_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv
+# 48 timed + 8 warm-up + 5 profiled frames in that command
+python tools/rocprof_conv_summary.py $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv 61 $OUT/bench_line_res50_1024.json > $OUT/rocprof_vs_bench.txt
 P="python bench.py --steps 8 --warmup 2 --cpu-frames 0 --inflight 1 --profile-frames 1"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/raw -o pmc_$C --output-format csv -- $P > /tmp/raw/pmc_$C.log 2>&1

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Cross-check of bench.py's roofline figures against a rocprofv3 --kernel-trace --stats run of the same command:
+sums the conv kernels (all conv_kernel / conv_wino* instantiations) and the split-K reduce passes that finish them.
+    python tools/rocprof_conv_summary.py KERNEL_STATS.csv FRAMES [BENCH_LINE.json]"""
+import csv
+import json
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+frames = float(sys.argv[2])
+conv = [r for r in rows if "conv_kernel" in r["Name"] or "conv_wino" in r["Name"]]
+red = [r for r in rows if "splitk_reduce" in r["Name"]]
+tot = lambda rs: sum(float(r["TotalDurationNs"]) for r in rs)
+calls = lambda rs: sum(int(r["Calls"]) for r in rs)
+print("frames in the run                      : %g" % frames)
+print("conv kernel launches per frame         : %.1f  (%d template instantiations)" % (calls(conv) / frames, len(conv)))
+print("conv kernels, ms per frame             : %.3f  (avg %.2f us per launch)" % (tot(conv) / frames / 1e6,
+                                                                              tot(conv) / calls(conv) / 1e3))
+print("split-K / upsample-add reduce, ms/frame: %.3f  (%.1f launches per frame)" % (tot(red) / frames / 1e6,
+                                                                                   calls(red) / frames))
+print("conv + reduce, ms per frame            : %.3f" % ((tot(conv) + tot(red)) / frames / 1e6))
+if len(sys.argv) > 3:
+    d = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+    r = d["roofline"]
+    print("bench.py (HIP events, same ops)        : %.3f ms per frame, %.2f us per op, %.2f TFLOP/s algorithmic" %
+          (r["conv_ms_per_frame"], r["avg_launch_us"], r["achieved"]))
+    print("algorithmic GFLOP per frame            : %.3f -> %.2f TFLOP/s from the rocprof durations" %
+          (r["algorithmic_gflop_per_frame"], r["algorithmic_gflop_per_frame"] / ((tot(conv) + tot(red)) / frames / 1e6)))
