@@ -1552,8 +1552,10 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
           if (it > 0) map_ms[mm] = std::min(map_ms[mm], ms);
         }
       }
+      // an XCD-aware map that is no slower (within timer noise) is preferred: it re-fetches less from HBM
       for (int mm = 1; mm < 3; ++mm)
-        if (map_ms[mm] < 0.98f * map_ms[best_map]) best_map = mm;   // only a clear win leaves the default
+        if (map_ms[mm] <= 1.005f * map_ms[CONV_MAP_ROWS] && map_ms[mm] < map_ms[best_map == CONV_MAP_ROWS ? mm : best_map] * 1.0001f)
+          best_map = mm;
     }
     if (tmp_ws) (void)hipFree(tmp_ws);
     if (rc != FDT_OK) break;

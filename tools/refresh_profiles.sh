@@ -20,7 +20,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/raw -o pmc_$C --output-format csv -- $P > /tmp/raw/pmc_$C.log 2>&1
   python tools/summarize_pmc.py /tmp/raw/pmc_${C}_counter_collection.csv $OUT/pmc_${C}_by_kernel.csv
 done
-python tools/traffic_json.py $OUT/pmc_FETCH_SIZE_by_kernel.csv $OUT/pmc_WRITE_SIZE_by_kernel.csv 105 $OUT/conv_hbm_traffic.json
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/raw -o calib --output-format csv -- python tools/one_conv.py 0 0 1 256 256 256 128 > /tmp/raw/calib.log 2>&1
+python tools/summarize_pmc.py /tmp/raw/calib_counter_collection.csv $OUT/pmc_FETCH_SIZE_calibration_1x1_67MB.csv
+python tools/traffic_json.py $OUT/pmc_FETCH_SIZE_by_kernel.csv $OUT/pmc_WRITE_SIZE_by_kernel.csv 105 $OUT/conv_hbm_traffic.json $OUT/pmc_FETCH_SIZE_calibration_1x1_67MB.csv
 timeout -k 10 300 python tools/profile_layers.py > $OUT/per_layer_hip_events_res50_1024.txt
 timeout -k 10 300 python bench.py --steps 64 --warmup 8 --height 480 --width 640 --cpu-frames 2 > $OUT/bench_line_res50_640x480.json
 timeout -k 10 300 python bench.py --steps 32 --warmup 4 --height 1080 --width 1920 --cpu-frames 1 > $OUT/bench_line_res50_1920x1080.json

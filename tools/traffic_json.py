@@ -20,6 +20,13 @@ nf, fetch = conv_sum(sys.argv[1])
 nw, write = conv_sum(sys.argv[2])
 assert nf == nw, (nf, nw)
 per_frame = int(sys.argv[3])
+# optional: FETCH_SIZE summary of tools/one_conv.py 0 0 1 256 256 256 128 (a 1x1 conv that reads its 67.1 MB input
+# exactly once with the same 16-B-per-lane LDS-DMA the detector uses) -> what the counter reports per real byte
+calib = None
+if len(sys.argv) > 5:
+    for r in csv.DictReader(open(sys.argv[5])):
+        if "conv_kernel" in r["Kernel_Name"]:
+            calib = float(r["Mean"]) * 1024.0 / (256 * 256 * 256 * 4 + 128 * 256 * 4)
 frames = nf / per_frame
 total = (fetch * 2.0 + write) * 1024.0
 json.dump({
@@ -27,7 +34,13 @@ json.dump({
     "dispatches": nf, "frames": frames,
     "FETCH_SIZE_kb_sum": fetch, "WRITE_SIZE_kb_sum": write, "fetch_correction": 2.0,
     "hbm_bytes_per_launch": total / nf, "hbm_bytes_per_frame": total / frames,
+    "calibration_counter_per_byte_16B_lds_dma": calib,
+    "hbm_bytes_per_launch_calibrated": None if calib is None else (fetch / calib + write) * 1024.0 / nf,
     "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 8 --warmup 2 "
             "--cpu-frames 0 --inflight 1 --profile-frames 1` (committed tuned plan, no autotune dispatches); FETCH_SIZE "
-            "doubled per MI355X_MICROARCH.md (the dword LDS-DMA pattern is not separately calibrated)",
+            "doubled per MI355X_MICROARCH.md's rule for 16-B-per-lane streaming reads.  Calibrated on this code's own "
+            "pattern (a 1x1 conv that reads a 67.1 MB input once through global_load_lds_dwordx4) the counter reports "
+            "calibration_counter_per_byte_16B_lds_dma per real byte, i.e. close to 1, not 1/2: the *_calibrated figure "
+            "divides by that instead of doubling and is the likelier truth; the doubled one is the conservative upper "
+            "bound quoted as roofline.traffic",
 }, open(sys.argv[4], "w"), indent=1)
