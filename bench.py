@@ -213,14 +213,19 @@ def main():
         achieved = flops / (cms * 1e-3) / 1e12
         # HBM bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
         # command (PMC cannot be read from inside the process); the committed summary is quoted here.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_cal = None, None, None
         tj = os.path.join(ROOT, "profiles", "r01", "conv_hbm_traffic.json")
         if args.arch == "res50" and H == 1024 and os.path.exists(tj):
             tdata = json.load(open(tj))
             traffic = round(tdata["hbm_bytes_per_launch"])
+            if tdata.get("hbm_bytes_per_launch_calibrated"):
+                traffic_cal = round(tdata["hbm_bytes_per_launch_calibrated"])
             traffic_src = "profiles/r01/conv_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_calibrated": traffic_cal,     # FETCH_SIZE divided by its measured per-byte reading on this
+                                                       # code's LDS-DMA pattern instead of doubled (see the JSON note)
+                "algorithmic_bytes_per_launch": round((3.52e9 + 0.2688e9) / 105) if args.arch == "res50" and H == 1024 and W == 1024 else None,
                 "kernel": "conv_kernel (f32 MFMA implicit GEMM)", "launches_per_frame": n_conv,
                 "avg_launch_us": round(cms * 1e3 / n_conv, 2), "conv_ms_per_frame": round(cms / B, 3),
                 "other_ms_per_frame": round(float(np.mean(other_ms)) / B, 3),
