@@ -55,6 +55,13 @@ def test_argument_errors_do_not_need_a_gpu():
     cnt = ctypes.c_int(-1)
     assert L.fdt_nms(None, None, 0, 0.5, 10, lib.ptr(np.zeros(1, np.int64)), ctypes.byref(cnt)) == 0
     assert cnt.value == 0            # empty input: reference box_utils.py:290-291 returns (keep, 0)
+    # tracker: one frame's detections and association state live in LDS -> max_dets is bounded (include/fdt.h)
+    assert not L.fdt_tracker_create(0.4, 0.6, 5, 4096, 64)
+    assert b"does not fit the LDS-resident frame state" in L.fdt_last_error()
+    assert not L.fdt_tracker_create(0.4, 0.6, 5, 0, 64)
+    # unknown architecture ids are refused before any device work
+    assert not L.fdt_model_create(99, 0)
+    assert b"unknown arch" in L.fdt_last_error()
 
 
 def test_fails_loudly_without_gpu_or_library(monkeypatch):
