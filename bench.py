@@ -32,6 +32,68 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 
 
+def facebox_main(args):
+    """Config 5 of BASELINE.json: FaceBoxes, 1024x1024 frames, `--batch` frames per step on one GPU; /255 + forward +
+    softmax + decode_np + nms_np all on device (reference FACEBOX/My_test_facebox.py:12-36 after the resize).  Real
+    weights (tests/golden/faceboxes_weights.npz = the reference's FACEBOX/faceboxes.pt stored as plain arrays)."""
+    import torch
+    B = args.batch if args.batch > 1 else 16
+    lib = importlib.import_module("face-detection-and-tracking_amd._lib")
+    FaceBox = importlib.import_module("face-detection-and-tracking_amd.FACEBOX.networks").FaceBox
+    z = np.load(os.path.join(ROOT, "tests", "golden", "faceboxes_weights.npz"))
+    sd = {k: z[k] for k in z.files}
+    net = FaceBox()
+    net.load_state_dict(sd)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "facebox.npz"))
+    real = [g["img0_frame"], g["img1_frame"]]
+    frames_h = np.stack([real[i % 2] for i in range(B)])
+    dev = torch.device("cuda", 0)
+    frames_d = torch.from_numpy(frames_h).to(dev)
+    counts = torch.zeros(B, dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream()
+    torch.cuda.set_stream(st)
+    sp = ctypes.c_void_p(st.cuda_stream)
+    L = lib.lib()
+    net.detect_frames(frames_h)          # plan
+    net.autotune(3)
+
+    def step():
+        lib.check(L.fdt_model_detect_facebox_dev(net._h, ctypes.c_void_p(frames_d.data_ptr()), lib.FRAME_U8_HWC_BGR,
+                                                 B, 1024, 1024, 0.35, 0.5, ctypes.c_void_p(counts.data_ptr()), sp))
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = net.detect_frames(frames_h)
+    cpu = None
+    if args.cpu_frames > 0:
+        from oracle import facebox as ofb
+        times = []
+        for i in range(args.cpu_frames):
+            t1 = time.perf_counter()
+            rb, rp = ofb.detect(sd, frames_h[i % 2])
+            times.append(time.perf_counter() - t1)
+            gb, gp = res[i % 2]
+            assert len(gp) == len(rp) and np.abs(gp - rp).max() < 1e-4 and np.abs(gb - rb).max() < 1e-4
+        per = float(np.mean(times[1:])) if len(times) > 1 else times[0]
+        cpu = {"value": round(1 / per, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": "%d frames, oracle/facebox.py (boxes/probs of these frames within 1e-4 of the GPU path)"
+                         % max(len(times) - 1, 1)}
+    print(json.dumps({"metric": "frames/sec (FaceBoxes detect) at 1024x1024", "value": round(B * args.steps / dt, 2),
+                      "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": "f32",
+                      "data": "2 reference sample images (post-resize) tiled to the batch",
+                      "config": {"workload": "FaceBoxes 1024x1024 batch=%d, decode_np+nms_np on device" % B,
+                                 "weights": "reference FACEBOX/faceboxes.pt",
+                                 "faces_per_image": [int(c) for c in counts.cpu()[:2]]},
+                      "roofline": None, "cpu_baseline": cpu}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,7 +102,8 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--height", type=int, default=0, help="frame height (default: --size)")
     ap.add_argument("--width", type=int, default=0, help="frame width (default: --size)")
-    ap.add_argument("--arch", default="res50", choices=["res50", "try3"])
+    ap.add_argument("--arch", default="res50", choices=["res50", "try3", "facebox"],
+                    help="facebox = config 5 of BASELINE.json (FaceBoxes, 1024x1024, --batch 16), single GPU")
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (one batched forward)")
     ap.add_argument("--unique-frames", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-baseline sample (0 = skip)")
@@ -53,6 +116,8 @@ def main():
                     help="frames in flight per GPU: consecutive batch-1 steps overlap on separate HIP streams "
                          "(detection of frame i+1 runs beside the tail / tracker step of frame i)")
     args = ap.parse_args()
+    if args.arch == "facebox":
+        return facebox_main(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Stage-by-stage relative RMS error of the HIP forward against the CPU oracle at any size.
-    python tools/stage_diff.py [--arch res50] [--size 1024]"""
+"""Developer diagnostic (lives under tests/ because it uses the oracle as the checker): stage-by-stage relative
+RMS error of the HIP forward against the CPU oracle at any size.
+    python tests/stage_diff.py [--arch res50] [--size 1024]"""
 import argparse, importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -28,5 +28,5 @@ timeout -k 10 300 python bench.py --steps 64 --warmup 8 --height 480 --width 640
 timeout -k 10 300 python bench.py --steps 32 --warmup 4 --height 1080 --width 1920 --cpu-frames 1 > $OUT/bench_line_res50_1920x1080.json
 timeout -k 10 300 python bench.py --steps 64 --warmup 8 --arch try3 --cpu-frames 4 > $OUT/bench_line_try3_1024.json
 timeout -k 10 300 python bench.py --steps 32 --warmup 4 --arch try3 --batch 8 --cpu-frames 3 > $OUT/bench_line_try3_1024_b8.json
-timeout -k 10 300 python tools/bench_facebox.py > $OUT/bench_line_facebox_b16.json
+timeout -k 10 300 python bench.py --arch facebox --batch 16 --steps 50 --warmup 5 > $OUT/bench_line_facebox_b16.json
 tail -c 600 $OUT/bench_line_res50_1024.json
