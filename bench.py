@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--arch", default="res50", choices=["res50", "try3", "facebox"],
                     help="facebox = config 5 of BASELINE.json (FaceBoxes, 1024x1024, --batch 16), single GPU")
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (one batched forward)")
+    ap.add_argument("--source", default="", help="HxW of raw source frames (e.g. 1080x1920): the frames are resized on the "
+                    "GPU to --height x --width inside the timed step like iouTracke_cal.py:123 does with cv2.resize")
     ap.add_argument("--unique-frames", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--profile-frames", type=int, default=4)
@@ -187,7 +189,8 @@ def main():
 
     # synthetic frames, resident in HBM before the timed region
     U = (max(args.unique_frames, B) + B - 1) // B * B          # whole batches
-    frames_h = synth.make_frames(U, H, W, seed=1234 + rank)
+    SH, SW = (int(v) for v in args.source.lower().split("x")) if args.source else (H, W)
+    frames_h = synth.make_frames(U, SH, SW, seed=1234 + rank)
     frames_d = torch.from_numpy(frames_h).to(dev)
     REC = 2 * top_k * 5                                       # one frame's Detect record
     fps = [par.FrameParallel(rank, world, B * REC, dev) for _ in range(NF)]
@@ -211,9 +214,14 @@ def main():
         fp = fps[k]
         with torch.cuda.stream(det_streams[k]):
             det_streams[k].wait_event(trk_done[k])        # slot k's record was consumed (step i - NF)
-            lib.check(L.fdt_model_forward_dev(nets[k]._h, ctypes.c_void_p(f.data_ptr()), lib.FRAME_U8_HWC_BGR, B,
-                                              H, W, ctypes.c_void_p(fp.mine.data_ptr()),
-                                              ctypes.c_void_p(counts.data_ptr()), sp_det[k]))
+            if args.source:     # raw source frames: resize + mean subtraction in one kernel, then the forward
+                lib.check(L.fdt_model_forward_resized(nets[k]._h, ctypes.c_void_p(f.data_ptr()), 1, B, SH, SW, H, W,
+                                                      ctypes.c_void_p(fp.mine.data_ptr()),
+                                                      ctypes.c_void_p(counts.data_ptr()), sp_det[k]))
+            else:
+                lib.check(L.fdt_model_forward_dev(nets[k]._h, ctypes.c_void_p(f.data_ptr()), lib.FRAME_U8_HWC_BGR, B,
+                                                  H, W, ctypes.c_void_p(fp.mine.data_ptr()),
+                                                  ctypes.c_void_p(counts.data_ptr()), sp_det[k]))
             det_done[k].record(det_streams[k])
         with torch.cuda.stream(trk_stream):
             trk_stream.wait_event(det_done[k])
@@ -262,9 +270,14 @@ def main():
         net.profile(True)
         conv_ms, other_ms, flops = [], [], 0.0
         for i in range(args.profile_frames + 1):
-            lib.check(L.fdt_model_forward_dev(net._h, ctypes.c_void_p(frames_d[(i * B) % U:].data_ptr()),
-                                              lib.FRAME_U8_HWC_BGR, B, H, W, ctypes.c_void_p(mine.data_ptr()),
-                                              ctypes.c_void_p(counts.data_ptr()), stream))
+            if args.source:
+                lib.check(L.fdt_model_forward_resized(net._h, ctypes.c_void_p(frames_d[(i * B) % U:].data_ptr()), 1, B,
+                                                      SH, SW, H, W, ctypes.c_void_p(mine.data_ptr()),
+                                                      ctypes.c_void_p(counts.data_ptr()), stream))
+            else:
+                lib.check(L.fdt_model_forward_dev(net._h, ctypes.c_void_p(frames_d[(i * B) % U:].data_ptr()),
+                                                  lib.FRAME_U8_HWC_BGR, B, H, W, ctypes.c_void_p(mine.data_ptr()),
+                                                  ctypes.c_void_p(counts.data_ptr()), stream))
             torch.cuda.synchronize()
             prof = net.profile_read()
             if i == 0:
@@ -301,18 +314,22 @@ def main():
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         from oracle import postproc as opp
         from oracle import pyramidbox as opb
+        from oracle import ingest as oin
         ncores = torch.get_num_threads()
         ref_trk = opp.IouTracker(0.4, 0.6, 5)
         times, ref_dets, gpu_dets = [], [], []
         for i in range(args.cpu_frames):
             t1 = time.perf_counter()
-            y = opb.detect_frame(sd, frames_h[i % U], args.arch)
+            src = frames_h[i % U]
+            if args.source:       # the oracle's restatement of cv2.resize(image, (W, H)) (8-bit INTER_LINEAR)
+                src = oin.resize_linear_u8(src, W, H)
+            y = opb.detect_frame(sd, src, args.arch)
             det_ref = opp.unpack_detections(y, W, H, 0.4)
             with np.errstate(all="ignore"):
                 ref_trk.step(det_ref)
             times.append(time.perf_counter() - t1)
             # parity of the same frames on the GPU path (checker only; not timed)
-            yg = net(frames_h[i % U]).numpy()
+            yg = (net.forward_resized(frames_h[i % U], (W, H)) if args.source else net(frames_h[i % U])).numpy()
             ref_dets.append(det_ref)
             gpu_dets.append(opp.unpack_detections(yg, W, H, 0.4))
         ap, n_truth, n_pred = opp.ap_against_reference(gpu_dets, ref_dets, 0.5)
@@ -344,8 +361,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "PyramidBox-%s %dx%d synthetic u8 frames, batch=%d per GPU, decode+NMS+IoU-tracker "
-                                   "on device" % ("Res50" if args.arch == "res50" else "MobileNetV2-try3", W, H, B),
+            "config": {"workload": "PyramidBox-%s %dx%d synthetic u8 frames%s, batch=%d per GPU, decode+NMS+IoU-tracker "
+                                   "on device" % ("Res50" if args.arch == "res50" else "MobileNetV2-try3", W, H,
+                                                  " resized on the GPU from %dx%d sources" % (SW, SH) if args.source else "",
+                                                  B),
                        "frames_per_step": world * B, "frames_in_flight_per_gpu": NF, "kernel_plan": plan_src, "parallelism": "frame-parallel x%d%s" % (
                            world, ", RCCL all-gather of box lists" if world > 1 else ""),
                        "weights": "seeded synthetic (seed 0)", "detections_last_frame": n_cand_last,

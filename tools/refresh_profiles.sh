@@ -25,6 +25,7 @@ python tools/summarize_pmc.py /tmp/raw/calib_counter_collection.csv $OUT/pmc_FET
 python tools/traffic_json.py $OUT/pmc_FETCH_SIZE_by_kernel.csv $OUT/pmc_WRITE_SIZE_by_kernel.csv 105 $OUT/conv_hbm_traffic.json $OUT/pmc_FETCH_SIZE_calibration_1x1_67MB.csv
 timeout -k 10 300 python tools/profile_layers.py > $OUT/per_layer_hip_events_res50_1024.txt
 timeout -k 10 300 python bench.py --steps 64 --warmup 8 --height 480 --width 640 --cpu-frames 2 > $OUT/bench_line_res50_640x480.json
+timeout -k 10 300 python bench.py --steps 128 --warmup 16 --source 1080x1920 --height 480 --width 640 --cpu-frames 3 > $OUT/bench_line_res50_640x480_from_1080p.json
 timeout -k 10 300 python bench.py --steps 32 --warmup 4 --height 1080 --width 1920 --cpu-frames 1 > $OUT/bench_line_res50_1920x1080.json
 timeout -k 10 300 python bench.py --steps 64 --warmup 8 --arch try3 --cpu-frames 4 > $OUT/bench_line_try3_1024.json
 timeout -k 10 300 python bench.py --steps 32 --warmup 4 --arch try3 --batch 8 --cpu-frames 3 > $OUT/bench_line_try3_1024_b8.json
