@@ -60,6 +60,9 @@ enum ConvTile {
   TILE_128x64R4,
   TILE_64x64R4,
   TILE_64x128R4,
+  // quarter-split 8-wave Winograd (conv_wino4_kernel): 16x16 px / 8x32 px, 64 ch
+  TILE_WINO4_64x64R3,
+  TILE_WINO4_64x64W,
   CONV_TILE_COUNT
 };
 

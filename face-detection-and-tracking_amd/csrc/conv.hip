@@ -136,7 +136,9 @@ const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum 
     // 8-wave Winograd
     {256, 64, 16, 16}, {256, 64, 16, 16}, {512, 32, 16, 32}, {256, 64, 8, 32},
     // ring of four
-    {128, 128, 8, 16}, {128, 64, 8, 16}, {64, 64, 8, 8}, {64, 128, 8, 8}};
+    {128, 128, 8, 16}, {128, 64, 8, 16}, {64, 64, 8, 8}, {64, 128, 8, 8},
+    // quarter-split Winograd
+    {256, 64, 16, 16}, {256, 64, 8, 32}};
 
 }  // namespace
 
@@ -149,6 +151,9 @@ ConvKind conv_base_kind(ConvKind k) {
     case CONV_1x1_S1_K64: return CONV_1x1_S1;
     default: return k;
   }
+}
+bool tile_is_wino(ConvTile t) {
+  return (t >= TILE_WINO_64x64 && t <= TILE_WINO8_64x64W) || t == TILE_WINO4_64x64R3 || t == TILE_WINO4_64x64W;
 }
 int tile_bm(ConvTile t) { return kTileDims[t][0]; }
 int tile_bn(ConvTile t) { return kTileDims[t][1]; }
@@ -305,8 +310,8 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
                 "fdt_conv2d: kernel class %d does not implement this convolution", alt);
     kind = alt;
   }
-  if (kind == CONV_3x3_S1 && tile >= TILE_WINO_64x64 && tile <= TILE_WINO8_64x64W) kind = CONV_3x3_S1_WINO;
-  if (kind == CONV_3x3_S1_D2 && tile >= TILE_WINO_64x64 && tile <= TILE_WINO8_64x64W) kind = CONV_3x3_D2_WINO;
+  if (kind == CONV_3x3_S1 && tile_is_wino((ConvTile)tile)) kind = CONV_3x3_S1_WINO;
+  if (kind == CONV_3x3_S1_D2 && tile_is_wino((ConvTile)tile)) kind = CONV_3x3_D2_WINO;
   FDT_REQUIRE(tile >= 0 && tile < CONV_TILE_COUNT && conv_supported((ConvKind)kind, (ConvTile)tile), FDT_ERR_ARG,
               "fdt_conv2d: kernel (kind %d, tile %d) not instantiated", kind, tile);
   a.ksplit = ksplit > 0 ? ksplit : 1;

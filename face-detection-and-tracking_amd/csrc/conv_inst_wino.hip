@@ -15,6 +15,8 @@ void conv_fill_wino(void* row) {
   r[TILE_WINO8_64x64R3] = wino2_entry<W_64x64R3>();
   r[TILE_WINO8_128x32R3] = wino2_entry<W_128x32R3>();
   r[TILE_WINO8_64x64W] = wino2_entry<W_64x64W>();
+  r[TILE_WINO4_64x64R3] = wino4_entry<W_64x64R3>();
+  r[TILE_WINO4_64x64W] = wino4_entry<W_64x64W>();
 }
 void conv_fill_wino_d2(void* row) {
   KernelEntry* r = (KernelEntry*)row;
@@ -22,5 +24,7 @@ void conv_fill_wino_d2(void* row) {
   r[TILE_WINO8_64x64R3] = wino2_entry<WD2_64x64R3>();
   r[TILE_WINO8_128x32R3] = wino2_entry<WD2_128x32R3>();
   r[TILE_WINO8_64x64W] = wino2_entry<WD2_64x64W>();
+  r[TILE_WINO4_64x64R3] = wino4_entry<WD2_64x64R3>();
+  r[TILE_WINO4_64x64W] = wino4_entry<WD2_64x64W>();
 }
 }  // namespace fdt

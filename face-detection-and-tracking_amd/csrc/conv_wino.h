@@ -563,6 +563,273 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Quarter-split form of the 8-wave kernel: the four ROWS of the 4x4 position grid go to four waves, and every wave
+// covers all 64 output channels of the workgroup (two 32-row MFMA tiles) for its 32 blocks.  Same 8 accumulators,
+// but each transformed input value now feeds two MFMAs, a wave needs only two window rows and one of the four row
+// transforms: half the transform VALU and a third fewer LDS operand bytes per MFMA than the half-split form (the
+// MFMA pipe is what both are bound by; tools/microbench/mfma_mix.hip shows what the operand traffic around a 64-cycle
+// f32 MFMA costs).  The output transform is finished through LDS by all four quarters, each storing a quarter of the
+// rows.  WM = WN = 2 tiles only (64 blocks x 64 channels).
+template <class T>
+__global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(T::WM == 2 && T::WN == 2 && T::NBUF >= 3 && (T::KC / 2) % 2 == 0, "quarter split: 64x64 tiles, ring of 3");
+  static_assert(T::XSZP % 512 == 0 && T::WSZP % 2048 == 0, "8-wave staging granularity");
+  constexpr int NX2 = T::XSZP / 512, NW2 = T::WSZP / 2048, LOADS2 = NX2 + NW2;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = wave >> 1;                                   // row of the position grid
+  const int wm = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  constexpr int TH = 2 * T::TTH, TW = 2 * T::TTW;
+  const int tiles_x = (a.Wout + TW - 1) / TW;
+  FDT_BLOCK_MAP(a, sp_tile, n_tile);
+  const int oy0 = (sp_tile / tiles_x) * TH;
+  const int ox0 = (sp_tile % tiles_x) * TW;
+  const int b = blockIdx.z / a.ksplit;
+  const int ks = blockIdx.z - b * a.ksplit;
+
+  const int HW = a.Hin * a.Win;
+  const float* in_b = a.in + (long long)b * a.Cin * HW;
+  const int nstages = (a.Cin + T::KC - 1) / T::KC;
+  const float* w_t = a.w + (long long)n_tile * nstages * T::WSZP;
+  const int s_begin = (int)((long long)nstages * ks / a.ksplit);
+  const int s_end = (int)((long long)nstages * (ks + 1) / a.ksplit);
+
+  const float* zpad = g_zero_pad;
+  asm volatile("" : "+s"(zpad));
+  int goff[NX2];
+  unsigned okmask = 0;
+#pragma unroll
+  for (int k = 0; k < NX2; ++k) {
+    int e = tid + 512 * k;
+    int c = e / T::XPLANE;
+    int r = e - c * T::XPLANE;
+    int yy = r / T::PW, xx = r - yy * T::PW;
+    int gy = oy0 - T::D + yy, gx = ox0 - T::D + xx;
+    bool ok = (e < T::XSZ) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+    goff[k] = ok ? (c * HW + gy * a.Win + gx) : 0;
+    if (ok) okmask |= (1u << k);
+  }
+
+#define FDT_W4STAGE(s_, buf_)                                                                  \
+  {                                                                                            \
+    const int c0_ = (s_) * T::KC;                                                              \
+    const float* src_ = in_b + (long long)c0_ * HW;                                            \
+    const int crem_ = a.Cin - c0_;                                                             \
+    float* X_ = smem + (buf_) * T::STAGE + wave * 64;                                          \
+    _Pragma("unroll") for (int k = 0; k < NX2; ++k) {                                          \
+      const int c_ = (tid + 512 * k) / T::XPLANE;                                              \
+      const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                     \
+      glds4(ok_ ? src_ + goff[k] : zpad, X_ + 512 * k);                                        \
+    }                                                                                          \
+    const float* wsrc_ = w_t + (long long)(s_) * T::WSZP + tid * 4;                            \
+    float* W_ = smem + (buf_) * T::STAGE + T::XSZP + wave * 256;                               \
+    _Pragma("unroll") for (int k = 0; k < NW2; ++k) glds16(wsrc_ + 2048 * k, W_ + 2048 * k);   \
+  }
+
+  const int qb = wm * 32 + l31;
+  int oyl, oxl;
+  if (T::D == 1) {
+    oyl = 2 * (qb / T::TTW);
+    oxl = 2 * (qb % T::TTW);
+  } else {
+    constexpr int CX = (2 * T::TTW) / 4;
+    const int cell = qb >> 2, par = qb & 3;
+    oyl = 4 * (cell / CX) + (par >> 1);
+    oxl = 4 * (cell % CX) + (par & 1);
+  }
+  const int xo = half * T::XPLANE + oyl * T::PW + oxl;
+  const int wo = T::XSZP + half * 16 * T::BN + q * 4 * T::BN + l31;
+
+  f32x16 acc[8];                                               // [position column j][channel tile mt] = j * 2 + mt
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  const int nst = s_end - s_begin;
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+    if (p < nst) FDT_W4STAGE(s_begin + p, p);
+
+  auto main_loop = [&](auto q_c) {
+    constexpr int Q_ = decltype(q_c)::value;
+    // window rows this quarter needs: row Q_ of B^T d is  q0: d0 - d2,  q1: d1 + d2,  q2: d2 - d1,  q3: d1 - d3
+    constexpr int RA = (Q_ == 0) ? 0 : 1, RB = (Q_ == 3) ? 3 : 2;
+    struct Ops {
+      f32x4 d1[2];          // D = 1: window rows RA, RB
+      f32x2 d2[2][2];       // D = 2
+      f32x2 u[2][2];        // weights [channel tile][position pair (0,1) / (2,3)]
+    };
+    constexpr int NLD = (T::D == 1 ? 2 : 4) + 4;
+    constexpr int ROWB = T::D * T::PW * 4;
+    static_assert(ROWB % 8 == 0 && (3 * ROWB) / 8 + 1 < 256 && 3 * (ROWB / 4) + 6 < 256 && T::BN == 64, "ds offset fields");
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    const unsigned xb = lds0 + (unsigned)xo * 4u, wb = lds0 + (unsigned)wo * 4u;
+    auto load = [&](Ops& o, int buf, int cp) {
+      const unsigned xa = xb + (unsigned)(buf * T::STAGE + 2 * cp * T::XPLANE) * 4u;
+      const unsigned wa = wb + (unsigned)(buf * T::STAGE + 2 * cp * 16 * T::BN) * 4u;
+      if constexpr (T::D == 1) {
+        lds_read2_b64<RA * ROWB / 8, RA * ROWB / 8 + 1>(o.d1[0], xa);
+        lds_read2_b64<RB * ROWB / 8, RB * ROWB / 8 + 1>(o.d1[1], xa);
+      } else {
+        lds_read2_b32<RA * ROWB / 4, RA * ROWB / 4 + 2>(o.d2[0][0], xa);
+        lds_read2_b32<RA * ROWB / 4 + 4, RA * ROWB / 4 + 6>(o.d2[0][1], xa);
+        lds_read2_b32<RB * ROWB / 4, RB * ROWB / 4 + 2>(o.d2[1][0], xa);
+        lds_read2_b32<RB * ROWB / 4 + 4, RB * ROWB / 4 + 6>(o.d2[1][1], xa);
+      }
+      lds_read2st64_b32<0, 1>(o.u[0][0], wa);
+      lds_read2st64_b32<2, 3>(o.u[0][1], wa);
+      lds_read2st64_b32<0, 1>(o.u[1][0], wa + 128u);          // channel tile 1: +32 floats
+      lds_read2st64_b32<2, 3>(o.u[1][1], wa + 128u);
+    };
+    auto wait_for = [&](Ops& o, auto newer_c) {
+      constexpr int N_ = decltype(newer_c)::value;
+      if constexpr (T::D == 1)
+        asm volatile("s_waitcnt lgkmcnt(%6)"
+                     : "+v"(o.d1[0]), "+v"(o.d1[1]), "+v"(o.u[0][0]), "+v"(o.u[0][1]), "+v"(o.u[1][0]), "+v"(o.u[1][1])
+                     : "n"(N_));
+      else
+        asm volatile("s_waitcnt lgkmcnt(%8)"
+                     : "+v"(o.d2[0][0]), "+v"(o.d2[0][1]), "+v"(o.d2[1][0]), "+v"(o.d2[1][1]), "+v"(o.u[0][0]),
+                       "+v"(o.u[0][1]), "+v"(o.u[1][0]), "+v"(o.u[1][1])
+                     : "n"(N_));
+    };
+    auto mac_ops = [&](const Ops& o) {
+      float da[4], db[4], t[4], v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (T::D == 1) {
+          da[j] = o.d1[0][j];
+          db[j] = o.d1[1][j];
+        } else {
+          da[j] = o.d2[0][j >> 1][j & 1];
+          db[j] = o.d2[1][j >> 1][j & 1];
+        }
+        t[j] = (Q_ == 1) ? (da[j] + db[j]) : (Q_ == 2) ? (db[j] - da[j]) : (da[j] - db[j]);
+      }
+      v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[j * 2 + mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.u[mt][j >> 1][j & 1], v[j], acc[j * 2 + mt], 0, 0, 0);
+    };
+    using N0 = std::integral_constant<int, 0>;
+    using NL = std::integral_constant<int, NLD>;
+
+    if (nst > 1)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS2) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    Ops A, B;
+    int cur = 0;
+    load(A, 0, 0);
+    for (int it = 0; it < nst; ++it) {
+      const int nb = (cur + 1 == 3) ? 0 : cur + 1;
+#pragma unroll
+      for (int cp = 0; cp < T::KC / 2; cp += 2) {
+        if (cp == 2 || T::KC / 2 == 2) {
+          if (it + 1 < nst) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const int fb = (nb + 1 == 3) ? 0 : nb + 1;
+            if (it + 2 < nst) FDT_W4STAGE(s_begin + it + 2, fb);
+          }
+        }
+        load(B, cur, cp + 1);
+        wait_for(A, NL{});
+        mac_ops(A);
+        if (cp + 2 < T::KC / 2) load(A, cur, cp + 2);
+        else load(A, nb, 0);
+        wait_for(B, NL{});
+        mac_ops(B);
+      }
+      cur = nb;
+    }
+    wait_for(A, N0{});
+  };
+  switch (q) {
+    case 0: main_loop(std::integral_constant<int, 0>{}); break;
+    case 1: main_loop(std::integral_constant<int, 1>{}); break;
+    case 2: main_loop(std::integral_constant<int, 2>{}); break;
+    default: main_loop(std::integral_constant<int, 3>{}); break;
+  }
+#undef FDT_W4STAGE
+
+  // ---- output transform Y = A^T M A: this wave holds row q of M for (channel tile mt, register r) --------------
+  //   (t0, t1) = (m0 + m1 + m2, m1 - m2 - m3);  y0* = t(q0) + t(q1) + t(q2),  y1* = t(q1) - t(q2) - t(q3)
+  __syncthreads();                       // ring is dead; reuse it as the exchange buffer [wave][pair][2][lane]
+  float* E = smem;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0 * 2 + mt][r], m1 = acc[1 * 2 + mt][r], m2 = acc[2 * 2 + mt][r], m3 = acc[3 * 2 + mt][r];
+      const int p = mt * 16 + r;
+      E[((wave * 32 + p) * 2 + 0) * 64 + lane] = m0 + m1 + m2;
+      E[((wave * 32 + p) * 2 + 1) * 64 + lane] = m1 - m2 - m3;
+    }
+  __syncthreads();
+  const int HWo = a.Hout * a.Wout;
+  const int oy = oy0 + oyl, ox = ox0 + oxl;
+  const bool raw = a.ws != nullptr;
+  float* dst_b = raw ? a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWo
+                     : a.out + ((long long)b * a.out_ctot + a.out_coff) * HWo;
+  const float* res_b = (!raw && a.res) ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWo : nullptr;
+  const bool row0 = oy < a.Hout, row1 = oy + T::D < a.Hout;
+  const bool col0 = ox < a.Wout, col1 = ox + T::D < a.Wout;
+  const bool vec2 = (T::D == 1) && (a.Wout % 2 == 0);
+  // this wave finishes the pairs with (r & 3) == q: a quarter of the rows, every quarter stores
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = rr * 4 + q;
+      const int p = mt * 16 + r;
+      float t0[4], t1[4];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        t0[qq] = E[(((qq * 2 + wm) * 32 + p) * 2 + 0) * 64 + lane];
+        t1[qq] = E[(((qq * 2 + wm) * 32 + p) * 2 + 1) * 64 + lane];
+      }
+      float y00 = t0[0] + t0[1] + t0[2], y01 = t1[0] + t1[1] + t1[2];
+      float y10 = t0[1] - t0[2] - t0[3], y11 = t1[1] - t1[2] - t1[3];
+      const int co = n_tile * T::BN + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < a.Cout && col0) {
+        const long long base = (long long)co * HWo + (long long)oy * a.Wout + ox;
+        if (!raw) {
+          const float bv = a.bias ? a.bias[co] : 0.0f;
+          y00 += bv; y01 += bv; y10 += bv; y11 += bv;
+          if (res_b) {
+            if (row0) { y00 += res_b[base]; if (col1) y01 += res_b[base + T::D]; }
+            if (row1) { y10 += res_b[base + T::D * a.Wout]; if (col1) y11 += res_b[base + T::D * a.Wout + T::D]; }
+          }
+          if (a.act == ACT_RELU) {
+            y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f);
+          } else if (a.act == ACT_RELU6) {
+            y00 = fminf(fmaxf(y00, 0.f), 6.f); y01 = fminf(fmaxf(y01, 0.f), 6.f);
+            y10 = fminf(fmaxf(y10, 0.f), 6.f); y11 = fminf(fmaxf(y11, 0.f), 6.f);
+          }
+        }
+        if (vec2) {
+          if (row0) *reinterpret_cast<float2*>(dst_b + base) = make_float2(y00, y01);
+          if (row1) *reinterpret_cast<float2*>(dst_b + base + a.Wout) = make_float2(y10, y11);
+        } else {
+          if (row0) { dst_b[base] = y00; if (col1) dst_b[base + T::D] = y01; }
+          if (row1) { dst_b[base + T::D * a.Wout] = y10; if (col1) dst_b[base + T::D * a.Wout + T::D] = y11; }
+        }
+      }
+    }
+}
+
 //                           TTH TTW WM WN KC NBUF      patch (px)  couts
 using W_64x64    = WinoTile<8, 8, 2, 2, 8, 2>;     //  16 x 16     64
 using W_64x64R3  = WinoTile<8, 8, 2, 2, 8, 3>;
@@ -579,6 +846,11 @@ using WD2_64x64W   = WinoTile<4, 16, 2, 2, 8, 3, 2>;
 template <class T>
 KernelEntry wino_entry() {
   return KernelEntry{conv_wino_kernel<T>, T::LDS_BYTES, 256};
+}
+template <class T>
+KernelEntry wino4_entry() {
+  constexpr size_t ex = 8 * 32 * 2 * 64 * sizeof(float);   // epilogue exchange buffer: every wave's (t0, t1) pairs
+  return KernelEntry{conv_wino4_kernel<T>, T::LDS_BYTES > ex ? T::LDS_BYTES : ex, 512};
 }
 template <class T>
 KernelEntry wino2_entry() {

@@ -15,7 +15,7 @@ KINDS = {  # name: (k, stride, pad, dil)
     "1x1s1": (1, 1, 0, 1), "1x1s2": (1, 2, 0, 1), "3x3s1": (3, 1, 1, 1), "3x3d2": (3, 1, 2, 2),
     "3x3s2": (3, 2, 1, 1), "7x7s2": (7, 2, 3, 1), "7x7s4": (7, 4, 3, 1), "5x5s2": (5, 2, 2, 1),
     "7x7s2p1": (7, 2, 1, 1)}
-N_TILES = 29      # 14 direct tiles + 11 Winograd F(2x2,3x3) tiles (3x3 s1 only) + 4 ring-of-four tiles (1x1 only)
+N_TILES = 31      # 14 direct + 11 Winograd F(2x2,3x3) (3x3 s1 / d2 only) + 4 ring-of-four (1x1 only) + 2 quarter-split Winograd
 
 
 def lib():
@@ -87,7 +87,7 @@ def test_xcd_aware_workgroup_maps(mode, monkeypatch):
     convolution as the row-major map."""
     monkeypatch.setenv("FDT_CONV_MAP", str(mode))
     rng = np.random.default_rng(mode)
-    for (k, s, p, d, tiles) in ((1, 1, 0, 1, (0, 3, 9, 25)), (3, 1, 1, 1, (1, 3, 24)), (3, 1, 2, 2, (1, 24)), (3, 2, 1, 1, (1,))):
+    for (k, s, p, d, tiles) in ((1, 1, 0, 1, (0, 3, 9, 25)), (3, 1, 1, 1, (1, 3, 24, 30)), (3, 1, 2, 2, (1, 24, 29)), (3, 2, 1, 1, (1,))):
         for (Cin, H, W, Cout) in ((24, 52, 76, 200), (17, 9, 11, 40)):      # 28 / 1 spatial tiles; 7 / 2 channel tiles
             x = rng.standard_normal((2, Cin, H, W)).astype(np.float32)
             w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
@@ -117,7 +117,7 @@ def test_fused_epilogues(tile, W):
             assert rel_err(got, reference(x, w, b, 1, 1, 0, 1, **kw)) < 1e-5, (tile, W, split, list(kw))
 
 
-@pytest.mark.parametrize("tile", range(14, 25))
+@pytest.mark.parametrize("tile", list(range(14, 25)) + [29, 30])
 @pytest.mark.parametrize("shape", [(64, 40, 48, 96), (37, 31, 45, 70)])
 def test_winograd_variants(tile, shape):
     """Winograd F(2x2,3x3): 2.25x fewer multiplies, same result up to f32 rounding of the transforms

@@ -20,6 +20,8 @@ namespace fdt { namespace {
 template __global__ void conv_wino2_kernel<W_64x64W>(const ConvArgs);       // 3x3 pad 1, 8x32-pixel tile
 template __global__ void conv_wino2_kernel<W_128x32R3>(const ConvArgs);     // 32-channel tile (detection heads)
 template __global__ void conv_wino2_kernel<WD2_64x64W>(const ConvArgs);     // dilation 2
+template __global__ void conv_wino4_kernel<W_64x64W>(const ConvArgs);       // quarter-split form
+template __global__ void conv_wino4_kernel<WD2_64x64R3>(const ConvArgs);
 } }
 """
 
@@ -34,6 +36,7 @@ def test_async_lds_reads_have_no_hazards(tmp_path):
     text = asm.read_text()
     # the hand-counted waits are really there (7 = 3 window rows + 4 weight pairs, 10 for the dilated window)
     assert "s_waitcnt lgkmcnt(7)" in text and "s_waitcnt lgkmcnt(10)" in text
+    assert "s_waitcnt lgkmcnt(6)" in text and "s_waitcnt lgkmcnt(8)" in text      # quarter-split: 2 / 4 window reads + 4
     assert text.count("ds_read2_b64") > 0 and text.count("ds_read2st64_b32") > 0
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_async_lds.py"), str(asm)],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
