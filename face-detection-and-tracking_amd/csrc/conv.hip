@@ -60,19 +60,24 @@ __global__ void splitk_reduce_kernel(const ConvArgs a) {
   for (int e = 0; e < VEC; ++e) v[e] += bv;
   if (a.up) {
     const float* u = a.up + ((long long)b * a.Cout + co) * a.up_h * a.up_w;
+    // the VEC pixels of a thread sit in one output row (VEC == 4 only when Wout % 4 == 0): one row lookup per thread
+    const int oy = pix / a.Wout, ox0 = pix - oy * a.Wout;
+    const float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.0f);
+    int y0 = (int)sy;
+    y0 = y0 < a.up_h - 1 ? y0 : a.up_h - 1;
+    const int y1 = y0 + (y0 < a.up_h - 1 ? 1 : 0);
+    const float ly = sy - (float)y0;
+    const float* u0 = u + y0 * a.up_w;
+    const float* u1 = u + y1 * a.up_w;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const int oy = (pix + e) / a.Wout, ox = (pix + e) % a.Wout;
-      float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.0f);
-      float sx = fmaxf(0.5f * (ox + 0.5f) - 0.5f, 0.0f);
-      int y0 = (int)sy, x0 = (int)sx;
-      y0 = y0 < a.up_h - 1 ? y0 : a.up_h - 1;
+      const float sx = fmaxf(0.5f * (ox0 + e + 0.5f) - 0.5f, 0.0f);
+      int x0 = (int)sx;
       x0 = x0 < a.up_w - 1 ? x0 : a.up_w - 1;
-      const int y1 = y0 + (y0 < a.up_h - 1 ? 1 : 0);
       const int x1 = x0 + (x0 < a.up_w - 1 ? 1 : 0);
-      const float ly = sy - (float)y0, lx = sx - (float)x0;
-      const float top = (1.0f - lx) * u[y0 * a.up_w + x0] + lx * u[y0 * a.up_w + x1];
-      const float bot = (1.0f - lx) * u[y1 * a.up_w + x0] + lx * u[y1 * a.up_w + x1];
+      const float lx = sx - (float)x0;
+      const float top = (1.0f - lx) * u0[x0] + lx * u0[x1];
+      const float bot = (1.0f - lx) * u1[x0] + lx * u1[x1];
       v[e] += (1.0f - ly) * top + ly * bot;
     }
   }
