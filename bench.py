@@ -269,6 +269,7 @@ def main():
     if rank == 0:
         net.profile(True)
         conv_ms, other_ms, flops = [], [], 0.0
+        dw_stats = []
         for i in range(args.profile_frames + 1):
             if args.source:
                 lib.check(L.fdt_model_forward_resized(net._h, ctypes.c_void_p(frames_d[(i * B) % U:].data_ptr()), 1, B,
@@ -286,6 +287,18 @@ def main():
             other_ms.append(sum(ms for nm, ms, fl in prof if "#k" not in nm))
             flops = sum(fl for nm, ms, fl in prof if "#k" in nm)
             n_conv = sum(1 for nm, ms, fl in prof if "#k" in nm)
+            if args.arch == "try3":
+                # the depthwise 3x3 layers (HBM-bound by construction: in + out bytes, nothing else).  A depthwise op
+                # has 18 FLOP per output element, so its output size follows from its FLOPs; the input is stride^2
+                # times that (strides: pyramid_mb2_try3.py:150-168, layer6 :178).
+                s2 = {"features.%d.conv.3" % i for i, _, _, st, _ in synth.try3_blocks() if st == 2} | {"layer6.conv.3"}
+                dwb = dwm = 0.0
+                for nm, ms, fl in prof:
+                    if "#k" not in nm and (nm.startswith("features.") or nm.startswith("layer6.")) and fl > 0:
+                        out_el = fl / 18.0
+                        dwb += 4.0 * out_el * (1 + (4 if nm in s2 else 1))
+                        dwm += ms
+                dw_stats.append((dwb, dwm))
         net.profile(False)
         cms = float(np.mean(conv_ms))
         achieved = flops / (cms * 1e-3) / 1e12
@@ -308,6 +321,13 @@ def main():
                 "avg_launch_us": round(cms * 1e3 / n_conv, 2), "conv_ms_per_frame": round(cms / B, 3),
                 "other_ms_per_frame": round(float(np.mean(other_ms)) / B, 3),
                 "algorithmic_gflop_per_frame": round(flops / B / 1e9, 3)}
+        if dw_stats and dw_stats[-1][1] > 0:      # config 3: state the HBM side too
+            dwb = float(np.mean([d[0] for d in dw_stats]))
+            dwm = float(np.mean([d[1] for d in dw_stats]))
+            roof["hbm_side"] = {"bound": "hbm", "kernel": "dwconv3_vec_kernel (depthwise 3x3 + BN + ReLU6)",
+                                "achieved": round(dwb / (dwm * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                "frac": round(dwb / (dwm * 1e-3) / 1e9 / 8000.0, 4),
+                                "algorithmic_bytes_per_frame": round(dwb / B), "ms_per_frame": round(dwm / B, 4)}
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample ---------------------------
     cpu, parity = None, None
