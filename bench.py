@@ -94,6 +94,65 @@ def facebox_main(args):
                       "roofline": None, "cpu_baseline": cpu}))
 
 
+KIND_NAMES = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2", "3x3s1_wino", "3x3d2_wino", "1x1s1_k32",
+              "1x1s1_k64", "7x7s2p1"]
+WINO_KINDS = (8, 9)           # conv.h: CONV_3x3_S1_WINO / CONV_3x3_D2_WINO execute 16/36 of the direct MACs
+WINO_RATIO = 2.25
+
+
+def kernel_label(kind, tile):
+    """Kernel template a (kind, tile) pair of conv.h launches (names as rocprofv3 prints them)."""
+    if kind in WINO_KINDS:
+        k = "conv_wino4_kernel" if tile in (29, 30) else ("conv_wino2_kernel" if 21 <= tile <= 24 else "conv_wino_kernel")
+        return "%s<%s, tile %d>" % (k, KIND_NAMES[kind], tile)
+    return "conv_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
+
+
+def parse_op(name):
+    """'layer#k8t29s1' -> (layer, kind, tile, split) ; non-conv ops -> (name, None, None, None)."""
+    if "#k" not in name:
+        return name, None, None, None
+    layer, suf = name.rsplit("#k", 1)
+    kind, rest = suf.split("t", 1)
+    tile, split = rest.split("s", 1)
+    return layer, int(kind), int(tile), int(split)
+
+
+def cpu_info():
+    """(model name, physical cores, logical cpus) from /proc/cpuinfo."""
+    model, phys, logical = "unknown", set(), 0
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model == "unknown":
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("processor"):
+                logical += 1
+            elif ln.startswith("physical id"):
+                pid = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                cid = ln.split(":", 1)[1].strip()
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    return model, (len(phys) or logical or 1), (logical or 1)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as children (before anything touches the GPU),
+    relay rank 0's JSON line and exit with the launcher's code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,7 +167,8 @@ def main():
     ap.add_argument("--source", default="", help="HxW of raw source frames (e.g. 1080x1920): the frames are resized on the "
                     "GPU to --height x --width inside the timed step like iouTracke_cal.py:123 does with cv2.resize")
     ap.add_argument("--unique-frames", type=int, default=8)
-    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", default="sweep", help="'sweep' (8/16/32/64/physical, best is reported) or a number")
     ap.add_argument("--profile-frames", type=int, default=4)
     ap.add_argument("--autotune", type=int, default=1,
                     help="1: use the committed tuned plan for this shape if there is one, else autotune (tile, split-K) "
@@ -117,6 +177,10 @@ def main():
     ap.add_argument("--inflight", type=int, default=3,
                     help="frames in flight per GPU: consecutive batch-1 steps overlap on separate HIP streams "
                          "(detection of frame i+1 runs beside the tail / tracker step of frame i)")
+    ap.add_argument("--graph", type=int, default=1, help="replay each forward as a captured HIP graph (0: eager launches)")
+    ap.add_argument("--host-frames", type=int, default=0,
+                    help="also report the PCIe-inclusive rate: N frames handed over as pageable host buffers through the "
+                         "pipelined fdt_model_forward_async / fdt_model_wait path (never `value`)")
     args = ap.parse_args()
     if args.arch == "facebox":
         return facebox_main(args)
@@ -124,16 +188,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)"
-                             % (args.gpus, world))
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
     import torch.distributed as dist
 
-    # FDT_BENCH_BACKEND=gloo lets the N > 1 path be rehearsed with several ranks sharing one GPU
+    # FDT_BENCH_BACKEND=gloo lets the N > 1 path be rehearsed with several ranks sharing one GPU (host all-gather)
     backend = os.environ.get("FDT_BENCH_BACKEND", "nccl")
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
@@ -148,8 +212,8 @@ def main():
     pkg = importlib.import_module("face-detection-and-tracking_amd")
     synth = importlib.import_module("face-detection-and-tracking_amd.synth")
     layers = importlib.import_module("face-detection-and-tracking_amd.layers")
-    trk = importlib.import_module("face-detection-and-tracking_amd.tracker")
     par = importlib.import_module("face-detection-and-tracking_amd.parallel")
+    pipeline = importlib.import_module("face-detection-and-tracking_amd.pipeline")
     lib = pkg._lib
 
     H = args.height or args.size
@@ -157,80 +221,58 @@ def main():
     sd = synth.make_state_dict(args.arch, seed=0)
     NF = max(1, args.inflight)
     B = max(1, args.batch)
-    nets = []
-    for _ in range(NF):     # one handle (own activations + stream) per frame in flight; weights replicated
-        if args.arch == "res50":
-            n = importlib.import_module("face-detection-and-tracking_amd.pyramid").SFD(device=local_rank)
-            n.priorbox = layers.PriorBoxLayer(W, H)
-        else:
-            n = importlib.import_module("face-detection-and-tracking_amd.pyramid_mb2_try3").SFD_mobile(device=local_rank)
-            n.priorbox = layers.PriorBoxLayer(W, H, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256))
-        n.load_state_dict(sd)
-        n.cuda(); n.eval()
-        n._sync_attributes(H, W)
-        plan_file = os.path.join(ROOT, "face-detection-and-tracking_amd", "tuned",
-                                 "%s_%dx%d_b%d.plan" % (args.arch, W, H, B))
-        if args.autotune == 1 and os.path.exists(plan_file):
-            n.import_plan(open(plan_file).read())      # committed result of an earlier autotune on MI355X
-            plan_src = "tuned/" + os.path.basename(plan_file)
-        elif args.autotune:
-            # plan-time measurement of every (tile, split-K) variant per layer; outside the timed region
-            n(synth.make_frames(B, H, W, seed=99) if B > 1 else synth.make_frames(1, H, W, seed=99)[0])
-            n.autotune(3)
-            plan_src = "autotuned at start-up"
-            if args.save_plan and not nets:
-                with open(plan_file, "w") as f:
-                    f.write(n.export_plan())
-        else:
-            plan_src = "analytic model"
-        nets.append(n)
-    net = nets[0]
-    top_k = net.detect.top_k
+    if args.arch == "res50":
+        net = importlib.import_module("face-detection-and-tracking_amd.pyramid").SFD(device=local_rank)
+        net.priorbox = layers.PriorBoxLayer(W, H)
+    else:
+        net = importlib.import_module("face-detection-and-tracking_amd.pyramid_mb2_try3").SFD_mobile(device=local_rank)
+        net.priorbox = layers.PriorBoxLayer(W, H, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256))
+    net.load_state_dict(sd)      # ONE weight copy per GPU: the other in-flight handles are fdt_model_clone()s
+    net.cuda(); net.eval()
+    net.enable_graph(bool(args.graph))
+    net._sync_attributes(H, W)
+    plan_file = os.path.join(ROOT, "face-detection-and-tracking_amd", "tuned", "%s_%dx%d_b%d.plan" % (args.arch, W, H, B))
+    plan_text = None
+    if args.autotune == 1 and os.path.exists(plan_file):
+        plan_text = open(plan_file).read()           # committed result of an earlier autotune on MI355X
+        plan_src = "tuned/" + os.path.basename(plan_file)
+    elif args.autotune:
+        # plan-time measurement of every (tile, split-K) variant per layer; outside the timed region
+        net(synth.make_frames(B, H, W, seed=99) if B > 1 else synth.make_frames(1, H, W, seed=99)[0])
+        net.autotune(3)
+        plan_text = net.export_plan()
+        plan_src = "autotuned at start-up"
+        if args.save_plan and rank == 0:
+            with open(plan_file, "w") as f:
+                f.write(plan_text)
+    else:
+        plan_src = "analytic model"
+
+    # the one exchange of the path: RCCL all-gather behind the C ABI (fdt_allgather_dets); torch.distributed only ships
+    # the 128-byte communicator id and does the barrier / max-over-ranks of the timing
+    exch_kind = os.environ.get("FDT_BENCH_EXCHANGE", "rccl-cabi" if backend == "nccl" else "torch")
+    comm = par.make_rccl_comm(rank, world, local_rank) if (world > 1 and exch_kind == "rccl-cabi") else None
+
+    def make_exchange(rec):
+        if comm is not None:
+            return par.RcclExchange(rank, world, rec, dev, comm=comm)
+        return par.FrameParallel(rank, world, rec, dev)
+
+    SH, SW = (int(v) for v in args.source.lower().split("x")) if args.source else (H, W)
+    pipe = pipeline.DetectTrackPipeline(net, H, W, dev, inflight=NF, batch=B, exchange_factory=make_exchange, world=world,
+                                        rank=rank, source_hw=(SH, SW) if args.source else None, plan_text=plan_text)
+    top_k = pipe.top_k
+    REC = pipe.REC
 
     # synthetic frames, resident in HBM before the timed region
     U = (max(args.unique_frames, B) + B - 1) // B * B          # whole batches
-    SH, SW = (int(v) for v in args.source.lower().split("x")) if args.source else (H, W)
     frames_h = synth.make_frames(U, SH, SW, seed=1234 + rank)
     frames_d = torch.from_numpy(frames_h).to(dev)
-    REC = 2 * top_k * 5                                       # one frame's Detect record
-    fps = [par.FrameParallel(rank, world, B * REC, dev) for _ in range(NF)]
-    counts = torch.zeros(2 * B, dtype=torch.int32, device=dev)
-    tracker = trk.IouTracker(0.4, 0.6, 5, max_dets=2 * top_k, log_frames=64)
-    # non-default torch streams: their handles go through the C ABI, so torch.cuda.Event brackets and the
-    # RCCL collective are ordered with the library's launches.  One stream per frame in flight for the
-    # detector, one for the (strictly sequential) exchange + association.
-    det_streams = [torch.cuda.Stream(device=dev) for _ in range(NF)]
-    trk_stream = torch.cuda.Stream(device=dev)
-    sp_det = [ctypes.c_void_p(s_.cuda_stream) for s_ in det_streams]
-    sp_trk = ctypes.c_void_p(trk_stream.cuda_stream)
-    assert all(p_.value for p_ in sp_det) and sp_trk.value, "need real stream handles"
-    det_done = [torch.cuda.Event() for _ in range(NF)]
-    trk_done = [torch.cuda.Event() for _ in range(NF)]
     L = lib.lib()
 
-    def step(i):
-        k = i % NF
-        f = frames_d[(i * B) % U:(i * B) % U + B]
-        fp = fps[k]
-        with torch.cuda.stream(det_streams[k]):
-            det_streams[k].wait_event(trk_done[k])        # slot k's record was consumed (step i - NF)
-            if args.source:     # raw source frames: resize + mean subtraction in one kernel, then the forward
-                lib.check(L.fdt_model_forward_resized(nets[k]._h, ctypes.c_void_p(f.data_ptr()), 1, B, SH, SW, H, W,
-                                                      ctypes.c_void_p(fp.mine.data_ptr()),
-                                                      ctypes.c_void_p(counts.data_ptr()), sp_det[k]))
-            else:
-                lib.check(L.fdt_model_forward_dev(nets[k]._h, ctypes.c_void_p(f.data_ptr()), lib.FRAME_U8_HWC_BGR, B,
-                                                  H, W, ctypes.c_void_p(fp.mine.data_ptr()),
-                                                  ctypes.c_void_p(counts.data_ptr()), sp_det[k]))
-            det_done[k].record(det_streams[k])
-        with torch.cuda.stream(trk_stream):
-            trk_stream.wait_event(det_done[k])
-            # the one exchange step of the path: fixed-size per-frame box lists, rank order == frame order
-            g = fp.exchange()
-            for r in range(world):            # rank order == frame order; B consecutive frames per rank
-                for b in range(B):
-                    tracker.step_dev(ctypes.c_void_p(g[r].data_ptr() + 4 * b * REC), 2, top_k, W, H, 0.4, sp_trk)
-            trk_done[k].record(trk_stream)
+    def frames_of(i):
+        o = (i * B) % U
+        return frames_d[o:o + B]
 
     def sync_all():
         torch.cuda.synchronize()
@@ -239,15 +281,15 @@ def main():
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        step(i)
+        pipe.step(i, frames_of(i))
     sync_all()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    e0.record(trk_stream)
+    e0.record(pipe.trk_stream)
     for i in range(args.steps):
-        step(args.warmup + i)
-    e1.record(trk_stream)
+        pipe.step(args.warmup + i, frames_of(args.warmup + i))
+    e1.record(pipe.trk_stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -258,76 +300,140 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    n_cand_last = int(counts.cpu()[1])
-    tracks = tracker.finish()
-    mine = fps[0].mine
-    stream = sp_det[0]
-    torch.cuda.set_stream(det_streams[0])
+    n_cand_last = int(pipe.counts[(args.warmup + args.steps - 1) % NF].cpu()[1])
+    tracks = pipe.finish()
+    mine = pipe.fps[0].mine
+    counts0 = pipe.counts[0]
+    stream = pipe.sp_det[0]
+    torch.cuda.set_stream(pipe.det_streams[0])
 
-    # ---- per-launch timing of the dominant kernel (HIP events on the same stream) ---------------
+    def forward_dev(i):
+        f = frames_of(i)
+        if args.source:
+            lib.check(L.fdt_model_forward_resized(net._h, ctypes.c_void_p(f.data_ptr()), 1, B, SH, SW, H, W,
+                                                  ctypes.c_void_p(mine.data_ptr()), ctypes.c_void_p(counts0.data_ptr()),
+                                                  stream))
+        else:
+            lib.check(L.fdt_model_forward_dev(net._h, ctypes.c_void_p(f.data_ptr()), lib.FRAME_U8_HWC_BGR, B, H, W,
+                                              ctypes.c_void_p(mine.data_ptr()), ctypes.c_void_p(counts0.data_ptr()),
+                                              stream))
+
+    # ---- parity of the TIMED loop: the same steps again, one frame at a time, fully synchronous ---------------------
+    # (single rank: every rank of an N > 1 run sees all frames through the exchange, which the gloo / RCCL tests pin)
+    tracks_equal = None
+    if rank == 0 and world == 1:
+        trk = importlib.import_module("face-detection-and-tracking_amd.tracker")
+        seq = trk.IouTracker(0.4, 0.6, 5, max_dets=2 * top_k, log_frames=256)
+        for i in range(args.warmup + args.steps):
+            forward_dev(i)
+            for b in range(B):
+                seq.step_dev(ctypes.c_void_p(mine.data_ptr() + 4 * b * REC), 2, top_k, W, H, 0.4, stream)
+            torch.cuda.synchronize()
+        seq_tracks = seq.finish()
+        tracks_equal = (len(seq_tracks) == len(tracks) and
+                        all(a["start_frame"] == b["start_frame"] and a["max_score"] == b["max_score"] and
+                            a["bboxes"] == b["bboxes"] for a, b in zip(seq_tracks, tracks)))
+        seq.close()
+
+    # ---- per-launch timing (HIP events around every launch on the stream the kernels run on) -------------------------
     roof = None
     if rank == 0:
         net.profile(True)
-        conv_ms, other_ms, flops = [], [], 0.0
-        dw_stats = []
+        per_frame = []
         for i in range(args.profile_frames + 1):
-            if args.source:
-                lib.check(L.fdt_model_forward_resized(net._h, ctypes.c_void_p(frames_d[(i * B) % U:].data_ptr()), 1, B,
-                                                      SH, SW, H, W, ctypes.c_void_p(mine.data_ptr()),
-                                                      ctypes.c_void_p(counts.data_ptr()), stream))
-            else:
-                lib.check(L.fdt_model_forward_dev(net._h, ctypes.c_void_p(frames_d[(i * B) % U:].data_ptr()),
-                                                  lib.FRAME_U8_HWC_BGR, B, H, W, ctypes.c_void_p(mine.data_ptr()),
-                                                  ctypes.c_void_p(counts.data_ptr()), stream))
+            forward_dev(i)
             torch.cuda.synchronize()
             prof = net.profile_read()
-            if i == 0:
-                continue      # first profiled frame creates the events
-            conv_ms.append(sum(ms for nm, ms, fl in prof if "#k" in nm))
-            other_ms.append(sum(ms for nm, ms, fl in prof if "#k" not in nm))
-            flops = sum(fl for nm, ms, fl in prof if "#k" in nm)
-            n_conv = sum(1 for nm, ms, fl in prof if "#k" in nm)
-            if args.arch == "try3":
-                # the depthwise 3x3 layers (HBM-bound by construction: in + out bytes, nothing else).  A depthwise op
-                # has 18 FLOP per output element, so its output size follows from its FLOPs; the input is stride^2
-                # times that (strides: pyramid_mb2_try3.py:150-168, layer6 :178).
-                s2 = {"features.%d.conv.3" % i for i, _, _, st, _ in synth.try3_blocks() if st == 2} | {"layer6.conv.3"}
-                dwb = dwm = 0.0
-                for nm, ms, fl in prof:
-                    if "#k" not in nm and (nm.startswith("features.") or nm.startswith("layer6.")) and fl > 0:
-                        out_el = fl / 18.0
-                        dwb += 4.0 * out_el * (1 + (4 if nm in s2 else 1))
-                        dwm += ms
-                dw_stats.append((dwb, dwm))
+            if i:
+                per_frame.append(prof)       # the first profiled frame creates the events
         net.profile(False)
-        cms = float(np.mean(conv_ms))
-        achieved = flops / (cms * 1e-3) / 1e12
-        # HBM bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-        # command (PMC cannot be read from inside the process); the committed summary is quoted here.
-        traffic, traffic_src, traffic_cal = None, None, None
-        tj = os.path.join(ROOT, "profiles", "r01", "conv_hbm_traffic.json")
-        if args.arch == "res50" and H == 1024 and os.path.exists(tj):
-            tdata = json.load(open(tj))
-            traffic = round(tdata["hbm_bytes_per_launch"])
-            if tdata.get("hbm_bytes_per_launch_calibrated"):
-                traffic_cal = round(tdata["hbm_bytes_per_launch_calibrated"])
-            traffic_src = "profiles/r01/conv_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
-        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "traffic_calibrated": traffic_cal,     # FETCH_SIZE divided by its measured per-byte reading on this
-                                                       # code's LDS-DMA pattern instead of doubled (see the JSON note)
-                "algorithmic_bytes_per_launch": round((3.52e9 + 0.2688e9) / 105) if args.arch == "res50" and H == 1024 and W == 1024 else None,
-                "kernel": "conv_kernel (f32 MFMA implicit GEMM)", "launches_per_frame": n_conv,
-                "avg_launch_us": round(cms * 1e3 / n_conv, 2), "conv_ms_per_frame": round(cms / B, 3),
-                "other_ms_per_frame": round(float(np.mean(other_ms)) / B, 3),
-                "algorithmic_gflop_per_frame": round(flops / B / 1e9, 3)}
-        if dw_stats and dw_stats[-1][1] > 0:      # config 3: state the HBM side too
-            dwb = float(np.mean([d[0] for d in dw_stats]))
-            dwm = float(np.mean([d[1] for d in dw_stats]))
+        nprof = len(per_frame)
+        ops = {}                              # op index -> [name, mean ms, flops]
+        for prof in per_frame:
+            for j, (nm, ms, fl) in enumerate(prof):
+                o = ops.setdefault(j, [nm, 0.0, fl])
+                o[1] += ms / nprof
+        groups = {}                           # (kind, tile) -> [launches, ms, algorithmic flops, executed flops]
+        conv_ms = other_ms = alg = exe = 0.0
+        n_conv = 0
+        dwb = dwm = 0.0
+        s2 = ({"features.%d.conv.3" % i for i, _, _, st_, _ in synth.try3_blocks() if st_ == 2} | {"layer6.conv.3"}
+              if args.arch == "try3" else set())
+        for nm, ms, fl in ops.values():
+            layer, kind, tile, split = parse_op(nm)
+            if kind is None:
+                other_ms += ms
+                # depthwise 3x3 layers of try3 (HBM-bound by construction: in + out bytes, nothing else).  A depthwise op
+                # has 18 FLOP per output element; the input is stride^2 times the output (pyramid_mb2_try3.py:150-178)
+                if args.arch == "try3" and (layer.startswith("features.") or layer.startswith("layer6.")) and fl > 0:
+                    dwb += 4.0 * (fl / 18.0) * (1 + (4 if layer in s2 else 1))
+                    dwm += ms
+                continue
+            ex = fl / WINO_RATIO if kind in WINO_KINDS else fl
+            g = groups.setdefault((kind, tile), [0, 0.0, 0.0, 0.0])
+            g[0] += 1; g[1] += ms; g[2] += fl; g[3] += ex
+            conv_ms += ms; alg += fl; exe += ex; n_conv += 1
+        (dk, dt_), dg = max(groups.items(), key=lambda kv: kv[1][1])
+        # HBM bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (PMC
+        # cannot be read from inside the process); the committed summary of the current round is quoted here.
+        traffic = traffic_src = traffic_cal = None
+        for rnd in ("r02", "r01"):
+            tj = os.path.join(ROOT, "profiles", rnd, "conv_hbm_traffic.json")
+            if args.arch == "res50" and H == 1024 and W == 1024 and os.path.exists(tj):
+                tdata = json.load(open(tj))
+                traffic = round(tdata["hbm_bytes_per_launch"])
+                if tdata.get("hbm_bytes_per_launch_calibrated"):
+                    traffic_cal = round(tdata["hbm_bytes_per_launch_calibrated"])
+                traffic_src = "profiles/%s/conv_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, all conv " \
+                              "kernels, bytes/launch)" % rnd
+                break
+        tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        step_ms = dt / args.steps * 1e3
+        roof = {
+            "bound": "mfma",
+            # the dominant kernel by measured time, with the MFMA work it EXECUTES (Winograd F(2x2,3x3) layers do
+            # 1/2.25 of the direct-convolution MACs): frac is matrix-pipe utilisation and cannot exceed 1
+            "kernel": kernel_label(dk, dt_),
+            "achieved": round(tf(dg[3], dg[1]), 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf(dg[3], dg[1]) / PEAK_F32_MFMA_TFLOPS, 4),
+            "frac_executed": round(tf(dg[3], dg[1]) / PEAK_F32_MFMA_TFLOPS, 4),
+            "achieved_algorithmic": round(tf(dg[2], dg[1]), 2),
+            "frac_algorithmic": round(tf(dg[2], dg[1]) / PEAK_F32_MFMA_TFLOPS, 4),
+            "launches_per_frame": dg[0], "avg_launch_us": round(dg[1] * 1e3 / dg[0], 2),
+            "time_share_of_convs": round(dg[1] / conv_ms, 4),
+            "algorithmic_gflop_per_launch": round(dg[2] / dg[0] / 1e9, 3),
+            "executed_gflop_per_launch": round(dg[3] / dg[0] / 1e9, 3),
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_calibrated": traffic_cal,
+            "algorithmic_bytes_per_launch": round((3.52e9 + 0.2688e9) / 105) if args.arch == "res50" and H == 1024 and W == 1024 else None,
+            # all conv launches of a frame (serial profile pass on one stream)
+            "conv_stack": {"launches_per_frame": n_conv, "ms_per_frame": round(conv_ms / B, 3),
+                           "algorithmic_gflop_per_frame": round(alg / B / 1e9, 3),
+                           "executed_gflop_per_frame": round(exe / B / 1e9, 3),
+                           "achieved_executed": round(tf(exe, conv_ms), 2),
+                           "frac_executed": round(tf(exe, conv_ms) / PEAK_F32_MFMA_TFLOPS, 4),
+                           "achieved_algorithmic": round(tf(alg, conv_ms), 2),
+                           "frac_algorithmic": round(tf(alg, conv_ms) / PEAK_F32_MFMA_TFLOPS, 4),
+                           "other_ms_per_frame": round(other_ms / B, 3)},
+            # the timed region itself (frames overlap on several streams): FLOPs of a step / ms_per_step
+            "timed_step": {"ms_per_step": round(step_ms, 4),
+                           "achieved_executed": round(tf(exe, step_ms), 2),
+                           "frac_executed": round(tf(exe, step_ms) / PEAK_F32_MFMA_TFLOPS, 4),
+                           "achieved_algorithmic": round(tf(alg, step_ms), 2),
+                           "frac_algorithmic": round(tf(alg, step_ms) / PEAK_F32_MFMA_TFLOPS, 4)},
+            "by_kernel": [{"kernel": kernel_label(k, t), "launches": g[0], "ms": round(g[1], 4),
+                           "executed_tflops": round(tf(g[3], g[1]), 1), "algorithmic_tflops": round(tf(g[2], g[1]), 1)}
+                          for (k, t), g in sorted(groups.items(), key=lambda kv: -kv[1][1])[:6]],
+        }
+        if dwm > 0:      # config 3: state the HBM side too
             roof["hbm_side"] = {"bound": "hbm", "kernel": "dwconv3_vec_kernel (depthwise 3x3 + BN + ReLU6)",
                                 "achieved": round(dwb / (dwm * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                 "frac": round(dwb / (dwm * 1e-3) / 1e9 / 8000.0, 4),
                                 "algorithmic_bytes_per_frame": round(dwb / B), "ms_per_frame": round(dwm / B, 4)}
+
+    # ---- PCIe-inclusive rate: pageable host frames through the pipelined async ingest (never `value`) ---------------
+    host_path = None
+    if rank == 0 and world == 1 and args.host_frames > 0 and B == 1:
+        host_path = host_frames_rate(args, lib, pipe, frames_h, H, W, SH, SW)
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample ---------------------------
     cpu, parity = None, None
@@ -335,36 +441,65 @@ def main():
         from oracle import postproc as opp
         from oracle import pyramidbox as opb
         from oracle import ingest as oin
-        ncores = torch.get_num_threads()
-        ref_trk = opp.IouTracker(0.4, 0.6, 5)
-        times, ref_dets, gpu_dets = [], [], []
-        for i in range(args.cpu_frames):
-            t1 = time.perf_counter()
+        model, phys, logical = cpu_info()
+
+        def cpu_frame(i, trk_=None):
             src = frames_h[i % U]
             if args.source:       # the oracle's restatement of cv2.resize(image, (W, H)) (8-bit INTER_LINEAR)
                 src = oin.resize_linear_u8(src, W, H)
             y = opb.detect_frame(sd, src, args.arch)
-            det_ref = opp.unpack_detections(y, W, H, 0.4)
-            with np.errstate(all="ignore"):
-                ref_trk.step(det_ref)
+            det = opp.unpack_detections(y, W, H, 0.4)
+            if trk_ is not None:
+                with np.errstate(all="ignore"):
+                    trk_.step(det)
+            return det
+
+        default_threads = torch.get_num_threads()
+        sweep = {}
+        if args.cpu_threads == "sweep":
+            cand = sorted({t for t in (8, 16, 32, 64, phys, default_threads) if 1 <= t <= logical})
+            cpu_frame(0)                                   # warm-up (allocator, oneDNN primitive cache)
+            for t in cand:
+                torch.set_num_threads(t)
+                t1 = time.perf_counter()
+                cpu_frame(1)
+                sweep[t] = time.perf_counter() - t1
+            best_t = min(sweep, key=sweep.get)
+        else:
+            best_t = max(1, min(int(args.cpu_threads), logical))
+        torch.set_num_threads(best_t)
+        ref_trk = opp.IouTracker(0.4, 0.6, 5)
+        times, ref_dets, gpu_dets = [], [], []
+        for i in range(args.cpu_frames):
+            t1 = time.perf_counter()
+            det_ref = cpu_frame(i, ref_trk)
             times.append(time.perf_counter() - t1)
             # parity of the same frames on the GPU path (checker only; not timed)
             yg = (net.forward_resized(frames_h[i % U], (W, H)) if args.source else net(frames_h[i % U])).numpy()
             ref_dets.append(det_ref)
             gpu_dets.append(opp.unpack_detections(yg, W, H, 0.4))
-        ap, n_truth, n_pred = opp.ap_against_reference(gpu_dets, ref_dets, 0.5)
+        torch.set_num_threads(default_threads)
+        ap_, n_truth, n_pred = opp.ap_against_reference(gpu_dets, ref_dets, 0.5)
         iou_def = 0.0
         for g, r in zip(gpu_dets, ref_dets):
             if g.shape == r.shape and r.shape[0]:
                 with np.errstate(all="ignore"):
                     iou_def = max(iou_def, float((1 - opp.calculate_iou(r[:, :4].astype(np.float64),
                                                                          g[:, :4].astype(np.float64)).max(1)).max()))
-        parity = {"ap_vs_cpu_ref": round(ap, 6), "ref_boxes": n_truth, "gpu_boxes": n_pred,
-                  "max_iou_deficit": float("%.3g" % iou_def), "frames": len(ref_dets)}
+        parity = {"ap_vs_cpu_ref": round(ap_, 6), "ref_boxes": n_truth, "gpu_boxes": n_pred,
+                  "max_iou_deficit": float("%.3g" % iou_def), "frames": len(ref_dets),
+                  "tracks_equal": tracks_equal,
+                  "tracks_equal_note": "track list of the TIMED multi-stream loop == the same %d steps re-run one frame at a "
+                                       "time, synchronously (bitwise)" % (args.warmup + args.steps)}
         per = float(np.mean(times[1:])) if len(times) > 1 else times[0]
-        cpu = {"value": round(1.0 / per, 4), "unit": "frames/s", "cores": ncores, "kind": "port",
-               "sample": "%d frames of the same %dx%d workload after 1 warm-up (oracle/: torch-CPU convs + numpy "
-                         "Detect + tracker), %.2f s/frame" % (max(len(times) - 1, 1), H, W, per)}
+        cpu = {"value": round(1.0 / per, 4), "unit": "frames/s", "cores": best_t, "kind": "port",
+               "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
+               "thread_sweep_s_per_frame": {str(k): round(v, 3) for k, v in sorted(sweep.items())} or None,
+               "sample": "%d frames of the same %dx%d workload after a warm-up (oracle/: torch-CPU convs + numpy "
+                         "Detect + tracker) at the best thread count of the sweep, %.2f s/frame"
+                         % (max(len(times) - 1, 1), H, W, per)}
+    elif rank == 0 and world == 1:
+        parity = {"tracks_equal": tracks_equal}
 
     if rank == 0:
         frames = args.steps * world * B
@@ -385,19 +520,76 @@ def main():
                                    "on device" % ("Res50" if args.arch == "res50" else "MobileNetV2-try3", W, H,
                                                   " resized on the GPU from %dx%d sources" % (SW, SH) if args.source else "",
                                                   B),
-                       "frames_per_step": world * B, "frames_in_flight_per_gpu": NF, "kernel_plan": plan_src, "parallelism": "frame-parallel x%d%s" % (
-                           world, ", RCCL all-gather of box lists" if world > 1 else ""),
+                       "frames_per_step": world * B, "frames_in_flight_per_gpu": NF, "kernel_plan": plan_src,
+                       "hip_graph": bool(args.graph), "weight_copies_per_gpu": 1,
+                       "parallelism": "frame-parallel x%d%s" % (
+                           world, (", all-gather of box lists: " + ("RCCL via fdt_allgather_dets (C ABI)" if comm is not None
+                                                                    else "torch.distributed " + backend)) if world > 1 else ""),
                        "weights": "seeded synthetic (seed 0)", "detections_last_frame": n_cand_last,
                        "tracks": len(tracks), "gpu_ms_per_step_events": round(gpu_ms / args.steps, 4),
                        "device": pkg.device_name(local_rank)},
             "roofline": roof,
             "cpu_baseline": cpu,
             "parity": parity,
+            "host_path": host_path,
         }
         print(json.dumps(line))
+    pipe.close()
+    if comm is not None:
+        L.fdt_comm_destroy(comm)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def host_frames_rate(args, lib, pipe, frames_h, H, W, SH, SW):
+    """Frames handed over as pageable HOST buffers (what iouTracke_cal.py:119-124 has after cv2.read): pinned staging
+    ring + copy stream + forward + tracker, `inflight` handles each with 2 tickets in flight."""
+    import torch
+    L = lib.lib()
+    trk = importlib.import_module("face-detection-and-tracking_amd.tracker")
+    tracker = trk.IouTracker(0.4, 0.6, 5, max_dets=2 * pipe.top_k, log_frames=256)
+    NF, U = pipe.NF, frames_h.shape[0]
+    n = args.host_frames
+    pending = []                     # (net index, ticket) in frame order
+    sp = pipe.sp_trk
+
+    def issue(i):
+        k = i % NF
+        t = ctypes.c_int(0)
+        f = frames_h[i % U]
+        lib.check(L.fdt_model_forward_async(pipe.nets[k]._h, lib.ptr(f), lib.FRAME_U8_HWC_BGR, 1, H, W,
+                                            SH if args.source else 0, SW if args.source else 0, ctypes.byref(t)))
+        pending.append((k, t.value))
+
+    def retire():
+        k, t = pending.pop(0)
+        rec = ctypes.c_void_p(0)
+        lib.check(L.fdt_model_async_record(pipe.nets[k]._h, t, ctypes.byref(rec), sp))   # tracker stream waits on device
+        tracker.step_dev(rec, 2, pipe.top_k, W, H, 0.4, sp)
+        lib.check(L.fdt_model_wait(pipe.nets[k]._h, t, None, None, sp))                   # slot reusable after the tracker
+
+    depth = 2 * NF
+    for i in range(min(depth, 8)):       # warm-up
+        issue(i)
+    while pending:
+        retire()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        if len(pending) >= depth:
+            retire()
+        issue(i)
+    while pending:
+        retire()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tracks = tracker.finish()
+    tracker.close()
+    return {"value": round(n / dt, 2), "unit": "frames/s", "frames": n, "ms_per_frame": round(dt / n * 1e3, 3),
+            "tracks": len(tracks),
+            "what": "PCIe-inclusive: pageable host u8 frames -> pinned ring -> H2D on a copy stream -> forward -> "
+                    "device-resident tracker; %d handles x 2 tickets in flight (fdt_model_forward_async / fdt_model_wait)" % NF}
 
 
 if __name__ == "__main__":

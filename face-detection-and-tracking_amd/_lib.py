@@ -39,6 +39,7 @@ SIGNATURES = {
     "fdt_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "fdt_set_device": (C.c_int, [C.c_int]),
     "fdt_device_synchronize": (C.c_int, []),
+    "fdt_device_mem_info": (C.c_int, [_c_i64_p, _c_i64_p]),
     "fdt_priorbox": (C.c_int, [C.c_int] * 5 + [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     "fdt_decode": (C.c_int, [_vp, _vp, C.c_int, C.c_float, C.c_float, _vp]),
     "fdt_nms": (C.c_int, [_vp, _vp, C.c_int, C.c_float, C.c_int, _vp, _c_int_p]),
@@ -58,12 +59,24 @@ SIGNATURES = {
     "fdt_tracker_reset": (C.c_int, [_vp]),
     "fdt_tracker_step": (C.c_int, [_vp, _vp, C.c_int]),
     "fdt_tracker_step_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
+    "fdt_tracker_step_dev_multi": (C.c_int, [_vp, _vp, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                             _vp]),
     "fdt_tracker_finish": (C.c_int, [_vp]),
     "fdt_tracker_num_tracks": (C.c_int, [_vp, _c_int_p]),
     "fdt_tracker_track_info": (C.c_int, [_vp, C.c_int, _c_int_p, _c_f64_p, _c_int_p]),
     "fdt_tracker_track_boxes": (C.c_int, [_vp, C.c_int, _vp]),
     "fdt_model_create": (_vp, [C.c_int, C.c_int]),
     "fdt_model_destroy": (None, [_vp]),
+    "fdt_model_clone": (_vp, [_vp]),
+    "fdt_model_enable_graph": (C.c_int, [_vp, C.c_int]),
+    "fdt_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "fdt_comm_init_rank": (_vp, [C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "fdt_comm_init_all": (_vp, [C.c_int, _c_int_p]),
+    "fdt_comm_world": (C.c_int, [_vp, _c_int_p, _c_int_p]),
+    "fdt_comm_group_begin": (C.c_int, []),
+    "fdt_comm_group_end": (C.c_int, []),
+    "fdt_allgather_dets": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_longlong, _vp]),
+    "fdt_comm_destroy": (None, [_vp]),
     "fdt_model_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int, _c_i64_p]),
     "fdt_model_missing": (C.c_int, [_vp, _c_int_p]),
     "fdt_model_missing_name": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int]),
@@ -74,6 +87,9 @@ SIGNATURES = {
     "fdt_model_forward_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "fdt_model_forward_resized": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
                                             _vp]),
+    "fdt_model_forward_async": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _c_int_p]),
+    "fdt_model_async_record": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _vp]),
+    "fdt_model_wait": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "fdt_model_forward_raw": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "fdt_model_detect_facebox": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                            _vp, _vp, _vp]),

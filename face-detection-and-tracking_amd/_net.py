@@ -38,6 +38,24 @@ class DetectorNet:
         self._sd_cache = None
         self._prior_shape = None
 
+    def clone(self):
+        """A second handle for another frame in flight: own stream / activations / plan, SHARED device weights
+        (fdt_model_clone).  Attribute objects (.priorbox, .detect) are shared references like a shallow module copy."""
+        if not self._loaded:
+            raise RuntimeError("weights not loaded: call load_state_dict / load_weights first")
+        c = object.__new__(type(self))
+        c.__dict__.update(self.__dict__)
+        c._h = _lib.lib().fdt_model_clone(self._h)
+        if not c._h:
+            raise _lib.FdtError(_lib.FDT_ERR_HIP, (_lib.lib().fdt_last_error() or b"").decode())
+        c.firstTime = True
+        c._prior_shape = None
+        return c
+
+    def enable_graph(self, on=True):
+        """Replay the forward as a captured HIP graph (default on)."""
+        _lib.check(_lib.lib().fdt_model_enable_graph(self._h, 1 if on else 0))
+
     # ---- nn.Module surface the reference's callers touch ------------------------------------
     def cuda(self, device=None):
         return self
@@ -96,7 +114,10 @@ class DetectorNet:
         return self
 
     def load_weights(self, base_file):
-        """reference pyramid.py:353-364: keep only the keys the model knows."""
+        """reference pyramid.py:353-364: `model_dict.update({k: v for k in pretrained if k in model_dict})` -- unknown
+        keys are dropped silently.  The reference also keeps keys the file lacks at their random initial values; a
+        detector with random layers is never what an inference caller wants, so here missing keys still raise (the
+        message lists them) instead of silently producing garbage."""
         print('Loading weights into state dict...')
         sd = torch.load(base_file, map_location='cpu', weights_only=True)
         self.load_state_dict(sd, strict=False)

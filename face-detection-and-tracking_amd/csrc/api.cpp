@@ -39,3 +39,11 @@ extern "C" int fdt_device_synchronize(void) {
   FDT_HIP(hipDeviceSynchronize());
   return FDT_OK;
 }
+
+extern "C" int fdt_device_mem_info(long long* free_bytes, long long* total_bytes) {
+  size_t f = 0, t = 0;
+  FDT_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (long long)f;
+  if (total_bytes) *total_bytes = (long long)t;
+  return FDT_OK;
+}

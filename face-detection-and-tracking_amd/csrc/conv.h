@@ -91,7 +91,7 @@ struct ConvArgs {
   int out_ctot, out_coff, res_ctot, res_coff, up_h, up_w;
   int act;
   int ksplit;             // >= 1: split the input-channel reduction over this many workgroups
-  float* ws;              // split-K workspace, B*ksplit*Cout*Hout*Wout floats (ksplit > 1)
+  float* ws;              // split-K workspace, B*ksplit*Cout*Hout*Wout floats (ksplit > 1, or `up` on a Winograd tile)
   // workgroup -> (spatial tile, output-channel tile) map (FDT_BLOCK_MAP below): map_mode is the caller's choice
   // (CONV_MAP_*), n_sp / n_ct are filled in by launch_conv
   int map_mode, n_sp, n_ct;
@@ -126,6 +126,32 @@ enum { CONV_MAP_ROWS = 0, CONV_MAP_XCD_SPATIAL = 1, CONV_MAP_XCD_CHANNEL = 2 };
     if (s_ >= (a_).n_sp || n_ >= (a_).n_ct) return;                             \
   }
 
+// Bilinear x2 upsample (align_corners=False, F.interpolate of pyramid.py:65) of the coarser map `u` [up_h][up_w] at the
+// 4 consecutive output pixels (oy, ox0 .. ox0+3), added to v[0..3]: the fused `+ up` of ContextTexture.forward
+// (pyramid.py:66-68).  One row lookup per call; same operand order in the conv epilogue and in splitk_reduce_kernel.
+template <int VEC>
+__device__ __forceinline__ void add_upsampled_x2(const float* __restrict__ u, int up_h, int up_w, int oy, int ox0,
+                                                 float* v) {
+  const float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.0f);
+  int y0 = (int)sy;
+  y0 = y0 < up_h - 1 ? y0 : up_h - 1;
+  const int y1 = y0 + (y0 < up_h - 1 ? 1 : 0);
+  const float ly = sy - (float)y0;
+  const float* u0 = u + y0 * up_w;
+  const float* u1 = u + y1 * up_w;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const float sx = fmaxf(0.5f * (ox0 + e + 0.5f) - 0.5f, 0.0f);
+    int x0 = (int)sx;
+    x0 = x0 < up_w - 1 ? x0 : up_w - 1;
+    const int x1 = x0 + (x0 < up_w - 1 ? 1 : 0);
+    const float lx = sx - (float)x0;
+    const float top = (1.0f - lx) * u0[x0] + lx * u0[x1];
+    const float bot = (1.0f - lx) * u1[x0] + lx * u1[x1];
+    v[e] += (1.0f - ly) * top + ly * bot;
+  }
+}
+
 // Workspace floats a split-K launch needs.
 long long conv_ws_floats(const ConvArgs& a);
 
@@ -137,7 +163,9 @@ void tile_weights(const float* w_oihw, const float* scale, int Cout, int Cin, Co
 // FLOPs (2*MAC) of one launch, algorithmic (no padding).
 double conv_flops(const ConvArgs& a, ConvKind kind);
 
-int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a, hipStream_t st);
+// `device`: the HIP device `st` belongs to (< 0: ask the runtime); only used to set the per-(function, device)
+// dynamic-LDS attribute once.
+int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a, hipStream_t st, int device = -1);
 bool conv_supported(ConvKind kind, ConvTile tile);
 
 }  // namespace fdt

@@ -18,11 +18,14 @@
 //    so global->LDS traffic is ~1.4x the input instead of 9x for a 3x3.
 //  * Weights are pre-tiled on the host to [n_tile][stage][KC][taps][BN]: each stage is one contiguous,
 //    16-byte-vectorised stream.
-//  * Register-staged double buffering: stage s+1's global loads are issued before stage s's MFMAs and
-//    written to the other LDS buffer after them; one barrier per stage.  256 threads = 4 waves (one per
-//    SIMD); 2-3 workgroups per CU hide the rest of the latency.
-//  * Fused epilogue: + bias (folded BN), + residual, + bilinear-upsampled coarser map, ReLU/ReLU6,
-//    direct write into a channel slice of the destination (kills torch.cat / permute).
+//  * Both operands arrive by LDS-DMA (global_load_lds_dword / _dwordx4): nothing is staged in VGPRs.  LDS is a
+//    ring of 2-4 stages; stage i is retired with a counted s_waitcnt vmcnt(N) + raw s_barrier so that the
+//    newer stages stay in flight.  256 threads = 4 waves (one per SIMD); 2-3 workgroups per CU hide the rest.
+//  * Fused epilogue: + bias (folded BN), + residual, + bilinear-upsampled coarser map (in the conv epilogue
+//    itself when the layer is not split along K, else in splitk_reduce_kernel), ReLU/ReLU6, direct write into
+//    a channel slice of the destination (kills torch.cat / permute).
+#include <atomic>
+
 #include "conv_kernel.h"
 #include "conv_wino.h"
 
@@ -59,27 +62,9 @@ __global__ void splitk_reduce_kernel(const ConvArgs a) {
 #pragma unroll
   for (int e = 0; e < VEC; ++e) v[e] += bv;
   if (a.up) {
-    const float* u = a.up + ((long long)b * a.Cout + co) * a.up_h * a.up_w;
-    // the VEC pixels of a thread sit in one output row (VEC == 4 only when Wout % 4 == 0): one row lookup per thread
-    const int oy = pix / a.Wout, ox0 = pix - oy * a.Wout;
-    const float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.0f);
-    int y0 = (int)sy;
-    y0 = y0 < a.up_h - 1 ? y0 : a.up_h - 1;
-    const int y1 = y0 + (y0 < a.up_h - 1 ? 1 : 0);
-    const float ly = sy - (float)y0;
-    const float* u0 = u + y0 * a.up_w;
-    const float* u1 = u + y1 * a.up_w;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const float sx = fmaxf(0.5f * (ox0 + e + 0.5f) - 0.5f, 0.0f);
-      int x0 = (int)sx;
-      x0 = x0 < a.up_w - 1 ? x0 : a.up_w - 1;
-      const int x1 = x0 + (x0 < a.up_w - 1 ? 1 : 0);
-      const float lx = sx - (float)x0;
-      const float top = (1.0f - lx) * u0[x0] + lx * u0[x1];
-      const float bot = (1.0f - lx) * u1[x0] + lx * u1[x1];
-      v[e] += (1.0f - ly) * top + ly * bot;
-    }
+    // the VEC pixels of a thread sit in one output row (VEC == 4 only when Wout % 4 == 0)
+    const int oy = pix / a.Wout;
+    add_upsampled_x2<VEC>(a.up + ((long long)b * a.Cout + co) * a.up_h * a.up_w, a.up_h, a.up_w, oy, pix - oy * a.Wout, v);
   }
   const long long ooff = ((long long)b * a.out_ctot + a.out_coff + co) * HWout + pix;
   if (a.res) {
@@ -104,10 +89,14 @@ __global__ void splitk_reduce_kernel(const ConvArgs a) {
 
 struct Table {
   KernelEntry e[CONV_KIND_COUNT][CONV_TILE_COUNT];
-  bool attr_set[16][CONV_KIND_COUNT][CONV_TILE_COUNT];   // per device: the attribute is per (function, device)
+  // per device: the attribute is per (function, device).  Handles on different host threads race here only to set
+  // the same value twice (idempotent); the flag itself is atomic.
+  std::atomic<unsigned char> attr_set[16][CONV_KIND_COUNT][CONV_TILE_COUNT];
   Table() {
     memset(e, 0, sizeof(e));
-    memset(attr_set, 0, sizeof(attr_set));
+    for (auto& d : attr_set)
+      for (auto& k : d)
+        for (auto& t : k) t.store(0, std::memory_order_relaxed);
     conv_fill_1x1_s1(e[CONV_1x1_S1]);
     conv_fill_1x1_s2(e[CONV_1x1_S2]);
     conv_fill_3x3_s1(e[CONV_3x3_S1]);
@@ -207,8 +196,10 @@ void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKin
   }
 }
 
+// Split-K layers finish in splitk_reduce_kernel.  A layer with the fused upsample-add and ksplit == 1 adds the
+// upsampled map in the conv epilogue itself (no workspace round trip).
 long long conv_ws_floats(const ConvArgs& a) {
-  return (a.ksplit > 1 || a.up) ? (long long)a.B * a.ksplit * a.Cout * a.Hout * a.Wout : 0;
+  return a.ksplit > 1 ? (long long)a.B * a.ksplit * a.Cout * a.Hout * a.Wout : 0;
 }
 
 double conv_flops(const ConvArgs& a, ConvKind kind) {
@@ -216,7 +207,7 @@ double conv_flops(const ConvArgs& a, ConvKind kind) {
   return 2.0 * a.B * (double)a.Hout * a.Wout * a.Cout * a.Cin * g.kh * g.kw;
 }
 
-int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t st) {
+int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t st, int dev) {
   ConvArgs a = a_in;
   KernelEntry& ke = table().e[kind][tile];
   FDT_REQUIRE(ke.fn, FDT_ERR_ARG, "launch_conv: kernel (kind %d, tile %d) not instantiated", kind, tile);
@@ -233,20 +224,21 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
   if (a.res) FDT_REQUIRE(a.res_coff + a.Cout <= a.res_ctot, FDT_ERR_ARG, "launch_conv: bad residual slice");
   if (a.up) FDT_REQUIRE(a.up_h * 2 >= a.Hout && a.up_w * 2 >= a.Wout && a.up_h >= 1 && a.up_w >= 1,
                         FDT_ERR_ARG, "launch_conv: upsample source too small");
-  int dev = 0;
-  FDT_HIP(hipGetDevice(&dev));
-  dev &= 15;
-  if (!table().attr_set[dev][kind][tile]) {
+  if (dev < 0) FDT_HIP(hipGetDevice(&dev));
+  FDT_REQUIRE(dev < 16, FDT_ERR_ARG, "launch_conv: device index %d out of range", dev);
+  if (!table().attr_set[dev][kind][tile].load(std::memory_order_acquire)) {
     FDT_HIP(hipFuncSetAttribute((const void*)ke.fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)ke.lds));
-    table().attr_set[dev][kind][tile] = true;
+    table().attr_set[dev][kind][tile].store(1, std::memory_order_release);
   }
   const int nstages = ceil_div(a.Cin, g.kc);
   FDT_REQUIRE(a.ksplit >= 1 && a.ksplit <= nstages, FDT_ERR_ARG,
               "launch_conv: bad split-K %d (stages %d)", a.ksplit, nstages);
-  // split-K layers and layers with the fused upsample-add finish in splitk_reduce_kernel
-  FDT_REQUIRE(!(a.ksplit > 1 || a.up) || a.ws, FDT_ERR_ARG, "launch_conv: workspace required");
-  FDT_REQUIRE(!a.ws || a.ksplit > 1 || a.up, FDT_ERR_ARG, "launch_conv: unexpected workspace");
+  // split-K layers finish in splitk_reduce_kernel (which then also carries the fused upsample-add)
+  FDT_REQUIRE(a.ksplit == 1 || a.ws, FDT_ERR_ARG, "launch_conv: workspace required");
+  FDT_REQUIRE(!a.ws || a.ksplit > 1, FDT_ERR_ARG, "launch_conv: unexpected workspace");
+  FDT_REQUIRE(!a.up || conv_base_kind(kind) == CONV_1x1_S1, FDT_ERR_ARG,
+              "launch_conv: the fused upsample-add exists for the 1x1 class only (ContextTexture.main_conv)");
   const int tiles = ceil_div(a.Hout, tile_th(tile)) * ceil_div(a.Wout, tile_tw(tile));
   const int n_ct = ceil_div(a.Cout, tile_bn(tile));
   a.n_sp = tiles;
@@ -345,7 +337,7 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
     FDT_HIP(hipMemcpy(dup.p, up, n_up * 4, hipMemcpyHostToDevice));
     a.up = dup.as<float>(); a.up_h = up_h; a.up_w = up_w;
   }
-  if (a.ksplit > 1 || a.up) { FDT_TRY(dws.alloc((size_t)conv_ws_floats(a) * 4)); a.ws = dws.as<float>(); }
+  if (a.ksplit > 1) { FDT_TRY(dws.alloc((size_t)conv_ws_floats(a) * 4)); a.ws = dws.as<float>(); }
   if (const char* mm = getenv("FDT_CONV_MAP")) a.map_mode = atoi(mm);   // test hook: workgroup map (conv.h CONV_MAP_*)
   FDT_TRY(launch_conv((ConvKind)kind, (ConvTile)tile, a, 0));
   FDT_HIP(hipMemcpy(out, dout.p, n_out * 4, hipMemcpyDeviceToHost));
@@ -389,7 +381,7 @@ extern "C" int fdt_debug_conv_bench(int kind, int tile, int ksplit, int B, int C
     FDT_HIP(hipMemset(dup.p, 0, (size_t)B * Cout * a.up_h * a.up_w * 4));
     a.up = dup.as<float>();
   }
-  if (ksplit > 1 || has_up) { FDT_TRY(dws.alloc((size_t)conv_ws_floats(a) * 4)); a.ws = dws.as<float>(); }
+  if (ksplit > 1) { FDT_TRY(dws.alloc((size_t)conv_ws_floats(a) * 4)); a.ws = dws.as<float>(); }
   hipEvent_t e0, e1;
   FDT_HIP(hipEventCreate(&e0)); FDT_HIP(hipEventCreate(&e1));
   for (int i = 0; i < 2; ++i) FDT_TRY(launch_conv((ConvKind)kind, (ConvTile)tile, a, 0));

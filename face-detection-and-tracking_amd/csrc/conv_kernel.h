@@ -274,6 +274,11 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
                 const float bv = a.bias[co];
                 v.x += bv; v.y += bv; v.z += bv; v.w += bv;
               }
+              if (G::KH == 1 && G::S == 1 && a.up) {   // ContextTexture: + bilinear x2 of the coarser map, before the residual like the reduce pass
+                float u4[4] = {v.x, v.y, v.z, v.w};
+                add_upsampled_x2<4>(a.up + ((long long)b * a.Cout + co) * a.up_h * a.up_w, a.up_h, a.up_w, oy, ox, u4);
+                v = make_float4(u4[0], u4[1], u4[2], u4[3]);
+              }
               if (res_b) {
                 const float4 rv = *reinterpret_cast<const float4*>(res_b + off);
                 v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
@@ -327,6 +332,8 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
         const int coc = co < a.Cout ? co : a.Cout - 1;
         float v = acc[j][i][r];
         if (a.bias) v += a.bias[coc];
+        if (G::KH == 1 && G::S == 1 && a.up && pix_ok)
+          add_upsampled_x2<1>(a.up + ((long long)b * a.Cout + coc) * a.up_h * a.up_w, a.up_h, a.up_w, oy, ox, &v);
         if (res_b) v += res_b[(long long)coc * HWout + pix];
         if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
         else if (a.act == ACT_RELU6) v = fminf(fmaxf(v, 0.0f), 6.0f);

@@ -11,6 +11,8 @@
 #include <cmath>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <tuple>
 #include <set>
 #include <string>
 #include <vector>
@@ -61,10 +63,72 @@ struct DevW {
 
 }  // namespace
 
+// Weights of one net on one GPU: the state dict as loaded, the BN-folded host copies and the tiled device copies per
+// (layer, kernel class, tile).  Shared (shared_ptr) between a handle and its fdt_model_clone()s, so that several frames
+// in flight cost one weight copy; the mutex covers the caches (handles may live on different host threads).
+struct WeightStore {
+  std::map<std::string, HostT> sd;
+  struct HostW {
+    std::vector<float> w, bias;   // BN-folded OIHW weights (+ fused second conv), bias
+    int Cout = 0, Cin = 0;
+  };
+  std::map<std::string, HostW> host_w;   // per conv layer, kept for re-tiling
+  std::map<std::string, DevW> wcache;    // key: layer|kind|tile
+  std::mutex mu;
+  void drop_device() {
+    for (auto& kv : wcache) {
+      if (kv.second.w) (void)hipFree(kv.second.w);
+      if (kv.second.bias) (void)hipFree(kv.second.bias);
+    }
+    wcache.clear();
+    host_w.clear();
+  }
+  ~WeightStore() { drop_device(); }
+};
+
+struct GraphKey {   // everything a captured forward bakes in besides the plan itself
+  const void* out;
+  const void* counts;
+  int run_detect;
+  float conf_t, nms_t;
+  bool operator<(const GraphKey& o) const {
+    return std::tie(out, counts, run_detect, conf_t, nms_t) < std::tie(o.out, o.counts, o.run_detect, o.conf_t, o.nms_t);
+  }
+};
+
+// One ticket of the pipelined host ingest (fdt_model_forward_async): pinned staging for the frame(s) and the Detect
+// record, the device-side copies, and the events that order copy stream -> compute stream -> consumer.
+struct AsyncSlot {
+  void* h_in = nullptr;
+  void* d_in = nullptr;
+  size_t in_bytes = 0;
+  float *d_out = nullptr, *h_out = nullptr;
+  int *d_counts = nullptr, *h_counts = nullptr;
+  size_t out_floats = 0, n_counts = 0;
+  hipEvent_t copied = nullptr, fwd = nullptr, done = nullptr, consumed = nullptr;
+  bool busy = false, consumed_pending = false;
+  int ticket = -1;
+  void release() {
+    if (h_in) (void)hipHostFree(h_in);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (h_out) (void)hipHostFree(h_out);
+    if (d_counts) (void)hipFree(d_counts);
+    if (h_counts) (void)hipHostFree(h_counts);
+    for (hipEvent_t* e : {&copied, &fwd, &done, &consumed})
+      if (*e) (void)hipEventDestroy(*e);
+    *this = AsyncSlot();
+  }
+};
+constexpr int kAsyncSlots = 2;
+
 struct fdt_model {
   int arch = 0, device = 0;
   hipStream_t stream = nullptr;
-  std::map<std::string, HostT> sd;
+  hipStream_t copy_stream = nullptr;   // H2D of the async ingest, created on first use
+  AsyncSlot slots[kAsyncSlots];
+  int next_ticket = 0;
+  std::shared_ptr<WeightStore> W = std::make_shared<WeightStore>();
   std::set<std::string> expected;      // keys the forward graph reads
   bool finalized = false;
 
@@ -80,12 +144,11 @@ struct fdt_model {
   bool dry = false;
   std::vector<Tensor> tensors;
   std::vector<Op> ops;
-  std::map<std::string, DevW> wcache;  // key: layer|kind|tile
-  struct HostW {
-    std::vector<float> w, bias;   // BN-folded OIHW weights (+ fused second conv), bias
-    int Cout = 0, Cin = 0;
-  };
-  std::map<std::string, HostW> host_w;                      // per conv layer, kept for re-tiling
+  // the launches of a forward after the ingest kernel (convs ... Detect), captured once per (plan, output buffers,
+  // thresholds) and replayed with one hipGraphLaunch: the small-frame configs are bound by launch issue otherwise
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  int plan_runs = 0;          // eager forwards since the plan was (re)built; capture starts at the second
+  bool use_graph = true;
   struct Hint { int kind, tile, split, map; };
   std::map<std::string, Hint> hints;                        // autotuned (kernel class, tile, split) per layer
   int hB = 0, hH = 0, hW = 0;                               // shape the hints were tuned for
@@ -110,15 +173,19 @@ struct fdt_model {
 
   ~fdt_model() {
     free_plan();
-    for (auto& kv : wcache) {
-      if (kv.second.w) (void)hipFree(kv.second.w);
-      if (kv.second.bias) (void)hipFree(kv.second.bias);
-    }
     for (auto e : ev) (void)hipEventDestroy(e);
     if (d_src_u8) (void)hipFree(d_src_u8);
+    for (auto& sl : slots) sl.release();
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (stream) (void)hipStreamDestroy(stream);
   }
+  void drop_graphs() {
+    for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+    graphs.clear();
+    plan_runs = 0;
+  }
   void free_plan() {
+    drop_graphs();
     for (void* p : plan_allocs) (void)hipFree(p);
     plan_allocs.clear();
     tensors.clear();
@@ -169,8 +236,8 @@ struct Builder {
   const HostT* get(const std::string& key) {
     m->expected.insert(key);
     if (m->dry) return nullptr;
-    auto it = m->sd.find(key);
-    if (it == m->sd.end()) {
+    auto it = m->W->sd.find(key);
+    if (it == m->W->sd.end()) {
       set_error("missing weight tensor '%s'", key.c_str());
       fail(FDT_ERR_STATE);
       return nullptr;
@@ -231,7 +298,7 @@ struct Builder {
         const double stage_cycles = mfma_per_stage_tile * mfma_per_wave * 64.0;
         const double block_cycles = 4000.0 + std::ceil((double)nstages / split) * stage_cycles;
         double cycles = rounds * block_cycles / (occ_eff * tile_eff);
-        if (split > 1 || needs_ws) {
+        if (split > 1) {
           // reduce pass: read split partials + write, ~3 TB/s effective, plus a launch
           const double bytes = (double)B * Cout * Ho * Wo * 4.0 * (split + 1);
           cycles += 2.0e9 * (bytes / 3.0e12) + 6000.0;
@@ -248,13 +315,15 @@ struct Builder {
   // Upload (cached) tiled weights + bias of a layer for (kind, tile) from the folded host copy.
   static int device_weights(fdt_model* m, const std::string& key, ConvKind kind, ConvTile tile, DevW& out) {
     std::string ck = key + "|" + std::to_string((int)kind) + "|" + std::to_string((int)tile);
-    auto it = m->wcache.find(ck);
-    if (it != m->wcache.end()) {
+    WeightStore& W = *m->W;
+    std::lock_guard<std::mutex> lk(W.mu);
+    auto it = W.wcache.find(ck);
+    if (it != W.wcache.end()) {
       out = it->second;
       return FDT_OK;
     }
-    auto hw = m->host_w.find(key);
-    FDT_REQUIRE(hw != m->host_w.end(), FDT_ERR_STATE, "no folded weights for layer %s", key.c_str());
+    auto hw = W.host_w.find(key);
+    FDT_REQUIRE(hw != W.host_w.end(), FDT_ERR_STATE, "no folded weights for layer %s", key.c_str());
     std::vector<float> tiled;
     tile_weights(hw->second.w.data(), nullptr, hw->second.Cout, hw->second.Cin, kind, tile, tiled);
     DevW d;
@@ -262,7 +331,7 @@ struct Builder {
     FDT_HIP(hipMemcpy(d.w, tiled.data(), tiled.size() * 4, hipMemcpyHostToDevice));
     FDT_HIP(hipMalloc((void**)&d.bias, (size_t)hw->second.Cout * 4));
     FDT_HIP(hipMemcpy(d.bias, hw->second.bias.data(), (size_t)hw->second.Cout * 4, hipMemcpyHostToDevice));
-    m->wcache[ck] = d;
+    W.wcache[ck] = d;
     out = d;
     return FDT_OK;
   }
@@ -332,12 +401,8 @@ struct Builder {
     a.act = o.act;
     op.flops = conv_flops(a, kind);
     op.out_t = out_t;
-    op.needs_ws = ksplit > 1 || o.up_t >= 0;
-    if (op.needs_ws) {
-      ConvArgs tmp = a;
-      tmp.up = (const float*)1;
-      m->ws_floats = std::max(m->ws_floats, conv_ws_floats(tmp));
-    }
+    op.needs_ws = ksplit > 1;
+    if (op.needs_ws) m->ws_floats = std::max(m->ws_floats, conv_ws_floats(a));
     if (!m->dry) {
       if (rc != FDT_OK) return -1;
       const size_t per = (size_t)in.C * g.kh * g.kw;
@@ -369,15 +434,21 @@ struct Builder {
         for (int c = 0; c < o.cout2; ++c) bias[Cout + c] = b2->v[c];
         wsrc = &wcat;
       }
-      if (!m->host_w.count(name)) {
-        fdt_model::HostW hw;
+      bool have_host;
+      {
+        std::lock_guard<std::mutex> lk(m->W->mu);
+        have_host = m->W->host_w.count(name) != 0;
+      }
+      if (!have_host) {
+        WeightStore::HostW hw;
         hw.Cout = Ctot;
         hw.Cin = in.C;
         hw.bias = bias;
         hw.w = *wsrc;
         for (int co = 0; co < Ctot; ++co)
           for (size_t k = 0; k < per; ++k) hw.w[(size_t)co * per + k] *= scale[co];
-        m->host_w[name] = std::move(hw);
+        std::lock_guard<std::mutex> lk(m->W->mu);
+        m->W->host_w[name] = std::move(hw);
       }
       DevW dw;
       int r = device_weights(m, name, kind, op.tile, dw);
@@ -481,9 +552,10 @@ struct Builder {
         return fail(FDT_ERR_STATE);
       }
       std::string ck = name + "|dw";
-      auto it = m->wcache.find(ck);
+      std::lock_guard<std::mutex> lk(m->W->mu);
+      auto it = m->W->wcache.find(ck);
       DevW d;
-      if (it == m->wcache.end()) {
+      if (it == m->W->wcache.end()) {
         std::vector<float> ws(w->v);
         for (int c = 0; c < in.C; ++c)
           for (int k = 0; k < K * K; ++k) ws[c * K * K + k] *= scale[c];
@@ -494,7 +566,7 @@ struct Builder {
         }
         (void)hipMemcpy(d.w, ws.data(), ws.size() * 4, hipMemcpyHostToDevice);
         (void)hipMemcpy(d.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice);
-        m->wcache[ck] = d;
+        m->W->wcache[ck] = d;
       } else {
         d = it->second;
       }
@@ -1081,7 +1153,7 @@ int run_ops(fdt_model* m, int B, hipStream_t st) {
     if (prof) FDT_HIP(hipEventRecord(m->ev[i], st));
     switch (op.type) {
       case OP_CONV:
-        FDT_TRY(launch_conv(op.kind, op.tile, op.ca, st));
+        FDT_TRY(launch_conv(op.kind, op.tile, op.ca, st, m->device));
         break;
       case OP_POOL: {
         const Tensor& in = m->tensors[op.in_t];
@@ -1171,17 +1243,52 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
   } else {
     FDT_HIP(hipMemcpyAsync(x, frames, (size_t)B * 3 * H * W * 4, kind, st));
   }
-  FDT_TRY(run_ops(m, B, st));
-  if (run_detect && m->arch == FDT_ARCH_FACEBOX) {
-    FDT_TRY(launch_facebox_decode(m->dplan, m->d_ws, m->d_loc, m->d_conf, m->d_priors, m->conf_t, m->nms_t,
-                                  m->d_fb_boxes, m->d_fb_probs, counts_dev ? counts_dev : m->d_counts, st));
-    if (m->profile) FDT_HIP(hipEventRecord(m->ev[m->ops.size() + 1], st));
-  } else if (run_detect) {
-    FDT_TRY(launch_detect(m->dplan, m->d_ws, m->d_loc, m->d_conf, m->d_priors, 2, m->top_k, m->conf_t,
-                          m->nms_t, 0.1f, 0.2f, out_dev ? out_dev : m->d_out,
-                          counts_dev ? counts_dev : m->d_counts, st));
-    if (m->profile) FDT_HIP(hipEventRecord(m->ev[m->ops.size() + 1], st));
+  // everything after the ingest kernel: one hipGraphLaunch once the plan has run eagerly (which also sets the
+  // per-function LDS attributes) -- the graph bakes in the plan, the output buffers and the thresholds
+  float* out_p = out_dev ? out_dev : m->d_out;
+  int* counts_p = counts_dev ? counts_dev : m->d_counts;
+  auto body = [&]() -> int {
+    FDT_TRY(run_ops(m, B, st));
+    if (run_detect && m->arch == FDT_ARCH_FACEBOX) {
+      FDT_TRY(launch_facebox_decode(m->dplan, m->d_ws, m->d_loc, m->d_conf, m->d_priors, m->conf_t, m->nms_t,
+                                    m->d_fb_boxes, m->d_fb_probs, counts_p, st));
+      if (m->profile) FDT_HIP(hipEventRecord(m->ev[m->ops.size() + 1], st));
+    } else if (run_detect) {
+      FDT_TRY(launch_detect(m->dplan, m->d_ws, m->d_loc, m->d_conf, m->d_priors, 2, m->top_k, m->conf_t,
+                            m->nms_t, 0.1f, 0.2f, out_p, counts_p, st));
+      if (m->profile) FDT_HIP(hipEventRecord(m->ev[m->ops.size() + 1], st));
+    }
+    return FDT_OK;
+  };
+  if (m->use_graph && !m->profile) {
+    const GraphKey key{run_detect ? (const void*)out_p : nullptr, run_detect ? (const void*)counts_p : nullptr,
+                       run_detect ? 1 : 0, m->conf_t, m->nms_t};
+    auto it = m->graphs.find(key);
+    if (it != m->graphs.end()) {
+      FDT_HIP(hipGraphLaunch(it->second, st));
+      return FDT_OK;
+    }
+    if (m->plan_runs >= 1 && m->graphs.size() < 16) {
+      FDT_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      const int rc = body();
+      hipGraph_t g = nullptr;
+      const hipError_t ce = hipStreamEndCapture(st, &g);
+      if (rc != FDT_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+      }
+      FDT_REQUIRE(ce == hipSuccess && g, FDT_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+      hipGraphExec_t ex = nullptr;
+      const hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      FDT_REQUIRE(ie == hipSuccess && ex, FDT_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+      m->graphs[key] = ex;
+      FDT_HIP(hipGraphLaunch(ex, st));
+      return FDT_OK;
+    }
   }
+  FDT_TRY(body());
+  m->plan_runs++;
   return FDT_OK;
 }
 
@@ -1204,6 +1311,7 @@ extern "C" fdt_model* fdt_model_create(int arch, int device) {
     set_error("fdt_model_create: stream creation failed");
     return nullptr;
   }
+  if (const char* g = getenv("FDT_GRAPH")) m->use_graph = atoi(g) != 0;
   if (arch == FDT_ARCH_TRY3 || arch == FDT_ARCH_TRY4 || arch == FDT_ARCH_TRY5) {   // pyramid_mb2_try3.py:216
     m->conf_t = 0.2f;
     m->nms_t = 0.35f;
@@ -1234,6 +1342,46 @@ extern "C" void fdt_model_destroy(fdt_model* m) {
   delete m;
 }
 
+// A second handle on the same net and GPU that SHARES the weights (state dict, folded host copies, tiled device
+// copies) with `src` but has its own stream, activations, plan and Detect workspace: what a caller keeps per frame in
+// flight.  Kernel-plan hints and the detect / priorbox configuration are copied.  Read-only on the weights: set_tensor
+// on either handle fails while both exist.
+extern "C" fdt_model* fdt_model_clone(fdt_model* src) {
+  if (!src || !src->finalized) {
+    set_error("fdt_model_clone: source handle is null or not finalized");
+    return nullptr;
+  }
+  if (hipSetDevice(src->device) != hipSuccess) {
+    set_error("fdt_model_clone: hipSetDevice(%d) failed", src->device);
+    return nullptr;
+  }
+  std::unique_ptr<fdt_model> m(new fdt_model());
+  m->arch = src->arch;
+  m->device = src->device;
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+    set_error("fdt_model_clone: stream creation failed");
+    return nullptr;
+  }
+  m->W = src->W;
+  m->expected = src->expected;
+  m->finalized = true;
+  m->top_k = src->top_k;
+  m->nms_top_k = src->nms_top_k;
+  m->conf_t = src->conf_t;
+  m->nms_t = src->nms_t;
+  m->pb_set = src->pb_set;
+  m->pb_w = src->pb_w;
+  m->pb_h = src->pb_h;
+  m->pb_stride = src->pb_stride;
+  m->pb_box = src->pb_box;
+  m->hints = src->hints;
+  m->hB = src->hB;
+  m->hH = src->hH;
+  m->hW = src->hW;
+  m->use_graph = src->use_graph;
+  return m.release();
+}
+
 extern "C" int fdt_model_set_tensor(fdt_model* m, const char* name, const float* data, int ndim,
                                     const long long* dims) {
   FDT_REQUIRE(m && name && ndim >= 0 && ndim <= 8, FDT_ERR_ARG, "fdt_model_set_tensor: bad argument");
@@ -1248,8 +1396,10 @@ extern "C" int fdt_model_set_tensor(fdt_model* m, const char* name, const float*
     t.dims.push_back(dims[i]);
     n *= dims[i];
   }
+  FDT_REQUIRE(m->W.use_count() == 1, FDT_ERR_STATE,
+              "fdt_model_set_tensor: the weights are shared with fdt_model_clone() handles; destroy those first");
   t.v.assign(data, data + n);
-  m->sd[k] = std::move(t);
+  m->W->sd[k] = std::move(t);
   m->finalized = false;
   return FDT_OK;
 }
@@ -1258,7 +1408,7 @@ extern "C" int fdt_model_missing(fdt_model* m, int* n) {
   FDT_REQUIRE(m && n, FDT_ERR_ARG, "fdt_model_missing: bad argument");
   int c = 0;
   for (auto& k : m->expected)
-    if (!m->sd.count(k)) ++c;
+    if (!m->W->sd.count(k)) ++c;
   *n = c;
   return FDT_OK;
 }
@@ -1267,7 +1417,7 @@ extern "C" int fdt_model_missing_name(fdt_model* m, int i, char* buf, int buflen
   FDT_REQUIRE(m && buf && buflen > 0, FDT_ERR_ARG, "fdt_model_missing_name: bad argument");
   int c = 0;
   for (auto& k : m->expected)
-    if (!m->sd.count(k)) {
+    if (!m->W->sd.count(k)) {
       if (c == i) {
         snprintf(buf, buflen, "%s", k.c_str());
         return FDT_OK;
@@ -1281,17 +1431,17 @@ extern "C" int fdt_model_missing_name(fdt_model* m, int i, char* buf, int buflen
 extern "C" int fdt_model_finalize(fdt_model* m) {
   FDT_REQUIRE(m, FDT_ERR_ARG, "fdt_model_finalize: null handle");
   for (auto& k : m->expected)
-    FDT_REQUIRE(m->sd.count(k), FDT_ERR_STATE, "Missing key(s) in state_dict: \"%s\"", k.c_str());
+    FDT_REQUIRE(m->W->sd.count(k), FDT_ERR_STATE, "Missing key(s) in state_dict: \"%s\"", k.c_str());
   FDT_HIP(hipSetDevice(m->device));
   // weights may have changed: drop cached device copies and the plan
   FDT_HIP(hipStreamSynchronize(m->stream));
   m->free_plan();
-  for (auto& kv : m->wcache) {
-    if (kv.second.w) (void)hipFree(kv.second.w);
-    if (kv.second.bias) (void)hipFree(kv.second.bias);
+  if (m->W.use_count() == 1) {
+    m->W->drop_device();
+  } else {
+    // clones still read the device copies: only legal when nothing was re-loaded since (set_tensor refuses that)
+    FDT_REQUIRE(m->finalized, FDT_ERR_STATE, "fdt_model_finalize: weights are shared with clones");
   }
-  m->wcache.clear();
-  m->host_w.clear();
   m->finalized = true;
   return FDT_OK;
 }
@@ -1384,6 +1534,104 @@ extern "C" int fdt_model_forward_dev(fdt_model* m, const void* frames_dev, int f
   FDT_REQUIRE(m && m->arch != FDT_ARCH_FACEBOX, FDT_ERR_ARG,
               "fdt_model_forward_dev: FaceBox has no Detect layer; use fdt_model_detect_facebox_dev");
   return forward_impl(m, frames_dev, true, format, B, H, W, true, out_dev, counts_dev, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------- pipelined host ingest
+// iouTracke_cal.py:119-124 hands the detector host arrays (cv2 frames).  forward_async copies the caller's pageable
+// buffer into a pinned slot (the caller may reuse its buffer at once), enqueues H2D on the handle's copy stream, the
+// forward on its compute stream and the D2H of the Detect record, and returns a ticket.  Two tickets per handle may be
+// in flight: the copy of frame n+1 overlaps the forward of frame n.
+extern "C" int fdt_model_forward_async(fdt_model* m, const void* frames, int format, int B, int H, int W, int src_h,
+                                       int src_w, int* ticket) {
+  FDT_REQUIRE(m && frames && ticket, FDT_ERR_ARG, "fdt_model_forward_async: null argument");
+  FDT_REQUIRE(m->arch != FDT_ARCH_FACEBOX, FDT_ERR_ARG, "fdt_model_forward_async: PyramidBox nets only");
+  FDT_REQUIRE(B >= 1 && H >= 1 && W >= 1, FDT_ERR_ARG, "fdt_model_forward_async: bad shape");
+  FDT_REQUIRE(format == FDT_FRAME_U8_HWC_BGR || format == FDT_FRAME_F32_NCHW, FDT_ERR_ARG,
+              "fdt_model_forward_async: unknown frame format %d", format);
+  const bool resized = format == FDT_FRAME_U8_HWC_BGR && src_h > 0 && src_w > 0 && (src_h != H || src_w != W);
+  FDT_HIP(hipSetDevice(m->device));
+  AsyncSlot& s = m->slots[m->next_ticket % kAsyncSlots];
+  FDT_REQUIRE(!s.busy, FDT_ERR_STATE, "fdt_model_forward_async: ticket %d is still in flight; fdt_model_wait it first",
+              s.ticket);
+  if (!m->copy_stream) FDT_HIP(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+  if (!s.copied) {
+    for (hipEvent_t* e : {&s.copied, &s.fwd, &s.done, &s.consumed})
+      FDT_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
+  const size_t in_bytes = format == FDT_FRAME_F32_NCHW ? (size_t)B * 3 * H * W * 4
+                                                       : (size_t)B * (resized ? src_h : H) * (resized ? src_w : W) * 3;
+  const size_t out_floats = (size_t)B * 2 * m->top_k * 5, n_counts = (size_t)B * 2;
+  if (in_bytes > s.in_bytes || out_floats != s.out_floats || n_counts != s.n_counts) {
+    FDT_HIP(hipDeviceSynchronize());   // a (rare) re-size: nothing may still read the old buffers
+    hipEvent_t ev[4] = {s.copied, s.fwd, s.done, s.consumed};
+    s.copied = s.fwd = s.done = s.consumed = nullptr;
+    s.release();
+    s.copied = ev[0]; s.fwd = ev[1]; s.done = ev[2]; s.consumed = ev[3];
+    m->drop_graphs();                  // captured forwards bake in the old record pointer
+    FDT_HIP(hipHostMalloc(&s.h_in, in_bytes, hipHostMallocDefault));
+    FDT_HIP(hipMalloc(&s.d_in, in_bytes));
+    FDT_HIP(hipMalloc((void**)&s.d_out, out_floats * 4));
+    FDT_HIP(hipHostMalloc((void**)&s.h_out, out_floats * 4, hipHostMallocDefault));
+    FDT_HIP(hipMalloc((void**)&s.d_counts, n_counts * 4));
+    FDT_HIP(hipHostMalloc((void**)&s.h_counts, n_counts * 4, hipHostMallocDefault));
+    s.in_bytes = in_bytes;
+    s.out_floats = out_floats;
+    s.n_counts = n_counts;
+  }
+  memcpy(s.h_in, frames, in_bytes);
+  FDT_HIP(hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, m->copy_stream));
+  FDT_HIP(hipEventRecord(s.copied, m->copy_stream));
+  FDT_HIP(hipStreamWaitEvent(m->stream, s.copied, 0));
+  if (s.consumed_pending) {            // the last consumer of this slot's device record (e.g. the tracker)
+    FDT_HIP(hipStreamWaitEvent(m->stream, s.consumed, 0));
+    s.consumed_pending = false;
+  }
+  FDT_TRY(forward_impl(m, s.d_in, true, format, B, H, W, true, s.d_out, s.d_counts, nullptr, resized ? src_h : 0,
+                       resized ? src_w : 0));
+  FDT_HIP(hipEventRecord(s.fwd, m->stream));
+  FDT_HIP(hipMemcpyAsync(s.h_out, s.d_out, out_floats * 4, hipMemcpyDeviceToHost, m->stream));
+  FDT_HIP(hipMemcpyAsync(s.h_counts, s.d_counts, n_counts * 4, hipMemcpyDeviceToHost, m->stream));
+  FDT_HIP(hipEventRecord(s.done, m->stream));
+  s.busy = true;
+  s.ticket = m->next_ticket++;
+  *ticket = s.ticket;
+  return FDT_OK;
+}
+
+namespace {
+AsyncSlot* find_ticket(fdt_model* m, int ticket) {
+  if (!m || ticket < 0) return nullptr;
+  AsyncSlot& s = m->slots[ticket % kAsyncSlots];
+  return (s.busy && s.ticket == ticket) ? &s : nullptr;
+}
+}  // namespace
+
+// Device-side hand-over: `consumer_stream` waits (on the GPU) for the forward of `ticket`; *record_dev is its Detect
+// record [B,2,top_k,5] in HBM (valid until fdt_model_wait).  Lets fdt_tracker_step_dev consume it with no host round trip.
+extern "C" int fdt_model_async_record(fdt_model* m, int ticket, float** record_dev, void* consumer_stream) {
+  AsyncSlot* s = find_ticket(m, ticket);
+  FDT_REQUIRE(s, FDT_ERR_ARG, "fdt_model_async_record: ticket %d is not in flight", ticket);
+  FDT_REQUIRE(record_dev, FDT_ERR_ARG, "fdt_model_async_record: null output");
+  FDT_HIP(hipStreamWaitEvent((hipStream_t)consumer_stream, s->fwd, 0));
+  *record_dev = s->d_out;
+  return FDT_OK;
+}
+
+// Host-side completion: blocks until the record of `ticket` is on the host, copies it to out [B,2,top_k,5] / counts
+// [B,2] (either may be NULL) and frees the slot.  consumer_stream != NULL: work already enqueued there (the tracker
+// step reading the device record) is ordered before the slot's next forward.
+extern "C" int fdt_model_wait(fdt_model* m, int ticket, float* out, int* counts, void* consumer_stream) {
+  AsyncSlot* s = find_ticket(m, ticket);
+  FDT_REQUIRE(s, FDT_ERR_ARG, "fdt_model_wait: ticket %d is not in flight", ticket);
+  if (consumer_stream) {
+    FDT_HIP(hipEventRecord(s->consumed, (hipStream_t)consumer_stream));
+    s->consumed_pending = true;
+  }
+  FDT_HIP(hipEventSynchronize(s->done));
+  if (out) memcpy(out, s->h_out, s->out_floats * 4);
+  if (counts) memcpy(counts, s->h_counts, s->n_counts * 4);
+  s->busy = false;
+  return FDT_OK;
 }
 
 extern "C" int fdt_model_forward_raw(fdt_model* m, const void* frames, int format, int B, int H, int W,
@@ -1514,11 +1762,11 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
       a.w = dw.w;
       a.bias = dw.bias;
       a.ksplit = c.split;
-      a.ws = (c.split > 1 || a.up) ? tmp_ws : nullptr;
+      a.ws = c.split > 1 ? tmp_ws : nullptr;
       float best_ms = 1e30f;
       for (int it = 0; it < iters + 1 && rc == FDT_OK; ++it) {
         (void)hipEventRecord(e0, st);
-        rc = launch_conv((ConvKind)c.kind, (ConvTile)c.tile, a, st);
+        rc = launch_conv((ConvKind)c.kind, (ConvTile)c.tile, a, st, m->device);
         (void)hipEventRecord(e1, st);
         if (hipEventSynchronize(e1) != hipSuccess) { set_error("autotune: kernel failed"); rc = FDT_ERR_HIP; }
         float ms = 0;
@@ -1538,13 +1786,13 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
       a.w = dwb.w;
       a.bias = dwb.bias;
       a.ksplit = best.split;
-      a.ws = (best.split > 1 || a.up) ? tmp_ws : nullptr;
+      a.ws = best.split > 1 ? tmp_ws : nullptr;
       float map_ms[3] = {1e30f, 1e30f, 1e30f};
       for (int mm = 0; mm < 3 && rc == FDT_OK; ++mm) {
         a.map_mode = mm;
         for (int it = 0; it < iters + 2 && rc == FDT_OK; ++it) {
           (void)hipEventRecord(e0, st);
-          rc = launch_conv((ConvKind)best.kind, (ConvTile)best.tile, a, st);
+          rc = launch_conv((ConvKind)best.kind, (ConvTile)best.tile, a, st, m->device);
           (void)hipEventRecord(e1, st);
           if (hipEventSynchronize(e1) != hipSuccess) { set_error("autotune: kernel failed"); rc = FDT_ERR_HIP; }
           float ms = 0;
@@ -1568,7 +1816,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
     op.ca.map_mode = best_map;
     op.ca.w = dw.w;
     op.ca.bias = dw.bias;
-    op.needs_ws = best.split > 1 || op.ca.up;
+    op.needs_ws = best.split > 1;
     m->hints[op.name] = {best.kind, best.tile, best.split, best_map};
   }
   (void)hipEventDestroy(e0);
@@ -1590,7 +1838,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   }
   for (auto& op : m->ops)
     if (op.type == OP_CONV) op.ca.ws = op.needs_ws ? m->d_convws : nullptr;
-  // re-run the forward once so every activation is consistent with the final plan
+  m->drop_graphs();   // captured forwards bake in the old kernel choice
   return FDT_OK;
 }
 
@@ -1640,6 +1888,17 @@ extern "C" int fdt_model_import_plan(fdt_model* m, const char* text) {
   m->hB = B;
   m->hH = H;
   m->hW = W;
+  return FDT_OK;
+}
+
+// Replay the forward as a captured HIP graph (default on; env FDT_GRAPH=0 turns it off at create time).
+extern "C" int fdt_model_enable_graph(fdt_model* m, int on) {
+  FDT_REQUIRE(m, FDT_ERR_ARG, "fdt_model_enable_graph: null handle");
+  m->use_graph = on != 0;
+  if (!on) {
+    if (m->stream) (void)hipDeviceSynchronize();
+    m->drop_graphs();
+  }
   return FDT_OK;
 }
 

@@ -65,8 +65,12 @@ __device__ __forceinline__ bool better(double av, int ai, double bv, int bi) {
 constexpr int TRK_THREADS = 1024;             // one workgroup of 16 waves per frame
 constexpr int TRK_LDS_PER_SLOT = 72;          // bytes of LDS per detection/track slot (see the carve-up below)
 
-// One frame.  Launch <<<1, TRK_THREADS, M * TRK_LDS_PER_SLOT>>>.  `dets_in` (f64 [n_in,5]) xor `det_out`
-// (f32 [C,top_k,5]) is given.
+// G consecutive frames in one launch <<<1, TRK_THREADS, M * TRK_LDS_PER_SLOT>>> (G = 1 for the single-frame entry
+// points; G = world size after the all-gather of a frame-parallel step: one launch instead of G).  `dets_in`
+// (f64 [n_in,5], G == 1 only) xor `det_out` (f32, frame g at det_out + g * det_stride, each [C,top_k,5]) is given.
+// The tracker state (counters, log cursor) lives in LDS across the G frames and the two active sets swap roles per
+// frame; a frame's writes are ordered before the next frame's reads by the workgroup barrier (one workgroup == one
+// CU, whose L1 all its waves share), so the result is bit-identical to G single-frame launches.
 //
 // The greedy loop of iouTracke_cal.py:129-148 is sequential over the tracks, but its expensive part is not:
 //   phase 1 (16 waves, one track per wave at a time): arg-max of the track's IoU row over ALL detections;
@@ -75,10 +79,10 @@ constexpr int TRK_LDS_PER_SLOT = 72;          // bytes of LDS per detection/trac
 //     few LDS reads; only when an earlier track has taken it is the row re-evaluated over the free ones.
 // Detections, the per-track results and the det->track map live in LDS for the whole kernel.
 __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
-    TrkState* __restrict__ st, ActiveSet cur, ActiveSet nxt, int M, double sigma_iou, double sigma_h,
-    int t_min, const double* __restrict__ dets_in, int n_in, const float* __restrict__ det_out,
-    int num_classes, int top_k, float fw, float fh, float score_thr, char* __restrict__ log,
-    long long log_cap) {
+    TrkState* __restrict__ st, ActiveSet set_a, ActiveSet set_b, int M, double sigma_iou, double sigma_h,
+    int t_min, const double* __restrict__ dets_in, int n_in, const float* __restrict__ det_out_base,
+    long long det_stride, int G, int num_classes, int top_k, float fw, float fh, float score_thr,
+    char* __restrict__ log, long long log_cap) {
   extern __shared__ double smem_d[];
   double* dbox = smem_d;                     // [M][4] this frame's boxes
   double* dscore = dbox + (size_t)M * 4;     // [M]
@@ -89,17 +93,29 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
   int* tids = tlens + M;                     // [M]
   volatile int* det_tid = tids + M;          // [M] track id that took det j, -1 while free
   __shared__ int s_first_fail;
-  __shared__ int s_counts[3];                // n_upd, n_fin, n_new
+  __shared__ int s_n_active, s_next_id, s_frame_num;
+  __shared__ long long s_cursor;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = TRK_THREADS / 64;
-  const int frame = st->frame_num + 1;       // iouTracke_cal.py:118 (1-based)
+  if (tid == 0) {
+    s_n_active = st->n_active;
+    s_next_id = st->next_id;
+    s_frame_num = st->frame_num;
+    s_cursor = st->log_cursor;
+  }
+  __syncthreads();
+  for (int g = 0; g < G; ++g) {
+  const float* det_out = det_out_base ? det_out_base + (long long)g * det_stride : nullptr;
+  const ActiveSet cur = (g & 1) ? set_b : set_a;
+  const ActiveSet nxt = (g & 1) ? set_a : set_b;
+  const int frame = s_frame_num + 1;         // iouTracke_cal.py:118 (1-based)
 
   // ---- record header + this frame's detections -------------------------------------------------
-  const long long cursor = st->log_cursor;
+  const long long cursor = s_cursor;
   const long long rec_max = 16 + (long long)M * (40 + 4 + 4) + 8;
   if (cursor + rec_max > log_cap) {          // uniform over the block
     if (tid == 0) st->overflow = 1;
-    return;
+    break;
   }
   int* hdr = (int*)(log + cursor);
   double* dets = (double*)(log + cursor + 16);   // [n][5], filled below
@@ -153,7 +169,7 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
   __syncthreads();
 
   // ---- phase 1: every track's arg-max over all detections, tracks spread over the waves --------
-  const int T = st->n_active;
+  const int T = s_n_active;
   for (int t = wave; t < T; t += NW) {
     const double tb[4] = {cur.box[t * 4 + 0], cur.box[t * 4 + 1], cur.box[t * 4 + 2], cur.box[t * 4 + 3]};
     double bv = 0.0;
@@ -226,7 +242,7 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
     }
 
     // ---- remaining detections start new tracks, in detection order (:150-155) -------------------
-    const int next_id = st->next_id;
+    const int next_id = s_next_id;
     int n_new = 0;
     for (int base = 0; base < n; base += 64) {
       int j = base + lane;
@@ -248,23 +264,28 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
       n_new += __popcll(bal);
     }
     if (lane == 0) {
-      s_counts[0] = n_upd;
-      s_counts[1] = n_fin;
-      s_counts[2] = n_new;
       hdr[0] = n;
       hdr[1] = n_fin;
       hdr[2] = frame;
       hdr[3] = 0;
       long long rec = 16 + (long long)n * 40 + (long long)(n + n_fin) * 4;
       rec = (rec + 7) & ~7ll;
-      st->log_cursor = cursor + rec;
-      st->n_active = n_upd + n_new;
-      st->next_id = next_id + n_new;
-      st->frame_num = frame;
+      s_cursor = cursor + rec;
+      s_n_active = n_upd + n_new;
+      s_next_id = next_id + n_new;
+      s_frame_num = frame;
     }
   }
   __syncthreads();
   for (int j = tid; j < n; j += TRK_THREADS) tid_log[j] = det_tid[j];
+  __syncthreads();   // det_tid / dbox are rewritten by the next frame; the new active set is visible to every wave
+  }
+  if (tid == 0) {
+    st->log_cursor = s_cursor;
+    st->n_active = s_n_active;
+    st->next_id = s_next_id;
+    st->frame_num = s_frame_num;
+  }
 }
 
 }  // namespace
@@ -285,6 +306,7 @@ struct fdt_tracker {
   int frames_total = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t last_stream = nullptr;
+  hipEvent_t step_done = nullptr;   // recorded after every step: the state chain is ordered across caller streams
 
   struct Track {
     std::vector<double> boxes;   // 4 per box
@@ -364,18 +386,23 @@ int flush_log(fdt_tracker* t) {
   return FDT_OK;
 }
 
-int step_common(fdt_tracker* t, const double* dets_dev, int n, const float* det_out, int nc, int top_k,
-                int w, int h, float thr, hipStream_t st) {
+int step_common(fdt_tracker* t, const double* dets_dev, int n, const float* det_out, long long det_stride, int G,
+                int nc, int top_k, int w, int h, float thr, hipStream_t st) {
   FDT_REQUIRE(!t->finalized, FDT_ERR_STATE, "fdt_tracker: already finished; call reset");
-  if (t->frames_in_log >= t->log_frames) FDT_TRY(flush_log(t));
+  FDT_REQUIRE(G >= 1 && G <= t->log_frames, FDT_ERR_ARG, "fdt_tracker: %d frames per launch > log_frames %d", G,
+              t->log_frames);
+  if (t->frames_in_log + G > t->log_frames) FDT_TRY(flush_log(t));
+  // the tracker is one sequential state machine: a step on another stream than the previous one waits for it
+  if (t->last_stream && t->last_stream != st) FDT_HIP(hipStreamWaitEvent(st, t->step_done, 0));
   hipLaunchKernelGGL(fdt::track_step_kernel, dim3(1), dim3(fdt::TRK_THREADS), (size_t)t->M * fdt::TRK_LDS_PER_SLOT,
                      st, t->d_state,
                      t->set[t->cur], t->set[t->cur ^ 1], t->M, t->sigma_iou, t->sigma_h, t->t_min,
-                     dets_dev, n, det_out, nc, top_k, (float)w, (float)h, thr, t->d_log, t->log_cap);
+                     dets_dev, n, det_out, det_stride, G, nc, top_k, (float)w, (float)h, thr, t->d_log, t->log_cap);
   FDT_LAUNCH_CHECK();
-  t->cur ^= 1;
-  t->frames_in_log++;
-  t->frames_total++;
+  FDT_HIP(hipEventRecord(t->step_done, st));
+  t->cur ^= (G & 1);
+  t->frames_in_log += G;
+  t->frames_total += G;
   t->last_stream = st;
   return FDT_OK;
 }
@@ -402,6 +429,7 @@ extern "C" fdt_tracker* fdt_tracker_create(double sigma_iou, double sigma_h, int
   t->log_cap = rec_max * (log_frames + 1);
   size_t per_set = (size_t)max_dets * (32 + 8 + 4 + 4);
   bool ok = hipStreamCreateWithFlags(&t->own_stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&t->step_done, hipEventDisableTiming) == hipSuccess &&
             hipMalloc((void**)&t->d_state, sizeof(fdt::TrkState)) == hipSuccess &&
             hipMalloc((void**)&t->d_log, t->log_cap) == hipSuccess &&
             hipMalloc((void**)&t->d_dets_in, (size_t)max_dets * 40) == hipSuccess &&
@@ -430,6 +458,7 @@ extern "C" void fdt_tracker_destroy(fdt_tracker* t) {
   if (t->d_log) (void)hipFree(t->d_log);
   if (t->d_dets_in) (void)hipFree(t->d_dets_in);
   if (t->d_sets) (void)hipFree(t->d_sets);
+  if (t->step_done) (void)hipEventDestroy(t->step_done);
   if (t->own_stream) (void)hipStreamDestroy(t->own_stream);
   delete t;
 }
@@ -454,7 +483,7 @@ extern "C" int fdt_tracker_step(fdt_tracker* t, const double* dets, int n) {
   hipStream_t st = t->own_stream;
   // pageable-host memcpy on a stream is synchronous w.r.t. the host buffer: safe to return
   if (n) FDT_HIP(hipMemcpyAsync(t->d_dets_in, dets, (size_t)n * 40, hipMemcpyHostToDevice, st));
-  return step_common(t, t->d_dets_in, n, nullptr, 0, 0, 0, 0, 0.f, st);
+  return step_common(t, t->d_dets_in, n, nullptr, 0, 1, 0, 0, 0, 0, 0.f, st);
 }
 
 extern "C" int fdt_tracker_step_dev(fdt_tracker* t, const float* det_out, int num_classes, int top_k,
@@ -464,7 +493,23 @@ extern "C" int fdt_tracker_step_dev(fdt_tracker* t, const float* det_out, int nu
   FDT_REQUIRE((long long)num_classes * top_k <= t->M, FDT_ERR_ARG,
               "fdt_tracker_step_dev: num_classes*top_k %d > max_dets %d", num_classes * top_k, t->M);
   hipStream_t st = stream ? (hipStream_t)stream : t->own_stream;
-  return step_common(t, nullptr, 0, det_out, num_classes, top_k, width, height, score_thresh, st);
+  return step_common(t, nullptr, 0, det_out, 0, 1, num_classes, top_k, width, height, score_thresh, st);
+}
+
+// The G frames of one frame-parallel step (rank order == frame order after the all-gather) in ONE
+// launch: frame g's Detect record is at det_out + g * stride_floats.  Bit-identical to G fdt_tracker_step_dev calls.
+extern "C" int fdt_tracker_step_dev_multi(fdt_tracker* t, const float* det_out, int n_frames, long long stride_floats,
+                                          int num_classes, int top_k, int width, int height, float score_thresh,
+                                          void* stream) {
+  FDT_REQUIRE(t && det_out && num_classes >= 1 && top_k >= 1 && n_frames >= 1, FDT_ERR_ARG,
+              "fdt_tracker_step_dev_multi: bad argument");
+  FDT_REQUIRE(stride_floats >= (long long)num_classes * top_k * 5, FDT_ERR_ARG,
+              "fdt_tracker_step_dev_multi: stride %lld smaller than one record", stride_floats);
+  FDT_REQUIRE((long long)num_classes * top_k <= t->M, FDT_ERR_ARG,
+              "fdt_tracker_step_dev_multi: num_classes*top_k %d > max_dets %d", num_classes * top_k, t->M);
+  hipStream_t st = stream ? (hipStream_t)stream : t->own_stream;
+  return step_common(t, nullptr, 0, det_out, stride_floats, n_frames, num_classes, top_k, width, height, score_thresh,
+                     st);
 }
 
 extern "C" int fdt_tracker_finish(fdt_tracker* t) {

@@ -1,0 +1,104 @@
+"""The per-GPU detect+track pipeline exactly as it is timed by bench.py and pinned by tests/test_gpu_pipeline.py.
+
+`inflight` frames in flight per GPU: slot k = step % inflight owns a model handle (fdt_model_clone: shared weights,
+own activations + captured HIP graph), a HIP stream, its Detect record and candidate-count buffer.  The exchange
+(N > 1: one all-gather of the fixed-size records) and the strictly sequential IoU association (reference
+iouTracke_cal.py:117-156) run on ONE more stream; HIP events order
+    detect(step i, slot k)  ->  exchange + track(step i)  ->  detect(step i + inflight, slot k)
+so consecutive frames overlap (the latency-bound small layers and the one-workgroup tracker of one frame run beside
+the MFMA-bound layers of the next) while every forward is still batch `batch` and the tracker sees frames in order.
+The frames of a step (world x batch records in rank order == frame order) are associated in one launch
+(fdt_tracker_step_dev_multi).  Nothing here synchronises with the host; `finish()` does.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .parallel import FrameParallel
+from .tracker import IouTracker
+
+
+class DetectTrackPipeline:
+    def __init__(self, net, H, W, device, inflight=3, batch=1, exchange_factory=None, world=1, rank=0,
+                 source_hw=None, score_thresh=0.4, sigma_iou=0.4, sigma_h=0.6, t_min=5, log_frames=256,
+                 plan_text=None, multi_step=True):
+        self.H, self.W, self.B, self.NF = H, W, max(1, batch), max(1, inflight)
+        self.world, self.rank, self.dev = world, rank, device
+        self.source_hw = source_hw
+        self.score_thresh = score_thresh
+        self.multi_step = multi_step
+        self.nets = [net] + [net.clone() for _ in range(self.NF - 1)]
+        for n in self.nets:
+            n.firstTime = True
+            n._sync_attributes(H, W)
+            if plan_text:
+                n.import_plan(plan_text)
+        self.top_k = net.detect.top_k
+        self.REC = 2 * self.top_k * 5                      # one frame's Detect record [2, top_k, 5]
+        mk = exchange_factory or (lambda rec: FrameParallel(rank, world, rec, device))
+        self.fps = [mk(self.B * self.REC) for _ in range(self.NF)]
+        self.counts = [torch.zeros(2 * self.B, dtype=torch.int32, device=device) for _ in range(self.NF)]
+        self.tracker = IouTracker(sigma_iou, sigma_h, t_min, max_dets=2 * self.top_k,
+                                  log_frames=max(log_frames, world * self.B))
+        # non-default torch streams: their handles go through the C ABI, so torch.cuda.Event and the collective are
+        # ordered with the library's launches
+        self.det_streams = [torch.cuda.Stream(device=device) for _ in range(self.NF)]
+        self.trk_stream = torch.cuda.Stream(device=device)
+        self.sp_det = [ctypes.c_void_p(s.cuda_stream) for s in self.det_streams]
+        self.sp_trk = ctypes.c_void_p(self.trk_stream.cuda_stream)
+        assert all(p.value for p in self.sp_det) and self.sp_trk.value, "need real stream handles"
+        self.det_done = [torch.cuda.Event() for _ in range(self.NF)]
+        self.trk_done = [torch.cuda.Event() for _ in range(self.NF)]
+        self._L = _lib.lib()
+
+    def step(self, i, frames_dev):
+        """Enqueue step i: `frames_dev` = torch uint8 tensor [B, h, w, 3] on the device (raw source frames when
+        `source_hw` is set: they are resized on the GPU inside the step, iouTracke_cal.py:123)."""
+        L, k = self._L, i % self.NF
+        fp, net = self.fps[k], self.nets[k]
+        st = self.det_streams[k]
+        with torch.cuda.stream(st):
+            st.wait_event(self.trk_done[k])             # slot k's record was consumed (step i - inflight)
+            if self.source_hw:
+                _lib.check(L.fdt_model_forward_resized(net._h, ctypes.c_void_p(frames_dev.data_ptr()), 1, self.B,
+                                                       self.source_hw[0], self.source_hw[1], self.H, self.W,
+                                                       ctypes.c_void_p(fp.mine.data_ptr()),
+                                                       ctypes.c_void_p(self.counts[k].data_ptr()), self.sp_det[k]))
+            else:
+                _lib.check(L.fdt_model_forward_dev(net._h, ctypes.c_void_p(frames_dev.data_ptr()),
+                                                   _lib.FRAME_U8_HWC_BGR, self.B, self.H, self.W,
+                                                   ctypes.c_void_p(fp.mine.data_ptr()),
+                                                   ctypes.c_void_p(self.counts[k].data_ptr()), self.sp_det[k]))
+            self.det_done[k].record(st)
+        with torch.cuda.stream(self.trk_stream):
+            self.trk_stream.wait_event(self.det_done[k])
+            # the one exchange step of the path: fixed-size per-frame box lists, rank order == frame order
+            g = fp.exchange(self.sp_trk)
+            n = self.world * self.B
+            if self.multi_step:
+                self.tracker.step_dev_multi(ctypes.c_void_p(g.data_ptr()), n, self.REC, 2, self.top_k, self.W, self.H,
+                                            self.score_thresh, self.sp_trk)
+            else:
+                for f in range(n):
+                    self.tracker.step_dev(ctypes.c_void_p(g.data_ptr() + 4 * f * self.REC), 2, self.top_k, self.W,
+                                          self.H, self.score_thresh, self.sp_trk)
+            self.trk_done[k].record(self.trk_stream)
+
+    def record_of_slot(self, k):
+        """Host copy of slot k's gathered records [world*B, 2, top_k, 5] (synchronises)."""
+        torch.cuda.synchronize(self.dev)
+        return self.fps[k].gathered.detach().cpu().numpy().reshape(self.world * self.B, 2, self.top_k, 5)
+
+    def finish(self):
+        torch.cuda.synchronize(self.dev)
+        return self.tracker.finish()
+
+    def close(self):
+        torch.cuda.synchronize(self.dev)
+        for n in self.nets[1:]:
+            n.close()
+        for fp in self.fps:
+            if hasattr(fp, "close"):
+                fp.close()
+        self.tracker.close()

@@ -38,6 +38,14 @@ class IouTracker:
                                                    int(width), int(height), float(score_thresh),
                                                    stream))
 
+    def step_dev_multi(self, det_out_ptr, n_frames, stride_floats, num_classes, top_k, width, height, score_thresh=0.4,
+                       stream=None):
+        """The n_frames records of one frame-parallel step (rank order == frame order) in ONE launch; bit-identical
+        to n_frames step_dev calls."""
+        _lib.check(_lib.lib().fdt_tracker_step_dev_multi(self._h, det_out_ptr, int(n_frames), int(stride_floats),
+                                                         num_classes, top_k, int(width), int(height),
+                                                         float(score_thresh), stream))
+
     def finish(self):
         L = _lib.lib()
         _lib.check(L.fdt_tracker_finish(self._h))

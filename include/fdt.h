@@ -49,6 +49,7 @@ extern "C" {
 
 typedef struct fdt_model fdt_model;
 typedef struct fdt_tracker fdt_tracker;
+typedef struct fdt_comm fdt_comm;
 
 /* ------------------------------------------------------------------ library / device */
 const char* fdt_last_error(void);
@@ -57,6 +58,8 @@ int fdt_device_count(int* n);
 int fdt_device_name(int dev, char* buf, int buflen);
 int fdt_set_device(int dev);
 int fdt_device_synchronize(void);
+/* free / total HBM of the current device (hipMemGetInfo) */
+int fdt_device_mem_info(long long* free_bytes, long long* total_bytes);
 
 /* ------------------------------------------------------------------ SSD post-processing ops
  * Stand-alone, no model handle: these are what `from layers import *` /
@@ -130,6 +133,13 @@ int fdt_tracker_step(fdt_tracker* t, const double* dets, int n);
  * boxes * (w,h,w,h) in f32, dummy row if none).  Asynchronous on `stream`.                   */
 int fdt_tracker_step_dev(fdt_tracker* t, const float* det_out, int num_classes, int top_k,
                          int width, int height, float score_thresh, void* stream);
+/* The n_frames frames of one frame-parallel step (rank order == frame order after fdt_allgather_dets) associated
+ * in ONE launch; frame g's Detect record is at det_out + g*stride_floats.  Bit-identical to n_frames calls of
+ * fdt_tracker_step_dev, i.e. to n_frames iterations of the loop at iouTracke_cal.py:117-156.  n_frames <= log_frames.
+ * Steps issued on different streams are ordered by the tracker itself (it is one sequential state machine).        */
+int fdt_tracker_step_dev_multi(fdt_tracker* t, const float* det_out, int n_frames, long long stride_floats,
+                               int num_classes, int top_k, int width, int height, float score_thresh,
+                               void* stream);
 /* iouTracke_cal.py:174-175, then copy the event log back.  After this the accessors work.    */
 int fdt_tracker_finish(fdt_tracker* t);
 int fdt_tracker_num_tracks(fdt_tracker* t, int* n);
@@ -141,6 +151,12 @@ int fdt_tracker_track_boxes(fdt_tracker* t, int idx, double* boxes /* [n_boxes,4
  * build_sfd('test',640,2) / build_sfd_mobile('test',640,2) / FaceBox()                       */
 fdt_model* fdt_model_create(int arch, int device);
 void fdt_model_destroy(fdt_model* m);
+/* A second handle on the same net and GPU that shares the weights of `src` (state dict, BN-folded and tiled device
+ * copies) but owns its stream, activations, kernel plan and Detect workspace: one per frame in flight costs one weight
+ * copy per GPU instead of one per handle.  `src` must be finalized; detect / priorbox settings and plan hints are
+ * copied.  While clones exist fdt_model_set_tensor fails with FDT_ERR_STATE on all of them (weights are read-only).
+ * The reference has one module object per process (iouTracke_cal.py:94-107); this is its multi-stream equivalent.   */
+fdt_model* fdt_model_clone(fdt_model* src);
 /* net.load_state_dict(d): one call per (key, tensor); unknown key -> FDT_ERR_NAME.
  * data is f32 (num_batches_tracked may be passed with ndim 0 and is ignored).               */
 int fdt_model_set_tensor(fdt_model* m, const char* name, const float* data, int ndim,
@@ -170,6 +186,19 @@ int fdt_model_forward_dev(fdt_model* m, const void* frames_dev, int format, int 
  * Agreement with cv2 itself is unpinned (cv2 is not available to the build); see DESIGN.md.        */
 int fdt_model_forward_resized(fdt_model* m, const void* frames, int frames_on_device, int B, int src_h,
                               int src_w, int H, int W, float* out, int* counts, void* stream);
+/* Pipelined host ingest (iouTracke_cal.py:119-124: frames reach the detector as host arrays).  forward_async copies the
+ * caller's (pageable) frames into a pinned slot -- the caller may reuse its buffer at once --, enqueues the H2D copy on
+ * the handle's copy stream, the forward (+ the device-side resize when src_h x src_w differs from H x W; 0 = none) on
+ * its compute stream and the D2H of the Detect record, and returns a ticket without waiting.  Two tickets per handle
+ * may be in flight (the copy of frame n+1 overlaps the forward of frame n); more frames in flight = more
+ * fdt_model_clone handles.  fdt_model_wait blocks until the ticket's record [B,2,top_k,5] / counts [B,2] are on the
+ * host (out / counts may be NULL) and frees the slot.  fdt_model_async_record hands the record over ON THE DEVICE:
+ * consumer_stream waits for the forward, *record_dev stays valid until fdt_model_wait, whose consumer_stream argument
+ * (may be NULL) orders what was enqueued there before the slot's next forward.                                       */
+int fdt_model_forward_async(fdt_model* m, const void* frames, int format, int B, int H, int W, int src_h, int src_w,
+                            int* ticket);
+int fdt_model_async_record(fdt_model* m, int ticket, float** record_dev, void* consumer_stream);
+int fdt_model_wait(fdt_model* m, int ticket, float* out, int* counts, void* consumer_stream);
 /* Network output without Detect: loc [B,P,4], conf [B,P,2].  PyramidBox: conf is softmaxed
  * (pyramid.py:332).  FaceBox.forward (FACEBOX/networks.py:87-116): conf is the raw conf_preds.       */
 int fdt_model_forward_raw(fdt_model* m, const void* frames, int format, int B, int H, int W,
@@ -195,6 +224,10 @@ int fdt_model_autotune(fdt_model* m, int iters);
  * so a tuned plan is reproducible across processes.  export: *needed = bytes incl. NUL; buf may be NULL. */
 int fdt_model_export_plan(fdt_model* m, char* buf, int buflen, int* needed);
 int fdt_model_import_plan(fdt_model* m, const char* text);
+/* After the first eager forward of a plan the launches behind the ingest kernel (all convs ... Detect) are captured
+ * into a HIP graph per (output buffer, thresholds) and replayed with one hipGraphLaunch.  on = 0 returns to eager
+ * launches (also: env FDT_GRAPH=0 at create time).  Per-op profiling always runs eagerly.  Results are identical.    */
+int fdt_model_enable_graph(fdt_model* m, int on);
 /* per-op timing of the next forwards (HIP events around every launch on the model stream).
  * fdt_model_profile_read: fills up to max entries; returns count in *n.                      */
 int fdt_model_profile_enable(fdt_model* m, int on);
@@ -202,6 +235,27 @@ int fdt_model_profile_read(fdt_model* m, int max, char* names /* max*48 */, floa
                            double* flops, int* n);
 /* algorithmic conv FLOPs (2*MAC, live convs only) of one frame at the last forward's size    */
 int fdt_model_flops(fdt_model* m, double* flops);
+
+/* ------------------------------------------------------------------ multi-GPU exchange (RCCL over xGMI)
+ * The reference is single-GPU (its only trace of more is the commented nn.DataParallel at MyTrain_repo.py:71).  The
+ * path shards by frame (frame f -> rank f mod G); the ONE exchange per step is an all-gather of each rank's fixed-size
+ * Detect record [num_classes, top_k, 5] f32 (layers/functions/detection.py:48,82), after which the sequential
+ * association of iouTracke_cal.py:117-156 runs over the gathered records in rank order (fdt_tracker_step_dev_multi).
+ * One process per GPU: rank 0 calls fdt_comm_unique_id and ships the FDT_COMM_ID_BYTES bytes to the other ranks over
+ * any host channel, then every rank calls fdt_comm_init_rank.  One process driving n GPUs: fdt_comm_init_all, and one
+ * fdt_allgather_dets per local device between fdt_comm_group_begin / fdt_comm_group_end.                            */
+#define FDT_COMM_ID_BYTES 128
+int fdt_comm_unique_id(char* id_out /* [FDT_COMM_ID_BYTES] */);
+fdt_comm* fdt_comm_init_rank(int world, int rank, const char* id /* [FDT_COMM_ID_BYTES] */, int device);
+fdt_comm* fdt_comm_init_all(int n_dev, const int* dev_ids);
+int fdt_comm_world(fdt_comm* c, int* world, int* n_local);
+int fdt_comm_group_begin(void);
+int fdt_comm_group_end(void);
+/* all_dev[r*floats_per_rank ...] = rank r's local_dev[0 .. floats_per_rank); device pointers, enqueued on `stream`.
+ * local_index: which local device of the communicator (0 for fdt_comm_init_rank).                                   */
+int fdt_allgather_dets(fdt_comm* c, int local_index, const float* local_dev, float* all_dev,
+                       long long floats_per_rank, void* stream);
+void fdt_comm_destroy(fdt_comm* c);
 
 #ifdef __cplusplus
 }

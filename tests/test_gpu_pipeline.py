@@ -1,0 +1,284 @@
+"""The timed path of bench.py, pinned: several model handles (fdt_model_clone: one weight copy) on their own HIP streams,
+captured HIP graphs, a tracker stream ordered by events, the step's frames associated in one launch
+(fdt_tracker_step_dev_multi), the RCCL all-gather behind the C ABI.  Everything is compared bit-for-bit with the
+sequential synchronous path (`net(frame)`) and the oracle's IouTracker (reference iouTracke_cal.py:117-156,174-177)."""
+import ctypes
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import postproc as opp
+
+pytestmark = pytest.mark.gpu
+
+
+def M(name):
+    return importlib.import_module("face-detection-and-tracking_amd." + name)
+
+
+def tracks_key(tracks):
+    return [(t["start_frame"], float(t["max_score"]), [list(map(float, b)) for b in t["bboxes"]]) for t in tracks]
+
+
+@pytest.fixture(scope="module")
+def res50(res50_sd):
+    net = M("pyramid").build_sfd('test', 640, 2)
+    net.load_state_dict(res50_sd)
+    yield net
+    net.close()
+
+
+def moving_frames(synth, n, H, W, seed):
+    """n frames that change slowly (a base frame plus a drifting bright block), so that detections persist and tracks
+    actually form under the synthetic weights."""
+    base = synth.make_frames(1, H, W, seed=seed)[0]
+    out = np.repeat(base[None], n, 0).copy()
+    for i in range(n):
+        out[i, 8 + i:40 + i, 16 + 2 * i:64 + 2 * i] = 255 - out[i, 8 + i:40 + i, 16 + 2 * i:64 + 2 * i]
+    return out
+
+
+def test_clone_shares_weights_and_matches(res50, synth):
+    L = M("_lib")
+    H, W = 128, 160
+    res50.priorbox = M("layers").PriorBoxLayer(W, H); res50.firstTime = True
+    res50.detect = M("layers").Detect(2, 0, 750, 0.05, 0.35)
+    frame = synth.make_frames(1, H, W, seed=3)[0]
+    y0 = res50(frame).numpy()
+    free0, tot = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    L.check(L.lib().fdt_device_mem_info(ctypes.byref(free0), ctypes.byref(tot)))
+    c = res50.clone()
+    y1 = c(frame).numpy()
+    free1 = ctypes.c_longlong(0)
+    L.check(L.lib().fdt_device_mem_info(ctypes.byref(free1), ctypes.byref(tot)))
+    assert np.array_equal(y0, y1)                        # same weights, same plan -> same bits
+    # a clone costs activations + workspaces at this size (tens of MB), not another ~270 MB of weights (+ Winograd copies)
+    assert free0.value - free1.value < 200e6, (free0.value - free1.value)
+    # weights are read-only while shared
+    w = np.zeros((64, 3, 7, 7), np.float32)
+    dims = (ctypes.c_longlong * 4)(64, 3, 7, 7)
+    rc = L.lib().fdt_model_set_tensor(c._h, b"conv1.weight", L.ptr(w), 4, dims)
+    assert rc == L.FDT_ERR_STATE
+    c.close()
+    y2 = res50(frame).numpy()                            # the original survives its clone
+    assert np.array_equal(y0, y2)
+
+
+def test_graph_replay_equals_eager(res50, synth):
+    H, W = 136, 200
+    res50.priorbox = M("layers").PriorBoxLayer(W, H); res50.firstTime = True
+    res50.detect = M("layers").Detect(2, 0, 750, 0.05, 0.35)
+    frames = synth.make_frames(3, H, W, seed=11)
+    res50.enable_graph(False)
+    eager = [res50(f).numpy() for f in frames]
+    res50.enable_graph(True)
+    res50(frames[0])                                     # eager run of the plan, then capture, then replays
+    got = [res50(f).numpy() for f in frames] + [res50(f).numpy() for f in frames]
+    for i, g in enumerate(got):
+        assert np.array_equal(g, eager[i % 3]), i
+    assert int((eager[0][0, 1, :, 0] > 0).sum()) > 5
+
+
+@pytest.mark.parametrize("inflight,multi", [(3, True), (3, False), (1, True)])
+def test_pipelined_streams_match_sequential_and_oracle(res50, synth, inflight, multi):
+    """>= 24 frames through `inflight` handles x streams + the tracker stream exactly as bench.py runs them: per-frame
+    Detect records and the final tracks are bit-equal to the sequential path + the oracle tracker."""
+    H, W, N = 128, 160, 26
+    dev = torch.device("cuda", 0)
+    res50.priorbox = M("layers").PriorBoxLayer(W, H); res50.firstTime = True
+    res50.detect = M("layers").Detect(2, 0, 750, 0.05, 0.35)
+    frames = moving_frames(synth, N, H, W, seed=5)
+    # sequential, synchronous reference run of the same handles' weights
+    seq = [res50(f).numpy() for f in frames]
+    ref = opp.IouTracker(0.4, 0.6, 5)
+    for y in seq:
+        with np.errstate(all="ignore"):
+            ref.step(opp.unpack_detections(y, W, H, 0.4))
+    want = tracks_key(ref.finish())
+    assert len(want) >= 2 and max(len(t[2]) for t in want) >= 8
+
+    pipe = M("pipeline").DetectTrackPipeline(res50, H, W, dev, inflight=inflight, multi_step=multi, log_frames=8)
+    frames_d = torch.from_numpy(frames).to(dev)
+    recs = {}
+    for i in range(N):
+        pipe.step(i, frames_d[i:i + 1])
+        if i % 5 == 4 or i == N - 1:                     # sample records without disturbing the overlap every step
+            recs[i] = pipe.record_of_slot(i % pipe.NF)[0].copy()
+    got = tracks_key(pipe.finish())
+    for i, r in recs.items():
+        assert np.array_equal(r, seq[i][0]), i
+    assert got == want
+    pipe.close()
+
+
+def test_step_dev_multi_equals_sequential_steps():
+    """G = 8 gathered records in one launch == 8 launches == the oracle (random records incl. empty frames)."""
+    TOP_K, G, STEPS = 40, 8, 9
+    rng = np.random.default_rng(17)
+    dev = torch.device("cuda", 0)
+    trk = M("tracker")
+    a = trk.IouTracker(0.4, 0.6, 5, max_dets=2 * TOP_K, log_frames=16)
+    b = trk.IouTracker(0.4, 0.6, 5, max_dets=2 * TOP_K, log_frames=16)
+    ref = opp.IouTracker(0.4, 0.6, 5)
+    faces = rng.uniform(0.1, 0.6, (6, 2))
+    for s in range(STEPS):
+        rec = np.zeros((G, 2, TOP_K, 5), np.float32)
+        for g in range(G):
+            f = s * G + g
+            n = 0 if f % 13 == 5 else 6
+            sc = np.sort(rng.uniform(0.41, 1.0, n))[::-1]
+            xy = faces[:n] + 0.003 * f + rng.uniform(-0.002, 0.002, (n, 2))
+            rec[g, 1, :n, 0] = sc
+            rec[g, 1, :n, 1:3] = xy
+            rec[g, 1, :n, 3:5] = xy + 0.15
+        d = torch.from_numpy(rec).to(dev)
+        a.step_dev_multi(ctypes.c_void_p(d.data_ptr()), G, 2 * TOP_K * 5, 2, TOP_K, 640, 480, 0.4, None)
+        for g in range(G):
+            b.step_dev(ctypes.c_void_p(d.data_ptr() + 4 * g * 2 * TOP_K * 5), 2, TOP_K, 640, 480, 0.4, None)
+            with np.errstate(all="ignore"):
+                ref.step(opp.unpack_detections(rec[g][None], 640, 480, 0.4))
+        torch.cuda.synchronize()
+    ta, tb, tr = tracks_key(a.finish()), tracks_key(b.finish()), tracks_key(ref.finish())
+    assert len(tr) >= 4
+    assert ta == tr and tb == tr
+    a.close(); b.close()
+
+
+def test_tracker_steps_on_alternating_streams_are_ordered():
+    """A caller that alternates streams still gets the sequential association (the tracker chains its steps)."""
+    TOP_K = 16
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(2)
+    t = M("tracker").IouTracker(0.4, 0.6, 3, max_dets=2 * TOP_K, log_frames=64)
+    ref = opp.IouTracker(0.4, 0.6, 3)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    recs = []
+    for f in range(40):
+        rec = np.zeros((2, TOP_K, 5), np.float32)
+        xy = np.array([[0.2, 0.2], [0.6, 0.5]]) + 0.004 * f
+        rec[1, :2, 0] = [0.9, 0.7]
+        rec[1, :2, 1:3] = xy
+        rec[1, :2, 3:5] = xy + 0.2 + rng.uniform(0, 0.01)
+        recs.append(torch.from_numpy(rec).to(dev))
+        with np.errstate(all="ignore"):
+            ref.step(opp.unpack_detections(rec[None], 640, 480, 0.4))
+    torch.cuda.synchronize()
+    for f, d in enumerate(recs):
+        s = streams[f % 3]
+        t.step_dev(ctypes.c_void_p(d.data_ptr()), 2, TOP_K, 640, 480, 0.4, ctypes.c_void_p(s.cuda_stream))
+    torch.cuda.synchronize()
+    assert tracks_key(t.finish()) == tracks_key(ref.finish())
+    t.close()
+
+
+def test_rccl_allgather_through_the_c_abi_single_rank():
+    """World of one: the communicator builds (ncclCommInitRank and ncclCommInitAll) and the all-gather is the identity."""
+    L = M("_lib")
+    lib = L.lib()
+    dev = torch.device("cuda", 0)
+    idb = ctypes.create_string_buffer(128)
+    L.check(lib.fdt_comm_unique_id(idb))
+    for make in (lambda: lib.fdt_comm_init_rank(1, 0, idb, 0), lambda: lib.fdt_comm_init_all(1, (ctypes.c_int * 1)(0))):
+        c = make()
+        assert c, lib.fdt_last_error()
+        w, nl = ctypes.c_int(0), ctypes.c_int(0)
+        L.check(lib.fdt_comm_world(c, ctypes.byref(w), ctypes.byref(nl)))
+        assert (w.value, nl.value) == (1, 1)
+        src = torch.arange(7500, dtype=torch.float32, device=dev)
+        dst = torch.zeros(7500, dtype=torch.float32, device=dev)
+        st = torch.cuda.Stream(device=dev)
+        L.check(lib.fdt_allgather_dets(c, 0, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), 7500,
+                                       ctypes.c_void_p(st.cuda_stream)))
+        st.synchronize()
+        assert torch.equal(src, dst)
+        lib.fdt_comm_destroy(c)
+    assert lib.fdt_allgather_dets(None, 0, None, None, 1, None) == L.FDT_ERR_ARG
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_rccl_allgather_two_devices_single_process():
+    L = M("_lib")
+    lib = L.lib()
+    c = lib.fdt_comm_init_all(2, (ctypes.c_int * 2)(0, 1))
+    assert c, lib.fdt_last_error()
+    bufs = []
+    for d in range(2):
+        dev = torch.device("cuda", d)
+        bufs.append((torch.full((7500,), float(d + 1), device=dev), torch.zeros(15000, device=dev)))
+    L.check(lib.fdt_comm_group_begin())
+    for d in range(2):
+        L.check(lib.fdt_allgather_dets(c, d, ctypes.c_void_p(bufs[d][0].data_ptr()),
+                                       ctypes.c_void_p(bufs[d][1].data_ptr()), 7500, None))
+    L.check(lib.fdt_comm_group_end())
+    for d in range(2):
+        torch.cuda.synchronize(d)
+        assert float(bufs[d][1][:7500].sum()) == 7500.0 and float(bufs[d][1][7500:].sum()) == 15000.0
+    lib.fdt_comm_destroy(c)
+
+
+def test_async_host_ingest_matches_sync(res50, synth):
+    """fdt_model_forward_async / fdt_model_wait (pinned ring, copy stream, two tickets in flight per handle) returns the
+    same records as the synchronous host path, also through the device-side hand-over to the tracker."""
+    L = M("_lib")
+    lib = L.lib()
+    H, W, N = 128, 160, 9
+    res50.priorbox = M("layers").PriorBoxLayer(W, H); res50.firstTime = True
+    res50.detect = M("layers").Detect(2, 0, 750, 0.05, 0.35)
+    frames = moving_frames(synth, N, H, W, seed=9)
+    seq = [res50(f).numpy() for f in frames]
+    ref = opp.IouTracker(0.4, 0.6, 3)
+    for y in seq:
+        with np.errstate(all="ignore"):
+            ref.step(opp.unpack_detections(y, W, H, 0.4))
+    trk = M("tracker").IouTracker(0.4, 0.6, 3, max_dets=1500, log_frames=64)
+    st = torch.cuda.Stream()
+    sp = ctypes.c_void_p(st.cuda_stream)
+    pending, got = [], []
+
+    def retire():
+        t = pending.pop(0)
+        rec = ctypes.c_void_p(0)
+        L.check(lib.fdt_model_async_record(res50._h, t, ctypes.byref(rec), sp))
+        trk.step_dev(rec, 2, 750, W, H, 0.4, sp)
+        out = np.empty((1, 2, 750, 5), np.float32)
+        cnt = np.zeros((1, 2), np.int32)
+        L.check(lib.fdt_model_wait(res50._h, t, L.ptr(out), L.ptr(cnt), sp))
+        got.append(out)
+
+    for i in range(N):
+        if len(pending) == 2:
+            retire()
+        t = ctypes.c_int(-1)
+        buf = frames[i].copy()
+        L.check(lib.fdt_model_forward_async(res50._h, L.ptr(buf), L.FRAME_U8_HWC_BGR, 1, H, W, 0, 0, ctypes.byref(t)))
+        buf[:] = 0                                        # the caller's buffer is free as soon as the call returns
+        pending.append(t.value)
+    # a third ticket on one handle is refused, not queued
+    t = ctypes.c_int(-1)
+    assert lib.fdt_model_forward_async(res50._h, L.ptr(frames[0]), L.FRAME_U8_HWC_BGR, 1, H, W, 0, 0,
+                                       ctypes.byref(t)) == L.FDT_ERR_STATE
+    while pending:
+        retire()
+    for i in range(N):
+        assert np.array_equal(got[i], seq[i]), i
+    assert tracks_key(trk.finish()) == tracks_key(ref.finish())
+    assert lib.fdt_model_wait(res50._h, 0, None, None, None) == L.FDT_ERR_ARG      # already retired
+    trk.close()
+
+
+def test_async_ingest_with_device_resize(res50, synth):
+    L = M("_lib")
+    lib = L.lib()
+    H, W, SH, SW = 96, 128, 270, 480
+    res50.priorbox = M("layers").PriorBoxLayer(W, H); res50.firstTime = True
+    res50.detect = M("layers").Detect(2, 0, 750, 0.05, 0.35)
+    src = synth.make_frames(2, SH, SW, seed=21)
+    want = [res50.forward_resized(f, (W, H)).numpy() for f in src]
+    for i in range(2):
+        t = ctypes.c_int(-1)
+        L.check(lib.fdt_model_forward_async(res50._h, L.ptr(src[i]), L.FRAME_U8_HWC_BGR, 1, H, W, SH, SW, ctypes.byref(t)))
+        out = np.empty((1, 2, 750, 5), np.float32)
+        L.check(lib.fdt_model_wait(res50._h, t.value, L.ptr(out), None, None))
+        assert np.array_equal(out, want[i])
