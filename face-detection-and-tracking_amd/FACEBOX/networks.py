@@ -45,10 +45,16 @@ class FaceBox(DetectorNet):
         """Whole `detect(im)` of reference FACEBOX/My_test_facebox.py:12-36 after the resize, on the GPU.
         Returns a list of (boxes [k,4] in [0,1], probs [k]) per image."""
         x, fmt, B, H, W = self._prepare(frames)
-        self._sync_attributes(H, W)
         boxes = np.empty((B, 21824, 4), np.float32)
         probs = np.empty((B, 21824), np.float32)
         counts = np.zeros(B, np.int32)
+        if fmt == _lib.FRAME_U8_HWC_BGR and (H, W) != (1024, 1024):
+            # line :13 of the reference's detect(): im = cv2.resize(im, (1024, 1024)) -- here on the GPU
+            _lib.check(_lib.lib().fdt_model_detect_facebox_resized(self._h, _lib.ptr(x), 0, B, H, W, float(conf_thresh),
+                                                                   float(nms_thresh), _lib.ptr(boxes), _lib.ptr(probs),
+                                                                   _lib.ptr(counts), None))
+            return [(boxes[b, :counts[b]].copy(), probs[b, :counts[b]].copy()) for b in range(B)]
+        self._sync_attributes(H, W)
         _lib.check(_lib.lib().fdt_model_detect_facebox(self._h, _lib.ptr(x), fmt, B, H, W, float(conf_thresh),
                                                        float(nms_thresh), _lib.ptr(boxes), _lib.ptr(probs),
                                                        _lib.ptr(counts)))

@@ -95,6 +95,9 @@ SIGNATURES = {
                                            _vp, _vp, _vp]),
     "fdt_model_detect_facebox_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                                C.c_float, _vp, _vp]),
+    "fdt_model_detect_facebox_resized": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                                   _vp, _vp, _vp, _vp]),
+    "fdt_model_traffic": (C.c_int, [_vp, _c_f64_p, _c_f64_p, C.c_int, _vp, _c_int_p]),
     "fdt_model_num_priors": (C.c_int, [_vp, _c_int_p]),
     "fdt_model_get_tensor": (C.c_int, [_vp, C.c_char_p, _vp, C.c_longlong, _c_i64_p]),
     "fdt_model_autotune": (C.c_int, [_vp, C.c_int]),

@@ -246,6 +246,14 @@ class DetectorNet:
         _lib.check(_lib.lib().fdt_model_flops(self._h, C.byref(f)))
         return f.value
 
+    def traffic(self):
+        """(activation bytes, weight bytes, per-op bytes in profile_read() order) of one forward of the current plan:
+        the algorithmic un-fused lower bound the HBM rooflines are computed from (fdt_model_traffic)."""
+        act, wts, n = C.c_double(0), C.c_double(0), C.c_int(0)
+        per = np.zeros(512, np.float64)
+        _lib.check(_lib.lib().fdt_model_traffic(self._h, C.byref(act), C.byref(wts), 512, _lib.ptr(per), C.byref(n)))
+        return act.value, wts.value, per[:n.value].copy()
+
     def profile(self, on=True):
         _lib.check(_lib.lib().fdt_model_profile_enable(self._h, 1 if on else 0))
 

@@ -1141,13 +1141,19 @@ int make_plan(fdt_model* m, int B, int H, int W) {
   return FDT_OK;
 }
 
-int run_ops(fdt_model* m, int B, hipStream_t st) {
-  const bool prof = m->profile;
-  if (prof && m->ev.size() != m->ops.size() + 2) {
+// profiling events: ev[i] before op i, ev[n] after the last op, ev[n+1] after Detect, ev[n+2] before the ingest kernel
+int ensure_profile_events(fdt_model* m) {
+  if (m->ev.size() != m->ops.size() + 3) {
     for (auto e : m->ev) (void)hipEventDestroy(e);
-    m->ev.resize(m->ops.size() + 2);
+    m->ev.assign(m->ops.size() + 3, nullptr);
     for (auto& e : m->ev) FDT_HIP(hipEventCreate(&e));
   }
+  return FDT_OK;
+}
+
+int run_ops(fdt_model* m, int B, hipStream_t st) {
+  const bool prof = m->profile;
+  if (prof) FDT_TRY(ensure_profile_events(m));
   for (size_t i = 0; i < m->ops.size(); ++i) {
     const Op& op = m->ops[i];
     if (prof) FDT_HIP(hipEventRecord(m->ev[i], st));
@@ -1211,6 +1217,10 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
   if (fresh && st != m->stream) FDT_HIP(hipStreamSynchronize(m->stream));   // priors were built there
   const hipMemcpyKind kind = frames_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   float* x = m->tensors[0].d;
+  if (m->profile) {
+    FDT_TRY(ensure_profile_events(m));
+    FDT_HIP(hipEventRecord(m->ev[m->ops.size() + 2], st));
+  }
   if (format == FDT_FRAME_U8_HWC_BGR && src_h > 0 && (src_h != H || src_w != W)) {
     // device-side ingest: cv2.resize(frame, (W, H)) + mean subtraction in one kernel
     const unsigned char* src = (const unsigned char*)frames;
@@ -1498,6 +1508,30 @@ extern "C" int fdt_model_detect_facebox_dev(fdt_model* m, const void* frames_dev
   m->conf_t = conf_thresh;
   m->nms_t = nms_thresh;
   return forward_impl(m, frames_dev, true, format, B, H, W, true, nullptr, counts_dev, (hipStream_t)stream);
+}
+
+// detect(im) of FACEBOX/My_test_facebox.py:12-36 INCLUDING its first line, im = cv2.resize(im, (1024, 1024)) (:13):
+// B raw u8 BGR frames of src_h x src_w (e.g. 2160 x 3840) are resized on the GPU (8-bit INTER_LINEAR restatement, parity
+// with cv2 itself unpinned), divided by 255, run through FaceBox, softmax, decode_np + nms_np.
+extern "C" int fdt_model_detect_facebox_resized(fdt_model* m, const void* frames, int frames_on_device, int B,
+                                                int src_h, int src_w, float conf_thresh, float nms_thresh,
+                                                float* boxes, float* probs, int* counts, void* stream) {
+  FDT_REQUIRE(m && m->arch == FDT_ARCH_FACEBOX, FDT_ERR_ARG, "fdt_model_detect_facebox_resized: not a FaceBox model");
+  FDT_REQUIRE(nms_thresh > 0.f, FDT_ERR_ARG, "nms threshold must be positive");
+  FDT_REQUIRE(src_h >= 1 && src_w >= 1, FDT_ERR_ARG, "fdt_model_detect_facebox_resized: bad source size");
+  m->conf_t = conf_thresh;
+  m->nms_t = nms_thresh;
+  if (frames_on_device)
+    return forward_impl(m, frames, true, FDT_FRAME_U8_HWC_BGR, B, 1024, 1024, true, nullptr, counts,
+                        (hipStream_t)stream, src_h, src_w);
+  FDT_REQUIRE(boxes && probs && counts, FDT_ERR_ARG, "fdt_model_detect_facebox_resized: null output");
+  FDT_TRY(forward_impl(m, frames, false, FDT_FRAME_U8_HWC_BGR, B, 1024, 1024, true, nullptr, nullptr, nullptr, src_h,
+                       src_w));
+  FDT_HIP(hipMemcpyAsync(counts, m->d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+  FDT_HIP(hipMemcpyAsync(boxes, m->d_fb_boxes, (size_t)B * m->P * 16, hipMemcpyDeviceToHost, m->stream));
+  FDT_HIP(hipMemcpyAsync(probs, m->d_fb_probs, (size_t)B * m->P * 4, hipMemcpyDeviceToHost, m->stream));
+  FDT_HIP(hipStreamSynchronize(m->stream));
+  return FDT_OK;
 }
 
 extern "C" int fdt_model_forward(fdt_model* m, const void* frames, int format, int B, int H, int W,
@@ -1910,25 +1944,65 @@ extern "C" int fdt_model_profile_enable(fdt_model* m, int on) {
 
 extern "C" int fdt_model_profile_read(fdt_model* m, int max, char* names, float* ms, double* flops, int* n) {
   FDT_REQUIRE(m && n, FDT_ERR_ARG, "fdt_model_profile_read: bad argument");
-  FDT_REQUIRE(m->profile && m->ev.size() == m->ops.size() + 2, FDT_ERR_STATE,
+  FDT_REQUIRE(m->profile && m->ev.size() == m->ops.size() + 3, FDT_ERR_STATE,
               "fdt_model_profile_read: profiling not enabled or no forward since enabling");
   FDT_HIP(hipStreamSynchronize(m->stream));
-  int cnt = (int)m->ops.size() + 1;   // + the Detect stage
+  const int nops = (int)m->ops.size();
+  int cnt = nops + 2;   // + the Detect stage + the ingest kernel (u8 -> f32 NCHW, optional resize) in front
   *n = cnt;
   for (int i = 0; i < cnt && i < max; ++i) {
     float t = 0.f;
-    hipError_t e = hipEventElapsedTime(&t, m->ev[i], m->ev[i + 1]);
+    hipError_t e = i <= nops ? hipEventElapsedTime(&t, m->ev[i], m->ev[i + 1])
+                             : hipEventElapsedTime(&t, m->ev[nops + 2], m->ev[0]);
     if (e != hipSuccess) t = 0.f;
     if (ms) ms[i] = t;
-    if (flops) flops[i] = i < (int)m->ops.size() ? m->ops[i].flops : 0.0;
+    if (flops) flops[i] = i < nops ? m->ops[i].flops : 0.0;
     if (names) {
-      std::string nm = i < (int)m->ops.size() ? m->ops[i].name : std::string("detect");
+      std::string nm = i < nops ? m->ops[i].name : std::string(i == nops ? "detect" : "ingest");
       if (i < (int)m->ops.size() && m->ops[i].type == OP_CONV)
         nm += "#k" + std::to_string((int)m->ops[i].kind) + "t" + std::to_string((int)m->ops[i].tile) + "s" +
               std::to_string(m->ops[i].ca.ksplit);
       snprintf(names + (size_t)i * 48, 48, "%s", nm.c_str());
     }
   }
+  return FDT_OK;
+}
+
+// Algorithmic (un-fused lower bound) HBM bytes of ONE forward of the current plan: every op reads its input tensor(s)
+// and writes its output once (f32), every conv reads its weights once.  SURVEY.md 8(d): the per-unit figure the HBM
+// roofline of the bandwidth-bound nets (FaceBoxes, the depthwise half of try3) is computed from.  Per-op values follow
+// the order of fdt_model_profile_read (ops..., then 0 for "detect" / "ingest").
+extern "C" int fdt_model_traffic(fdt_model* m, double* act_bytes, double* weight_bytes, int max, double* per_op,
+                                 int* n) {
+  FDT_REQUIRE(m, FDT_ERR_ARG, "fdt_model_traffic: null handle");
+  FDT_REQUIRE(m->pB > 0 && !m->ops.empty(), FDT_ERR_STATE, "fdt_model_traffic: no forward has run yet");
+  double act = 0, wts = 0;
+  int i = 0;
+  for (auto& op : m->ops) {
+    double b = 0, w = 0;
+    auto tb = [&](int t) { return t >= 0 ? 4.0 * m->pB * m->tensors[t].C * m->tensors[t].H * m->tensors[t].W : 0.0; };
+    if (op.type == OP_CONV) {
+      const ConvGeom g = conv_geom(conv_base_kind(op.kind));
+      b = 4.0 * op.ca.B * ((double)op.ca.Cin * op.ca.Hin * op.ca.Win + (double)op.ca.Cout * op.ca.Hout * op.ca.Wout);
+      if (op.ca.res) b += 4.0 * op.ca.B * (double)op.ca.Cout * op.ca.Hout * op.ca.Wout;
+      if (op.ca.up) b += 4.0 * op.ca.B * (double)op.ca.Cout * op.ca.up_h * op.ca.up_w;
+      w = 4.0 * ((double)op.ca.Cout * op.ca.Cin * g.kh * g.kw + op.ca.Cout);
+    } else if (op.type == OP_HEADFIN || op.type == OP_MBOXFIN) {
+      b = 2.0 * tb(op.in_t);
+    } else {
+      b = tb(op.in_t) + tb(op.out_t);
+      if (op.type == OP_DW) w = 4.0 * m->tensors[op.in_t].C * (op.ksize * op.ksize + 1);
+    }
+    act += b;
+    wts += w;
+    if (per_op && i < max) per_op[i] = b + w;
+    ++i;
+  }
+  if (per_op)
+    for (int k = i; k < i + 2 && k < max; ++k) per_op[k] = 0.0;
+  if (n) *n = i + 2;
+  if (act_bytes) *act_bytes = act;
+  if (weight_bytes) *weight_bytes = wts;
   return FDT_OK;
 }
 

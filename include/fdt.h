@@ -210,6 +210,12 @@ int fdt_model_detect_facebox(fdt_model* m, const void* frames, int format, int B
                              float conf_thresh, float nms_thresh, float* boxes, float* probs, int* counts);
 int fdt_model_detect_facebox_dev(fdt_model* m, const void* frames_dev, int format, int B, int H, int W,
                                  float conf_thresh, float nms_thresh, int* counts_dev, void* stream);
+/* The same with line :13 of the reference's detect(), im = cv2.resize(im, (1024, 1024)), done on the GPU: frames are
+ * B raw u8 BGR images of src_h x src_w (BASELINE config 5: 2160 x 3840).  frames_on_device != 0: device pointers for
+ * frames / counts, asynchronous on `stream`, boxes / probs stay on the device ("fb_boxes" / "fb_probs").            */
+int fdt_model_detect_facebox_resized(fdt_model* m, const void* frames, int frames_on_device, int B, int src_h,
+                                     int src_w, float conf_thresh, float nms_thresh, float* boxes, float* probs,
+                                     int* counts, void* stream);
 /* after a forward: number of priors, and a named activation of the last forward
  * ("loc","conf","priors","c2".."c7","src0".."src5", ...) for stage-level parity tests.       */
 int fdt_model_num_priors(fdt_model* m, int* P);
@@ -229,10 +235,14 @@ int fdt_model_import_plan(fdt_model* m, const char* text);
  * launches (also: env FDT_GRAPH=0 at create time).  Per-op profiling always runs eagerly.  Results are identical.    */
 int fdt_model_enable_graph(fdt_model* m, int on);
 /* per-op timing of the next forwards (HIP events around every launch on the model stream).
- * fdt_model_profile_read: fills up to max entries; returns count in *n.                      */
+ * fdt_model_profile_read: fills up to max entries; returns count in *n.  Entries: one per op of the plan, then
+ * "detect" (decode + NMS) and "ingest" (the u8 -> f32 NCHW / resize kernel in front of the first op).            */
 int fdt_model_profile_enable(fdt_model* m, int on);
 int fdt_model_profile_read(fdt_model* m, int max, char* names /* max*48 */, float* ms,
                            double* flops, int* n);
+/* Algorithmic HBM bytes of one forward of the current plan (every op reads its inputs and writes its output once,
+ * f32; convs read their weights once): totals, and per op in the order of fdt_model_profile_read.               */
+int fdt_model_traffic(fdt_model* m, double* act_bytes, double* weight_bytes, int max, double* per_op, int* n);
 /* algorithmic conv FLOPs (2*MAC, live convs only) of one frame at the last forward's size    */
 int fdt_model_flops(fdt_model* m, double* flops);
 

@@ -507,8 +507,118 @@ def gen_facebox():
     save("facebox", **out)
 
 
+# ----------------------------------------------------------------------------- round 2: configs VERDICT r01 found untested
+def gen_nets_r2():
+    """C1 (Res50 640x640, My_test.py's size) and C3 (try3 1024x1024 BATCH 8: eight seeded frames through ONE call of the
+    reference module, pyramid_mb2_try3.py:218-340) -> tests/golden/nets_r2.npz.  Stored per image: the Detect rows, a
+    strided sample of the pre-Detect loc / conf, and their sha256."""
+    from layers import PriorBoxLayer, Detect
+    from oracle import pyramidbox as opb
+    out, meta = {}, {}
+    for arch, H, W, seeds in (("res50", 640, 640, [640]), ("try3", 1024, 1024, [2000 + i for i in range(8)])):
+        sd = synth.make_state_dict(arch, seed=0)
+        net = _ref_net(arch, sd)
+        frames = np.stack([synth.make_frames(1, H, W, seed=sv)[0] for sv in seeds])
+        x = torch.from_numpy(np.stack([opb.preprocess(f)[0] for f in frames]))
+        if arch == "res50":
+            net.priorbox = PriorBoxLayer(W, H)
+            ct, nt = 0.3, 0.5
+        else:
+            net.priorbox = PriorBoxLayer(W, H, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256))
+            ct, nt = 0.2, 0.35
+        net.firstTime = True
+        real = Detect(2, 0, 750, ct, nt)
+        cap = {}
+
+        def spy(loc, conf, priors, _real=real, _cap=cap):
+            _cap["loc"], _cap["conf"] = loc.numpy().copy(), conf.numpy().copy()
+            return _real(loc, conf, priors)
+        net.detect = spy
+        with torch.no_grad():
+            y = net(x).numpy()
+        key = "%s_%dx%d_b%d" % (arch, H, W, len(seeds))
+        P = int(cap["loc"].shape[1])
+        sel = np.linspace(0, P - 1, 512).astype(np.int64)
+        out[key + "_sel"] = sel
+        n_outs = []
+        for b in range(len(seeds)):
+            n_out = int((y[b, 1, :, 0] > 0).sum())
+            n_outs.append(n_out)
+            out["%s_out%d" % (key, b)] = y[b, 1, :max(n_out, 1)]
+            out["%s_loc_s%d" % (key, b)] = cap["loc"][b, sel]
+            out["%s_conf_s%d" % (key, b)] = cap["conf"][b, sel]
+        assert not y[:, 0].any()
+        meta[key] = {"H": H, "W": W, "frame_seeds": seeds, "conf_t": ct, "nms_t": nt, "n_out": n_outs, "P": P,
+                     "n_cand": [int((cap["conf"][b, :, 1] > np.float32(ct)).sum()) for b in range(len(seeds))],
+                     "loc_sha": sha(cap["loc"]), "conf_sha": sha(cap["conf"])}
+        print(key, meta[key])
+    out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    save("nets_r2", **out)
+
+
+def gen_facebox_r2():
+    """FaceBoxes on SIX more of the reference's sample JPEGs (image_and_anno/test_image/try1), chosen for multi-face
+    outputs, through the reference's own FaceBox + DataEncoder.decode_np with the in-tree weights
+    (FACEBOX/My_test_facebox.py:12-36 after the resize).  Frames are stored post-resize (PIL bilinear; cv2 is absent)."""
+    import torch.nn.functional as F
+    from PIL import Image
+    from FACEBOX.networks import FaceBox
+    from FACEBOX.encoderl import DataEncoder
+    sd = torch.load(os.path.join(_refshim.REFERENCE, "FACEBOX", "faceboxes.pt"), map_location="cpu", weights_only=True)
+    net = FaceBox()
+    net.load_state_dict(sd)
+    net.eval()
+    enc = DataEncoder()
+    imgdir = os.path.join(_refshim.REFERENCE, "image_and_anno", "test_image", "try1")
+    names = sorted(os.listdir(imgdir))
+    res = []
+    for nm in names:
+        im = Image.open(os.path.join(imgdir, nm)).convert("RGB").resize((1024, 1024), Image.BILINEAR)
+        fr = np.ascontiguousarray(np.asarray(im)[:, :, ::-1])
+        x = torch.from_numpy(fr.transpose((2, 0, 1)).copy()).float().div(255)
+        with torch.no_grad():
+            loc, conf = net(x[None])
+        confs = F.softmax(conf.squeeze(0), dim=1)
+        boxes, probs = enc.decode_np(loc.squeeze(0), confs)
+        res.append((len(probs), nm, fr, boxes, probs, int((confs[:, 1] > 0.35).sum())))
+        print("facebox_r2", nm, len(probs), "faces,", res[-1][5], "candidates")
+    res.sort(key=lambda r: (-r[0], r[1]))
+    out, meta = {}, {}
+    for i, (n, nm, fr, boxes, probs, ncand) in enumerate(res[:6]):
+        key = "img%d" % i
+        out[key + "_frame"], out[key + "_boxes"], out[key + "_probs"] = fr, boxes, probs
+        meta[key] = {"n": int(n), "n_cand": ncand, "file": nm, "top": float(probs.max()),
+                     "min_gap": float(np.min(np.abs(np.diff(np.sort(probs))))) if n > 1 else None}
+    print("facebox_r2 kept", {k: (v["n"], v["file"]) for k, v in meta.items()})
+    out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    save("facebox_r2", **out)
+
+
+def gen_tp_fp_fixture():
+    """gen_tp_fp (reference draw_curve/draw_pr_roc.py:5-19).  The module runs its plotting script on import, so -- as for
+    the inline tracker -- the function's own lines are read from the reference file at generation time and exec'd."""
+    src = open(os.path.join(_refshim.REFERENCE, "draw_curve", "draw_pr_roc.py")).read().splitlines()
+    body = "\n".join(src[4:19])
+    assert body.startswith("def gen_tp_fp(tf_conf):") and "return true_pos, false_pos" in body
+    ns = {"np": np}
+    exec(compile(body, "ref_gen_tp_fp", "exec"), ns)
+    rng = np.random.default_rng(77)
+    out = {}
+    for nm, M, p in (("a", 257, 0.6), ("b", 40, 0.1), ("c", 1, 1.0), ("d", 1500, 0.35)):
+        flags = (rng.uniform(size=M) < p).astype(np.float64)
+        flags[rng.integers(0, M)] *= 2.0                      # any non-zero counts (np.count_nonzero)
+        conf = np.sort(rng.uniform(size=M))[::-1]
+        tf = np.stack([flags, conf])
+        tp, fp = ns["gen_tp_fp"](tf)
+        out["tf_" + nm], out["tp_" + nm], out["fp_" + nm] = tf, tp, fp
+    tp, fp = ns["gen_tp_fp"](np.zeros((2, 0)))
+    out["tf_empty"], out["tp_empty"], out["fp_empty"] = np.zeros((2, 0)), tp, fp
+    save("tp_fp", **out)
+
+
 GENS = {"facebox": gen_facebox, "priors": gen_priors, "detect": gen_detect, "iou": gen_iou, "tracker": gen_tracker, "nets": gen_nets,
-        "nets45": gen_nets45, "nets12": gen_nets12}
+        "nets45": gen_nets45, "nets12": gen_nets12, "nets_r2": gen_nets_r2,
+        "facebox_r2": gen_facebox_r2, "tp_fp": gen_tp_fp_fixture}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

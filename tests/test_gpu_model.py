@@ -309,3 +309,51 @@ def test_try12_vs_reference_fixture(try12, synth, size):
     d_iou, d_sc = match_detections(y[0, 1], np.vstack([exp, np.zeros((750 - exp.shape[0], 5), np.float32)]),
                                    m["n_out"])
     assert d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
+
+
+# ------------------------------------------------------------------ round-2 fixtures: C1 640x640 and C3 batch 8
+def test_res50_640x640_vs_reference_fixture(res50, synth):
+    """Config 1 of BASELINE.json (the size My_test.py feeds, reference My_test.py:31-36)."""
+    d, meta = load_npz("nets_r2")
+    key = "res50_640x640_b1"
+    m = meta[key]
+    frame = synth.make_frames(1, 640, 640, seed=m["frame_seeds"][0])[0]
+    res50.priorbox = M("layers").PriorBoxLayer(640, 640); res50.firstTime = True
+    res50.detect = M("layers").Detect(2, 0, 750, m["conf_t"], m["nms_t"])
+    y = res50(frame).numpy()
+    exp = d[key + "_out0"]
+    d_iou, d_sc = match_detections(y[0, 1], np.vstack([exp, np.zeros((750 - exp.shape[0], 5), np.float32)]),
+                                   m["n_out"][0])
+    assert d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
+    sel = d[key + "_sel"]
+    np.testing.assert_allclose(res50.get_tensor("loc")[0, sel], d[key + "_loc_s0"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(res50.get_tensor("conf")[0, sel], d[key + "_conf_s0"], atol=SCORE_ATOL, rtol=0)
+
+
+def test_try3_1024_batch8_vs_reference_fixture(try3, synth):
+    """Config 3 of BASELINE.json: ONE batched forward of eight 1024x1024 frames (the depthwise / batched conv plan that
+    bench.py --arch try3 --batch 8 times) against the reference's own batch-8 forward, per image."""
+    d, meta = load_npz("nets_r2")
+    key = "try3_1024x1024_b8"
+    m = meta[key]
+    frames = np.stack([synth.make_frames(1, 1024, 1024, seed=s)[0] for s in m["frame_seeds"]])
+    PB = M("layers").PriorBoxLayer
+    try3.priorbox = PB(1024, 1024, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256)); try3.firstTime = True
+    try3.detect = M("layers").Detect(2, 0, 750, m["conf_t"], m["nms_t"])
+    import os
+    plan = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "face-detection-and-tracking_amd",
+                        "tuned", "try3_1024x1024_b8.plan")
+    try3.import_plan(open(plan).read())           # the committed plan bench.py uses for this config
+    y = try3(frames).numpy()
+    assert y.shape == (8, 2, 750, 5) and not y[:, 0].any()
+    sel = d[key + "_sel"]
+    loc, conf = try3.get_tensor("loc"), try3.get_tensor("conf")
+    for b in range(8):
+        exp = d["%s_out%d" % (key, b)]
+        d_iou, d_sc = match_detections(y[b, 1], np.vstack([exp, np.zeros((750 - exp.shape[0], 5), np.float32)]),
+                                       m["n_out"][b])
+        assert d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL, (b, d_iou, d_sc)
+        np.testing.assert_allclose(loc[b, sel], d["%s_loc_s%d" % (key, b)], atol=2e-4, rtol=1e-4)
+        np.testing.assert_allclose(conf[b, sel], d["%s_conf_s%d" % (key, b)], atol=SCORE_ATOL, rtol=0)
+    # and the second (graph-replayed) batched forward returns the same bits
+    assert np.array_equal(try3(frames).numpy(), y)
