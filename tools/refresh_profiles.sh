@@ -1,21 +1,30 @@
 #!/bin/bash
-# Regenerates profiles/<round>/ on the GPU box: rocprofv3 kernel stats of the default bench command, two
-# separate PMC passes (FETCH_SIZE, WRITE_SIZE) summarised per kernel, the per-layer HIP-event table and the
-# bench lines of the other configurations.  Run through gpurun from the repo root:
-#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh r01'
+# Regenerates profiles/<round>/ on the GPU box: rocprofv3 kernel stats of the default bench command, two separate PMC
+# passes (FETCH_SIZE, WRITE_SIZE) summarised per kernel, MFMA-busy PMC of the dominant Winograd kernel and of the three
+# 1x1 instantiations that take the most time, the per-layer HIP-event table and the bench lines of the other
+# configurations.  Run through gpurun from the repo root:
+#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh r02'
 # Outputs land in gpurun_out/profiles_<round>/ (copy them into profiles/<round>/ afterwards).
 set -e -o pipefail
-R=${1:-r01}
+R=${1:-r02}
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT /tmp/raw
 export TMPDIR=/tmp
+PLAN=face-detection-and-tracking_amd/tuned/res50_1024x1024_b1.plan
+# the (kernel class, tile) pairs the single-kernel PMC passes below measure must still be what the committed plan runs:
+#   kind tile  layer the shape is taken from
+check_plan() { grep -q "^$1 $2 $3 " $PLAN || { echo "refresh_profiles: $PLAN no longer runs '$1' as kind $2 tile $3 -- update the PMC list" >&2; exit 1; }; }
+check_plan conv2_SSH.conv1 8 30
+check_plan layer3.1.conv1 10 3
+check_plan layer1.0.conv3 0 12
+check_plan layer2.1.conv3 0 6
 B="python bench.py --steps 48 --warmup 8 --cpu-frames 0"
-timeout -k 10 300 python bench.py --steps 64 --warmup 8 > $OUT/bench_line_res50_1024.json
+timeout -k 10 400 python bench.py --steps 64 --warmup 8 --host-frames 64 > $OUT/bench_line_res50_1024.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt --output-format csv -- $B > $OUT/bench_under_rocprof.log 2>&1
 cp /tmp/raw/kt_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv
-# 48 timed + 8 warm-up + 5 profiled frames in that command
-python tools/rocprof_conv_summary.py $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv 61 $OUT/bench_line_res50_1024.json > $OUT/rocprof_vs_bench.txt
-P="python bench.py --steps 8 --warmup 2 --cpu-frames 0 --inflight 1 --profile-frames 1"
+# that command runs 8 warm-up + 48 timed + 56 parity (sequential re-run) + 5 profiled forwards
+python tools/rocprof_conv_summary.py $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv 117 $OUT/bench_line_res50_1024.json > $OUT/rocprof_vs_bench.txt
+P="python bench.py --steps 8 --warmup 2 --cpu-frames 0 --inflight 1 --profile-frames 1 --graph 0"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/raw -o pmc_$C --output-format csv -- $P > /tmp/raw/pmc_$C.log 2>&1
   python tools/summarize_pmc.py /tmp/raw/pmc_${C}_counter_collection.csv $OUT/pmc_${C}_by_kernel.csv
@@ -23,11 +32,26 @@ done
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/raw -o calib --output-format csv -- python tools/one_conv.py 0 0 1 256 256 256 128 > /tmp/raw/calib.log 2>&1
 python tools/summarize_pmc.py /tmp/raw/calib_counter_collection.csv $OUT/pmc_FETCH_SIZE_calibration_1x1_67MB.csv
 python tools/traffic_json.py $OUT/pmc_FETCH_SIZE_by_kernel.csv $OUT/pmc_WRITE_SIZE_by_kernel.csv 105 $OUT/conv_hbm_traffic.json $OUT/pmc_FETCH_SIZE_calibration_1x1_67MB.csv
+# matrix-pipe occupancy of the production kernels (one kernel per process; SQ counters + GRBM in one pass)
+#        name                       kind tile split cin  h   w  cout res
+pmc_one() {
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
+    -d /tmp/raw -o mfma_$1 --output-format csv -- python tools/one_conv.py $2 $3 $4 $5 $6 $7 $8 $9 8 > $OUT/pmc_mfma_$1_times.txt 2>&1 || \
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
+    -d /tmp/raw -o mfma_$1 --output-format csv -- python tools/one_conv.py $2 $3 $4 $5 $6 $7 $8 $9 8 > $OUT/pmc_mfma_$1_times.txt 2>&1
+  python tools/summarize_pmc.py /tmp/raw/mfma_$1_counter_collection.csv $OUT/pmc_mfma_$1.csv
+}
+pmc_one wino4_256to256_256x256   8 30 1 256 256 256 256 0
+pmc_one 1x1k32_1024to256_64x64   10 3 1 1024 64 64 256 0
+pmc_one 1x1_64to256_256x256_res  0 12 1 64 256 256 256 1
+pmc_one 1x1_128to512_128x128_res 0 6 1 128 128 128 512 1
 timeout -k 10 300 python tools/profile_layers.py > $OUT/per_layer_hip_events_res50_1024.txt
 timeout -k 10 300 python bench.py --steps 64 --warmup 8 --height 480 --width 640 --cpu-frames 2 > $OUT/bench_line_res50_640x480.json
-timeout -k 10 300 python bench.py --steps 128 --warmup 16 --source 1080x1920 --height 480 --width 640 --cpu-frames 3 > $OUT/bench_line_res50_640x480_from_1080p.json
+timeout -k 10 300 python bench.py --steps 128 --warmup 16 --source 1080x1920 --height 480 --width 640 --cpu-frames 3 --host-frames 128 > $OUT/bench_line_res50_640x480_from_1080p.json
 timeout -k 10 300 python bench.py --steps 32 --warmup 4 --height 1080 --width 1920 --cpu-frames 1 > $OUT/bench_line_res50_1920x1080.json
-timeout -k 10 300 python bench.py --steps 64 --warmup 8 --arch try3 --cpu-frames 4 > $OUT/bench_line_try3_1024.json
+timeout -k 10 300 python bench.py --steps 64 --warmup 8 --arch try3 --cpu-frames 3 > $OUT/bench_line_try3_1024.json
 timeout -k 10 300 python bench.py --steps 32 --warmup 4 --arch try3 --batch 8 --cpu-frames 3 > $OUT/bench_line_try3_1024_b8.json
-timeout -k 10 300 python bench.py --arch facebox --batch 16 --steps 50 --warmup 5 > $OUT/bench_line_facebox_b16.json
+timeout -k 10 300 python bench.py --arch facebox --batch 16 --steps 50 --warmup 5 > $OUT/bench_line_facebox_4k_b16.json
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o ktfb --output-format csv -- python bench.py --arch facebox --batch 16 --steps 50 --warmup 5 --cpu-frames 0 > $OUT/bench_facebox_under_rocprof.log 2>&1
+cp /tmp/raw/ktfb_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_facebox_4k_b16.csv
 tail -c 600 $OUT/bench_line_res50_1024.json

@@ -22,7 +22,15 @@ print("conv + reduce, ms per frame            : %.3f" % ((tot(conv) + tot(red)) 
 if len(sys.argv) > 3:
     d = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
     r = d["roofline"]
-    print("bench.py (HIP events, same ops)        : %.3f ms per frame, %.2f us per op, %.2f TFLOP/s algorithmic" %
-          (r["conv_ms_per_frame"], r["avg_launch_us"], r["achieved"]))
-    print("algorithmic GFLOP per frame            : %.3f -> %.2f TFLOP/s from the rocprof durations" %
-          (r["algorithmic_gflop_per_frame"], r["algorithmic_gflop_per_frame"] / ((tot(conv) + tot(red)) / frames / 1e6)))
+    cs = r["conv_stack"]
+    print("bench.py (HIP events, same ops)        : %.3f ms per frame over %d launches; %.2f TFLOP/s executed, %.2f algorithmic" %
+          (cs["ms_per_frame"], cs["launches_per_frame"], cs["achieved_executed"], cs["achieved_algorithmic"]))
+    ms = (tot(conv) + tot(red)) / frames / 1e6
+    print("from the rocprof durations             : %.2f TFLOP/s executed (%.3f GFLOP/frame), %.2f algorithmic (%.3f GFLOP/frame)" %
+          (cs["executed_gflop_per_frame"] / ms, cs["executed_gflop_per_frame"], cs["algorithmic_gflop_per_frame"] / ms,
+           cs["algorithmic_gflop_per_frame"]))
+    dom = max(conv, key=lambda x: float(x["TotalDurationNs"]))
+    print("dominant kernel by rocprof time        : %s" % dom["Name"])
+    print("   calls/frame %.1f, average %.2f us (bench.py: %s, %d launches/frame, average %.2f us)" %
+          (int(dom["Calls"]) / frames, float(dom["TotalDurationNs"]) / int(dom["Calls"]) / 1e3, r["kernel"],
+           r["launches_per_frame"], r["avg_launch_us"]))
