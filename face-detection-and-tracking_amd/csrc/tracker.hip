@@ -52,6 +52,16 @@ __device__ __forceinline__ double iou64(const double* a, const double* b) {
   return inter / uni;
 }
 
+// f32 image of a box for the overlap pre-test, or the everything-box when the pre-test would not be exact for it.
+__device__ __forceinline__ float4 prefilter_box(double b0, double b1, double b2, double b3) {
+  const float f0 = (float)b0, f1 = (float)b1, f2 = (float)b2, f3 = (float)b3;
+  const float s = (f0 + f1) + (f2 + f3);
+  const bool ok = (double)f0 == b0 && (double)f1 == b1 && (double)f2 == b2 && (double)f3 == b3 && (s - s) == 0.0f &&
+                  f2 > f0 && f3 > f1;
+  const float inf = __builtin_huge_valf();
+  return ok ? make_float4(f0, f1, f2, f3) : make_float4(-inf, -inf, inf, inf);
+}
+
 // numpy argmax order: NaN beats everything, then larger value, then lower index.
 __device__ __forceinline__ bool better(double av, int ai, double bv, int bi) {
   if (bi < 0) return ai >= 0;
@@ -62,8 +72,14 @@ __device__ __forceinline__ bool better(double av, int ai, double bv, int bi) {
   return ai < bi;
 }
 
+#ifdef FDT_TRK_TIMING   // per-phase device clocks for tools/tracker_bench.py (not part of the product build)
+__device__ long long g_trk_time[8];
+#define TT(i) if (tid == 0) { long long c_ = wall_clock64(); g_trk_time[i] += c_ - tlast; tlast = c_; }
+#else
+#define TT(i)
+#endif
 constexpr int TRK_THREADS = 1024;             // one workgroup of 16 waves per frame
-constexpr int TRK_LDS_PER_SLOT = 72;          // bytes of LDS per detection/track slot (see the carve-up below)
+constexpr int TRK_LDS_PER_SLOT = 88;          // bytes of LDS per detection/track slot (see the carve-up below)
 
 // G consecutive frames in one launch <<<1, TRK_THREADS, M * TRK_LDS_PER_SLOT>>> (G = 1 for the single-frame entry
 // points; G = world size after the all-gather of a frame-parallel step: one launch instead of G).  `dets_in`
@@ -83,8 +99,12 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
     int t_min, const double* __restrict__ dets_in, int n_in, const float* __restrict__ det_out_base,
     long long det_stride, int G, int num_classes, int top_k, float fw, float fh, float score_thr,
     char* __restrict__ log, long long log_cap) {
-  extern __shared__ double smem_d[];
-  double* dbox = smem_d;                     // [M][4] this frame's boxes
+  extern __shared__ __attribute__((aligned(16))) double smem_d[];
+  // [M] f32 copy of this frame's boxes for the overlap pre-test of phase 1: the box itself when its coordinates are
+  // finite, exactly representable in f32 and x2 > x1, y2 > y1 (every box the Detect layer emits), else
+  // (-inf,-inf,+inf,+inf) = "may overlap anything", which sends every pair with it down the exact f64 path
+  float4* fbox = (float4*)smem_d;
+  double* dbox = smem_d + (size_t)M * 2;     // [M][4] this frame's boxes
   double* dscore = dbox + (size_t)M * 4;     // [M]
   double* best_v = dscore + M;               // [M] per active track: best IoU over all detections ...
   double* tmaxs = best_v + M;                // [M] ... and the track's max_score
@@ -93,7 +113,9 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
   int* tids = tlens + M;                     // [M]
   volatile int* det_tid = tids + M;          // [M] track id that took det j, -1 while free
   __shared__ int s_first_fail;
-  __shared__ int s_n_active, s_next_id, s_frame_num;
+  __shared__ double s_pv[TRK_THREADS];       // phase 1: per-segment partial arg-max (value, index) per track
+  __shared__ int s_pi[TRK_THREADS];
+  __shared__ int s_n_active, s_next_id, s_frame_num, s_nupd, s_nfin;
   __shared__ long long s_cursor;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = TRK_THREADS / 64;
@@ -104,6 +126,9 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
     s_cursor = st->log_cursor;
   }
   __syncthreads();
+#ifdef FDT_TRK_TIMING
+  long long tlast = wall_clock64();
+#endif
   for (int g = 0; g < G; ++g) {
   const float* det_out = det_out_base ? det_out_base + (long long)g * det_stride : nullptr;
   const ActiveSet cur = (g & 1) ? set_b : set_a;
@@ -140,6 +165,7 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
         d[0] = b0; d[1] = b1; d[2] = b2; d[3] = b3; d[4] = sc;
         double* l = dbox + (size_t)(n + j) * 4;
         l[0] = b0; l[1] = b1; l[2] = b2; l[3] = b3;
+        fbox[n + j] = prefilter_box(b0, b1, b2, b3);
         dscore[n + j] = sc;
       }
       n += cnt;
@@ -149,6 +175,7 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
       if (tid == 0) {
         dets[0] = 0; dets[1] = 0; dets[2] = 0; dets[3] = 0; dets[4] = 0.4;
         dbox[0] = 0; dbox[1] = 0; dbox[2] = 0; dbox[3] = 0; dscore[0] = 0.4;
+        fbox[0] = prefilter_box(0, 0, 0, 0);
       }
       n = 1;
     }
@@ -159,88 +186,226 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
       double* d = dets + (long long)j * 5;
       double* l = dbox + (size_t)j * 4;
       for (int k = 0; k < 4; ++k) { d[k] = r[k]; l[k] = r[k]; }
+      fbox[j] = prefilter_box(r[0], r[1], r[2], r[3]);
       d[4] = r[4];
       dscore[j] = r[4];
     }
   }
+  TT(0)
   int* tid_log = (int*)(log + cursor + 16 + (long long)n * 40);
   int* fin_log = tid_log + n;
   for (int j = tid; j < n; j += TRK_THREADS) det_tid[j] = -1;
   __syncthreads();
 
-  // ---- phase 1: every track's arg-max over all detections, tracks spread over the waves --------
+  // ---- phase 1: every track's arg-max over all detections -----------------------------------------
+  // One LANE per track, 64 tracks per wave, the detections streamed past them as LDS broadcasts: no cross-lane
+  // reduction, and the running arg-max of a lane sees its detections in index order.  When there are fewer than 16
+  // chunks of 64 tracks the detection range is cut into S segments so that all 16 waves work; the per-segment results
+  // are merged below (`better` is a total order, so the merge order does not matter).
+  // Per (track, detection) pair only the f32 overlap pre-test runs (exact: both boxes are f32-exact with positive
+  // extent, or one of them is the everything-box).  An empty intersection makes numpy's inter +0 and its IoU
+  // 0 / (area_a + area_b) = +0 with both areas positive and finite, so all such detections tie at 0 and only the first
+  // of them can be the arg-max; the (few) overlapping ones are remembered and evaluated exactly in f64 afterwards.
   const int T = s_n_active;
-  for (int t = wave; t < T; t += NW) {
-    const double tb[4] = {cur.box[t * 4 + 0], cur.box[t * 4 + 1], cur.box[t * 4 + 2], cur.box[t * 4 + 3]};
-    double bv = 0.0;
-    int bi = -1;
-    for (int j = lane; j < n; j += 64) {
-      double v = iou64(dbox + (size_t)j * 4, tb);
-      if (better(v, j, bv, bi)) { bv = v; bi = j; }
+  {
+    constexpr int KC = 4;                      // overlapping detections remembered per (track, segment)
+    const int n_chunks = (T + 63) >> 6;
+    const int S = (n_chunks > 0 && n_chunks < NW) ? NW / n_chunks : 1;
+    const float inf = __builtin_huge_valf();
+    for (int w = wave; w < n_chunks * S; w += NW) {
+      const int chunk = w % n_chunks, seg = w / n_chunks;
+      const int t = chunk * 64 + lane;
+      const bool in = t < T;
+      double tb[4] = {0, 0, 0, 0};
+      float4 tf = make_float4(inf, inf, -inf, -inf);          // overlaps nothing: lanes past the last track
+      if (in) {
+        tb[0] = cur.box[t * 4 + 0]; tb[1] = cur.box[t * 4 + 1]; tb[2] = cur.box[t * 4 + 2]; tb[3] = cur.box[t * 4 + 3];
+        tf = prefilter_box(tb[0], tb[1], tb[2], tb[3]);
+        if (seg == 0) {
+          tmaxs[t] = cur.max_score[t];
+          tlens[t] = cur.len[t];
+          tids[t] = cur.id[t];
+        }
+      }
+      const int j_lo = (int)((long long)n * seg / S), j_hi = (int)((long long)n * (seg + 1) / S);
+      // The pair test is four compares (min(a2,b2) > max(a0,b0) <=> a2 > b0 && b2 > a0 when a2 > a0 and b2 > b0, which
+      // the pre-test boxes guarantee); a detection that no track of the wave touches -- nearly all of them -- costs
+      // nothing else.  Overlapping detections go through a 4-deep shift register per lane (all of them are kept when
+      // there are at most KC; their order is irrelevant to the arg-max).
+      auto overlaps = [&](const float4 f) -> bool {
+        return (int)(f.z > tf.x) & (int)(tf.z > f.x) & (int)(f.w > tf.y) & (int)(tf.w > f.y);
+      };
+      // first detection of the segment that the lane's track does NOT touch (usually the very first one)
+      int zero_j = -1;
+      for (int j = j_lo; j < j_hi; ++j) {
+        if (zero_j < 0 && !overlaps(fbox[j])) zero_j = j;
+        if (__ballot(zero_j < 0) == 0ull) break;
+      }
+      int cnt = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+      auto visit = [&](int j, const float4 f) {
+        const bool maybe = overlaps(f);
+        if (__ballot(maybe) != 0ull) {
+          c3 = maybe ? c2 : c3;
+          c2 = maybe ? c1 : c2;
+          c1 = maybe ? c0 : c1;
+          c0 = maybe ? j : c0;
+          cnt += maybe ? 1 : 0;
+        }
+      };
+      int j = j_lo;
+      for (; j + 4 <= j_hi; j += 4) {           // four broadcast reads in flight per round trip
+        const float4 f0 = fbox[j], f1 = fbox[j + 1], f2 = fbox[j + 2], f3 = fbox[j + 3];
+        visit(j, f0); visit(j + 1, f1); visit(j + 2, f2); visit(j + 3, f3);
+      }
+      for (; j < j_hi; ++j) visit(j, fbox[j]);
+      double bv = 0.0;
+      int bi = zero_j;                                        // better(0, zero_j, 0, -1); -1 when the segment had none
+      if (cnt > KC) {                                         // crowded (or an everything-box): the plain exact scan
+        bv = 0.0;
+        bi = -1;
+        for (int j = j_lo; j < j_hi; ++j) {
+          const double v = iou64(dbox + (size_t)j * 4, tb);
+          if (better(v, j, bv, bi)) { bv = v; bi = j; }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+          const int cj = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
+          if (k < cnt) {
+            const double v = iou64(dbox + (size_t)cj * 4, tb);
+            if (better(v, cj, bv, bi)) { bv = v; bi = cj; }
+          }
+        }
+      }
+      if (in) {
+        if (S == 1) {
+          best_v[t] = bv;
+          best_i[t] = bi;
+        } else {
+          s_pv[seg * (n_chunks * 64) + t] = bv;
+          s_pi[seg * (n_chunks * 64) + t] = bi;
+        }
+      }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-      double ov = __shfl_xor(bv, o, 64);
-      int oi = __shfl_xor(bi, o, 64);
-      if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-    }
-    if (lane == 0) {
-      best_v[t] = bv;
-      best_i[t] = bi;
-      tmaxs[t] = cur.max_score[t];
-      tlens[t] = cur.len[t];
-      tids[t] = cur.id[t];
+    if (S > 1) {
+      __syncthreads();
+      for (int t = tid; t < T; t += TRK_THREADS) {
+        double bv = s_pv[t];
+        int bi = s_pi[t];
+        for (int sg = 1; sg < S; ++sg) {
+          const double ov = s_pv[sg * (n_chunks * 64) + t];
+          const int oi = s_pi[sg * (n_chunks * 64) + t];
+          if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        best_v[t] = bv;
+        best_i[t] = bi;
+      }
     }
   }
   __syncthreads();
+  TT(1)
 
   if (wave == 0) {
     // ---- phase 2: greedy association in track order (:129-148), one wave -----------------------
+    // Surviving tracks and finished ids are STAGED IN LDS, in the prefix [0, t] of the per-track arrays that track t and
+    // its predecessors have already consumed (n_upd + n_fin <= t before track t writes), and stored to HBM by the whole
+    // workgroup after the loop -- no global store (and the vmcnt(0) drain the volatile LDS accesses force) per track.
+    int* fin_ids = (int*)best_v;
+    int* det_claim = const_cast<int*>(det_tid);
     int n_alive = n;
     int n_upd = 0, n_fin = 0;
-    for (int t = 0; t < T; ++t) {
-      if (n_alive == 0) break;               // :130 has no else: remaining tracks vanish
-      double bv = best_v[t];
-      int bi = best_i[t];
-      const double tmax = tmaxs[t];
-      const int tlen = tlens[t];
-      const int tidv = tids[t];
-      if (det_tid[bi] != -1) {               // taken by an earlier track: arg-max over the free rows
-        const double tb[4] = {cur.box[t * 4 + 0], cur.box[t * 4 + 1], cur.box[t * 4 + 2], cur.box[t * 4 + 3]};
-        bv = 0.0;
-        bi = -1;
-        for (int j = lane; j < n; j += 64) {
-          if (det_tid[j] != -1) continue;
-          double v = iou64(dbox + (size_t)j * 4, tb);
-          if (better(v, j, bv, bi)) { bv = v; bi = j; }
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-          double ov = __shfl_xor(bv, o, 64);
-          int oi = __shfl_xor(bi, o, 64);
-          if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-        }
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // 64 tracks at a time: every lane loads its track's phase-1 result with ONE LDS read per field.  If no track of the
+    // chunk wants a detection that is already gone or that an earlier lane also wants, and the detections cannot run
+    // out inside the chunk, the sequential loop of :129-148 has no cross-track dependence here and the chunk commits in
+    // parallel (slots by prefix sums == what the loop would have assigned).  Otherwise the chunk runs the loop as
+    // written, one track after the other, with the per-track values broadcast from the lanes that hold them.
+    for (int t0 = 0; t0 < T && n_alive > 0; t0 += 64) {
+      const int t = t0 + lane;
+      const bool in = t < T;
+      double bv = in ? best_v[t] : 0.0;
+      int bi = in ? best_i[t] : -1;
+      const double tmax = in ? tmaxs[t] : 0.0;
+      const int tlen = in ? tlens[t] : 0;
+      const int tidv = in ? tids[t] : 0;
+      const bool want = in && (bv > sigma_iou);             // :134 strict; NaN -> unmatched
+      bool claimed = false, clash = false;
+      if (want) {
+        const int old = atomicCAS(&det_claim[bi], -1, -2 - lane);
+        claimed = old == -1;
+        clash = !claimed;                                   // taken by an earlier chunk, or wanted twice in this one
       }
-      if (bv > sigma_iou) {                  // :134 strict; NaN -> unmatched
-        if (lane == 0) {
-          const double* d = dbox + (size_t)bi * 4;
+      const unsigned long long want_m = __ballot(want);
+      const int n_want = __popcll(want_m);
+      if (__ballot(clash) == 0ull && n_want < n_alive) {
+        const bool fin = in && !want && tmax > sigma_h && tlen > t_min;   // :146
+        const unsigned long long fin_m = __ballot(fin);
+        __builtin_amdgcn_wave_barrier();                    // every lane holds its inputs in registers from here on
+        if (want) {
+          const int slot = n_upd + __popcll(want_m & lt_mask);
           const double sc = dscore[bi];
-          nxt.box[n_upd * 4 + 0] = d[0];
-          nxt.box[n_upd * 4 + 1] = d[1];
-          nxt.box[n_upd * 4 + 2] = d[2];
-          nxt.box[n_upd * 4 + 3] = d[3];
-          nxt.max_score[n_upd] = (sc > tmax) ? sc : tmax;   // max(track, det)  :141
-          nxt.len[n_upd] = tlen + 1;
-          nxt.id[n_upd] = tidv;
-          det_tid[bi] = tidv;
+          best_i[slot] = bi;                                // the track's new last box = detection bi
+          tmaxs[slot] = (sc > tmax) ? sc : tmax;            // max(track, det)  :141
+          tlens[slot] = tlen + 1;
+          tids[slot] = tidv;
+          det_claim[bi] = tidv;
         }
-        ++n_upd;
-        --n_alive;
-        __builtin_amdgcn_wave_barrier();     // LDS ops of one wave complete in order; keep the compiler honest
-      } else if (tmax > sigma_h && tlen > t_min) {   // :146
-        if (lane == 0) fin_log[n_fin] = tidv;
-        ++n_fin;
+        if (fin) fin_ids[n_fin + __popcll(fin_m & lt_mask)] = tidv;
+        n_upd += n_want;
+        n_alive -= n_want;
+        n_fin += __popcll(fin_m);
+        __builtin_amdgcn_wave_barrier();
+        continue;
+      }
+      if (claimed) det_claim[bi] = -1;                      // undo the probes of this chunk
+      __builtin_amdgcn_wave_barrier();
+      const int cnt = (T - t0) < 64 ? (T - t0) : 64;
+      for (int l = 0; l < cnt; ++l) {
+        if (n_alive == 0) break;                            // :130 has no else: remaining tracks vanish
+        const int tt = t0 + l;
+        double sbv = __shfl(bv, l, 64);
+        int sbi = __shfl(bi, l, 64);
+        const double stmax = __shfl(tmax, l, 64);
+        const int stlen = __shfl(tlen, l, 64);
+        const int stid = __shfl(tidv, l, 64);
+        // A track whose best IoU over ALL detections is not above sigma_iou stays unmatched whatever has been deleted
+        // (removing rows cannot raise the maximum; a NaN row belongs to a zero-area detection, which no track can
+        // take), so only a real conflict -- the wanted detection went to an earlier track -- re-evaluates the row.
+        if (sbv > sigma_iou && det_tid[sbi] != -1) {
+          const double tb[4] = {cur.box[tt * 4 + 0], cur.box[tt * 4 + 1], cur.box[tt * 4 + 2], cur.box[tt * 4 + 3]};
+          sbv = 0.0;
+          sbi = -1;
+          for (int j = lane; j < n; j += 64) {
+            if (det_tid[j] != -1) continue;
+            double v = iou64(dbox + (size_t)j * 4, tb);
+            if (better(v, j, sbv, sbi)) { sbv = v; sbi = j; }
+          }
+          for (int o = 32; o > 0; o >>= 1) {
+            double ov = __shfl_xor(sbv, o, 64);
+            int oi = __shfl_xor(sbi, o, 64);
+            if (better(ov, oi, sbv, sbi)) { sbv = ov; sbi = oi; }
+          }
+        }
+        if (sbv > sigma_iou) {
+          if (lane == 0) {
+            const double sc = dscore[sbi];
+            best_i[n_upd] = sbi;
+            tmaxs[n_upd] = (sc > stmax) ? sc : stmax;
+            tlens[n_upd] = stlen + 1;
+            tids[n_upd] = stid;
+            det_tid[sbi] = stid;
+          }
+          ++n_upd;
+          --n_alive;
+          __builtin_amdgcn_wave_barrier();     // LDS ops of one wave complete in order; keep the compiler honest
+        } else if (stmax > sigma_h && stlen > t_min) {
+          if (lane == 0) fin_ids[n_fin] = stid;
+          ++n_fin;
+        }
       }
     }
 
+    TT(2)
     // ---- remaining detections start new tracks, in detection order (:150-155) -------------------
     const int next_id = s_next_id;
     int n_new = 0;
@@ -263,7 +428,10 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
       }
       n_new += __popcll(bal);
     }
+    TT(3)
     if (lane == 0) {
+      s_nupd = n_upd;
+      s_nfin = n_fin;
       hdr[0] = n;
       hdr[1] = n_fin;
       hdr[2] = frame;
@@ -278,6 +446,18 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
   }
   __syncthreads();
   for (int j = tid; j < n; j += TRK_THREADS) tid_log[j] = det_tid[j];
+  for (int u = tid; u < s_nupd; u += TRK_THREADS) {        // staged survivors -> the next active set
+    const double* d = dbox + (size_t)best_i[u] * 4;
+    nxt.box[u * 4 + 0] = d[0];
+    nxt.box[u * 4 + 1] = d[1];
+    nxt.box[u * 4 + 2] = d[2];
+    nxt.box[u * 4 + 3] = d[3];
+    nxt.max_score[u] = tmaxs[u];
+    nxt.len[u] = tlens[u];
+    nxt.id[u] = tids[u];
+  }
+  for (int k = tid; k < s_nfin; k += TRK_THREADS) fin_log[k] = ((const int*)best_v)[k];
+  TT(4)
   __syncthreads();   // det_tid / dbox are rewritten by the next frame; the new active set is visible to every wave
   }
   if (tid == 0) {
@@ -414,9 +594,11 @@ extern "C" fdt_tracker* fdt_tracker_create(double sigma_iou, double sigma_h, int
     set_error("fdt_tracker_create: max_dets and log_frames must be >= 1");
     return nullptr;
   }
-  if ((long long)max_dets * fdt::TRK_LDS_PER_SLOT > 160 * 1024 - 64) {
+  // 160 KB of LDS per CU minus the kernel's static arrays (the 12 KB of per-segment partial arg-max results + counters)
+  constexpr long long kDynLds = 160 * 1024 - (12 * 1024 + 256);
+  if ((long long)max_dets * fdt::TRK_LDS_PER_SLOT > kDynLds) {
     set_error("fdt_tracker_create: max_dets %d does not fit the LDS-resident frame state (limit %d)", max_dets,
-              (160 * 1024 - 64) / fdt::TRK_LDS_PER_SLOT);
+              (int)(kDynLds / fdt::TRK_LDS_PER_SLOT));
     return nullptr;
   }
   fdt_tracker* t = new fdt_tracker();
@@ -557,3 +739,12 @@ extern "C" int fdt_tracker_track_boxes(fdt_tracker* t, int idx, double* boxes) {
   memcpy(boxes, tr.boxes.data(), tr.boxes.size() * 8);
   return FDT_OK;
 }
+
+#ifdef FDT_TRK_TIMING
+extern "C" int fdt_debug_trk_times(long long* out) {
+  FDT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(fdt::g_trk_time), 64));
+  long long z[8] = {0};
+  FDT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(fdt::g_trk_time), z, 64));
+  return FDT_OK;
+}
+#endif

@@ -11,13 +11,14 @@ OUT=gpurun_out/profiles_$R
 mkdir -p $OUT /tmp/raw
 export TMPDIR=/tmp
 PLAN=face-detection-and-tracking_amd/tuned/res50_1024x1024_b1.plan
-# the (kernel class, tile) pairs the single-kernel PMC passes below measure must still be what the committed plan runs:
-#   kind tile  layer the shape is taken from
-check_plan() { grep -q "^$1 $2 $3 " $PLAN || { echo "refresh_profiles: $PLAN no longer runs '$1' as kind $2 tile $3 -- update the PMC list" >&2; exit 1; }; }
-check_plan conv2_SSH.conv1 8 30
-check_plan layer3.1.conv1 10 3
-check_plan layer1.0.conv3 0 12
-check_plan layer2.1.conv3 0 6
+# the single-kernel PMC passes below measure the (kernel class, tile, split-K) the COMMITTED plan runs for these layers
+# (read from the plan, so a re-tune cannot leave the PMC files describing a kernel that is no longer used)
+plan_of() { awk -v L="$1" '$1==L {print $2, $3, $4; f=1} END {if(!f) exit 1}' $PLAN || { echo "refresh_profiles: layer $1 not in $PLAN" >&2; exit 1; }; }
+K_WINO=$(plan_of conv2_SSH.conv1)
+K_A=$(plan_of layer3.1.conv1)
+K_B=$(plan_of layer1.0.conv3)
+K_C=$(plan_of layer2.1.conv3)
+case "$K_WINO" in "8 29 "*|"8 30 "*) ;; *) echo "refresh_profiles: conv2_SSH.conv1 is no longer a quarter-split Winograd kernel ($K_WINO)" >&2; exit 1;; esac
 B="python bench.py --steps 48 --warmup 8 --cpu-frames 0"
 timeout -k 10 400 python bench.py --steps 64 --warmup 8 --host-frames 64 > $OUT/bench_line_res50_1024.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt --output-format csv -- $B > $OUT/bench_under_rocprof.log 2>&1
@@ -41,10 +42,11 @@ pmc_one() {
     -d /tmp/raw -o mfma_$1 --output-format csv -- python tools/one_conv.py $2 $3 $4 $5 $6 $7 $8 $9 8 > $OUT/pmc_mfma_$1_times.txt 2>&1
   python tools/summarize_pmc.py /tmp/raw/mfma_$1_counter_collection.csv $OUT/pmc_mfma_$1.csv
 }
-pmc_one wino4_256to256_256x256   8 30 1 256 256 256 256 0
-pmc_one 1x1k32_1024to256_64x64   10 3 1 1024 64 64 256 0
-pmc_one 1x1_64to256_256x256_res  0 12 1 64 256 256 256 1
-pmc_one 1x1_128to512_128x128_res 0 6 1 128 128 128 512 1
+pmc_one wino4_256to256_256x256   $K_WINO 256 256 256 256 0    # conv2_SSH.conv1 / smooth_c3
+pmc_one 1x1_1024to256_64x64      $K_A 1024 64 64 256 0        # layer3.x.conv1
+pmc_one 1x1_64to256_256x256_res  $K_B 64 256 256 256 1        # layer1.x.conv3 (+ residual)
+pmc_one 1x1_128to512_128x128_res $K_C 128 128 128 512 1       # layer2.x.conv3 (+ residual)
+echo "conv2_SSH.conv1 $K_WINO | layer3.1.conv1 $K_A | layer1.0.conv3 $K_B | layer2.1.conv3 $K_C" > $OUT/pmc_mfma_kernels.txt
 timeout -k 10 300 python tools/profile_layers.py > $OUT/per_layer_hip_events_res50_1024.txt
 timeout -k 10 300 python bench.py --steps 64 --warmup 8 --height 480 --width 640 --cpu-frames 2 > $OUT/bench_line_res50_640x480.json
 timeout -k 10 300 python bench.py --steps 128 --warmup 16 --source 1080x1920 --height 480 --width 640 --cpu-frames 3 --host-frames 128 > $OUT/bench_line_res50_640x480_from_1080p.json
