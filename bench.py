@@ -336,7 +336,22 @@ def main():
     # the one exchange of the path: RCCL all-gather behind the C ABI (fdt_allgather_dets); torch.distributed only ships
     # the 128-byte communicator id and does the barrier / max-over-ranks of the timing
     exch_kind = os.environ.get("FDT_BENCH_EXCHANGE", "rccl-cabi" if backend == "nccl" else "torch")
-    comm = par.make_rccl_comm(rank, world, local_rank) if (world > 1 and exch_kind == "rccl-cabi") else None
+    comm, exch_note = None, None
+    if world > 1 and exch_kind == "rccl-cabi":
+        try:
+            comm = par.make_rccl_comm(rank, world, local_rank)
+        except Exception as e:                       # noqa: BLE001 -- reported in the JSON line, never silent
+            exch_note = "fdt_comm_init_rank failed on rank %d: %s" % (rank, e)
+            print("bench.py: " + exch_note, file=sys.stderr)
+        # every rank must use the same transport for the collective: agree on it
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                lib.lib().fdt_comm_destroy(comm)
+                comm = None
+            exch_note = exch_note or "fdt_comm_init_rank failed on another rank"
+            exch_kind = "torch (C-ABI RCCL communicator could not be built on every rank)"
 
     def make_exchange(rec):
         if comm is not None:
@@ -610,6 +625,7 @@ def main():
                        "parallelism": "frame-parallel x%d%s" % (
                            world, (", all-gather of box lists: " + ("RCCL via fdt_allgather_dets (C ABI)" if comm is not None
                                                                     else "torch.distributed " + backend)) if world > 1 else ""),
+                       "exchange_note": exch_note,
                        "weights": "seeded synthetic (seed 0)", "detections_last_frame": n_cand_last,
                        "tracks": len(tracks), "gpu_ms_per_step_events": round(gpu_ms / args.steps, 4),
                        "device": pkg.device_name(local_rank)},
