@@ -119,6 +119,15 @@ def lib():
             raise FdtError(FDT_ERR_STATE,
                            "%s not found -- build it first (make -C %s); there is no CPU fallback"
                            % (LIB_PATH, os.path.dirname(LIB_PATH)))
+        # Load order: the PyTorch-ROCm wheel ships its own libamdhip64 / librccl and refers to them by un-versioned
+        # names, while this library links the versioned sonames of /opt/rocm.  If this library came first, a later
+        # `import torch` would bring a SECOND HIP runtime into the process (its torch.cuda then finds no GPU and stream /
+        # device pointers could not be shared); with torch first, the loader satisfies our sonames from the copies torch
+        # loaded.  Every host module of this package that hands out tensors imports torch anyway.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)        # AttributeError if a declared symbol is not exported
