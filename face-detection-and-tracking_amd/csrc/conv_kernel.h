@@ -2,6 +2,8 @@
 // Included by conv.hip (table, launch) and by one conv_inst_*.hip per convolution class so that the
 // ~70 instantiations compile in parallel.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 #include "conv.h"
 
@@ -68,6 +70,22 @@ __device__ __forceinline__ void glds4(const float* g, float* l) {
 }
 __device__ __forceinline__ void glds16(const float* g, float* l) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+// Compile-time loop: f(std::integral_constant<int, I>{}) for I = I0 .. N-1 (the step index feeds "n" asm constraints).
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// One LDS dword per lane, issued by hand (see the main loop): byte offset OFF from the lane's byte address.
+template <int OFF>
+__device__ __forceinline__ void lds_read_b32(float& v, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
 }
 
 template <class G, class T>
@@ -182,6 +200,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
   // it overwrites; stage `it` is waited for with a COUNTED vmcnt (the newer stages stay in flight) and a
   // raw s_barrier -- __syncthreads() would drain vmcnt(0) and serialise the ring.
   const int nst = s_end - s_begin;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
 #pragma unroll
   for (int p = 0; p < T::NBUF - 1; ++p)
     if (p < nst) FDT_STAGE(s_begin + p, p);
@@ -205,24 +224,62 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (it + T::NBUF - 1 < nst) FDT_STAGE(s_begin + it + T::NBUF - 1, nxt);
-    const float* S = smem + cur * L::STAGE;
+    // Operands of step s + 1 are requested before the MFMAs of step s are issued (two register sets), and every set is
+    // waited for with an EXACT lgkmcnt: the reads are issued through inline asm because the compiler's waitcnt model books
+    // each outstanding LDS-DMA load as a FLAT access and would turn its own LDS waits into lgkmcnt(0) right after the
+    // reads -- which left the matrix pipe idle for one LDS round trip per step (most of the time of the short-K 1x1
+    // layers).  Same step order as the plain loop (taps outer, channel pairs inner), so sums are bit-identical.
+    // tools/check_async_lds.py lints the generated ISA for any use of a register of a still-outstanding read.
+    {
+      constexpr int NSTEP = G::TAPS * (G::KC / 2);
+      constexpr int NLD = T::NI + T::MI;
+      const unsigned sb = lds0 + (unsigned)(cur * L::STAGE) * 4u;
+      unsigned wa[T::NI], xa[T::MI];
 #pragma unroll
-    for (int t = 0; t < G::TAPS; ++t) {
+      for (int j = 0; j < T::NI; ++j) wa[j] = sb + (unsigned)wo[j] * 4u;
 #pragma unroll
-      for (int cp = 0; cp < G::KC / 2; ++cp) {
-        const int kx = (2 * cp) * L::XPLANE + (t / G::KW) * G::D * L::PW + (t % G::KW) * G::D;
-        const int kw = ((2 * cp) * G::TAPS + t) * T::BN;
-        float av[T::NI], bv[T::MI];
+      for (int i = 0; i < T::MI; ++i) xa[i] = sb + (unsigned)xo[i] * 4u;
+      struct Ops {
+        float r[NLD];       // [0, NI): weights, [NI, NLD): pixels
+      };
+      auto load = [&](Ops& o, auto sc) {
+        constexpr int s_ = decltype(sc)::value;
+        constexpr int t_ = s_ / (G::KC / 2), cp_ = s_ % (G::KC / 2);
+        constexpr int kx_ = (2 * cp_) * L::XPLANE + (t_ / G::KW) * G::D * L::PW + (t_ % G::KW) * G::D;
+        constexpr int kw_ = ((2 * cp_) * G::TAPS + t_) * T::BN;
 #pragma unroll
-        for (int j = 0; j < T::NI; ++j) av[j] = S[wo[j] + kw];
+        for (int j = 0; j < T::NI; ++j) lds_read_b32<kw_ * 4>(o.r[j], wa[j]);
 #pragma unroll
-        for (int i = 0; i < T::MI; ++i) bv[i] = S[xo[i] + kx];
+        for (int i = 0; i < T::MI; ++i) lds_read_b32<kx_ * 4>(o.r[T::NI + i], xa[i]);
+      };
+      auto wait_for = [&](Ops& o, auto newer_c) {
+        constexpr int N_ = decltype(newer_c)::value;
+        if constexpr (NLD == 2)
+          asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(o.r[0]), "+v"(o.r[1]) : "n"(N_));
+        else if constexpr (NLD == 3)
+          asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(o.r[0]), "+v"(o.r[1]), "+v"(o.r[2]) : "n"(N_));
+        else
+          asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(o.r[0]), "+v"(o.r[1]), "+v"(o.r[2]), "+v"(o.r[3]) : "n"(N_));
+      };
+      static_assert(NLD >= 2 && NLD <= 4, "operand sets of 2..4 registers");
+      Ops A, B;
+      load(A, std::integral_constant<int, 0>{});
+      static_for<0, NSTEP>([&](auto sc) {
+        constexpr int s_ = decltype(sc)::value;
+        Ops& o = (s_ & 1) ? B : A;
+        Ops& n = (s_ & 1) ? A : B;
+        if constexpr (s_ + 1 < NSTEP) {
+          load(n, std::integral_constant<int, s_ + 1>{});
+          wait_for(o, std::integral_constant<int, NLD>{});
+        } else {
+          wait_for(o, std::integral_constant<int, 0>{});
+        }
 #pragma unroll
         for (int j = 0; j < T::NI; ++j)
 #pragma unroll
           for (int i = 0; i < T::MI; ++i)
-            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[i], acc[j][i], 0, 0, 0);
-      }
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.r[j], o.r[T::NI + i], acc[j][i], 0, 0, 0);
+      });
     }
     cur = (cur + 1 == T::NBUF) ? 0 : cur + 1;
     nxt = (nxt + 1 == T::NBUF) ? 0 : nxt + 1;

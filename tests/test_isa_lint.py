@@ -1,4 +1,5 @@
-"""ISA lint of the hand-issued LDS reads in the 8-wave Winograd kernel (csrc/conv_wino.h).
+"""ISA lint of the hand-issued LDS reads in the 8-wave Winograd kernels (csrc/conv_wino.h) and the direct kernel
+(csrc/conv_kernel.h).
 
 The main loop issues its ds_reads through inline asm and waits with exact `s_waitcnt lgkmcnt(N)` counts, which the
 compiler cannot see: a register copy or spill scheduled between a read and its wait would silently use stale
@@ -22,6 +23,11 @@ template __global__ void conv_wino2_kernel<W_128x32R3>(const ConvArgs);     // 3
 template __global__ void conv_wino2_kernel<WD2_64x64W>(const ConvArgs);     // dilation 2
 template __global__ void conv_wino4_kernel<W_64x64W>(const ConvArgs);       // quarter-split form
 template __global__ void conv_wino4_kernel<WD2_64x64R3>(const ConvArgs);
+// the direct kernel's pipelined main loop (conv_kernel.h): 1 + 1, 2 + 1 and 2 + 2 operand registers per step
+template __global__ void conv_kernel<G_1x1_S1_K32, T_64x64>(const ConvArgs);
+template __global__ void conv_kernel<G_1x1_S1, T_128x64W>(const ConvArgs);
+template __global__ void conv_kernel<G_3x3_S2, T_128x128>(const ConvArgs);
+template __global__ void conv_kernel<G_7x7_S2, T_128x64>(const ConvArgs);
 } }
 """
 
@@ -38,6 +44,7 @@ def test_async_lds_reads_have_no_hazards(tmp_path):
     assert "s_waitcnt lgkmcnt(7)" in text and "s_waitcnt lgkmcnt(10)" in text
     assert "s_waitcnt lgkmcnt(6)" in text and "s_waitcnt lgkmcnt(8)" in text      # quarter-split: 2 / 4 window reads + 4
     assert text.count("ds_read2_b64") > 0 and text.count("ds_read2st64_b32") > 0
+    assert "s_waitcnt lgkmcnt(2)" in text and "s_waitcnt lgkmcnt(3)" in text and "s_waitcnt lgkmcnt(4)" in text   # direct kernel
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_async_lds.py"), str(asm)],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
