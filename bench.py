@@ -223,6 +223,22 @@ def cpu_info():
     return model, (len(phys) or logical or 1), (logical or 1)
 
 
+class stdout_to_stderr:
+    """RCCL / gloo print banners from C code straight to fd 1 while a communicator comes up; the contract is ONE JSON line on
+    stdout, so fd 1 points at stderr for the duration of the block."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside a launcher: start the N ranks as children (before anything touches the GPU),
     relay rank 0's JSON line and exit with the launcher's code."""
@@ -289,10 +305,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        with stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.barrier()
 
     pkg = importlib.import_module("face-detection-and-tracking_amd")
     synth = importlib.import_module("face-detection-and-tracking_amd.synth")
@@ -339,7 +357,8 @@ def main():
     comm, exch_note = None, None
     if world > 1 and exch_kind == "rccl-cabi":
         try:
-            comm = par.make_rccl_comm(rank, world, local_rank)
+            with stdout_to_stderr():
+                comm = par.make_rccl_comm(rank, world, local_rank)
         except Exception as e:                       # noqa: BLE001 -- reported in the JSON line, never silent
             exch_note = "fdt_comm_init_rank failed on rank %d: %s" % (rank, e)
             print("bench.py: " + exch_note, file=sys.stderr)

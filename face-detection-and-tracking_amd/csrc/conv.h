@@ -167,5 +167,6 @@ double conv_flops(const ConvArgs& a, ConvKind kind);
 // dynamic-LDS attribute once.
 int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a, hipStream_t st, int device = -1);
 bool conv_supported(ConvKind kind, ConvTile tile);
+size_t conv_lds_bytes(ConvKind kind, ConvTile tile);   // dynamic LDS of the instantiation
 
 }  // namespace fdt

@@ -155,6 +155,7 @@ int tile_th(ConvTile t) { return kTileDims[t][2]; }
 int tile_tw(ConvTile t) { return kTileDims[t][3]; }
 
 bool conv_supported(ConvKind kind, ConvTile tile) { return table().e[kind][tile].fn != nullptr; }
+size_t conv_lds_bytes(ConvKind kind, ConvTile tile) { return table().e[kind][tile].lds; }
 
 void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKind kind, ConvTile tile,
                   std::vector<float>& out) {

@@ -1758,6 +1758,9 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   FDT_HIP(hipEventCreate(&e0));
   FDT_HIP(hipEventCreate(&e1));
   const long long kMaxWsFloats = 256ll * 1024 * 1024;   // 1 GiB of partial sums at most per candidate
+  // Experiment hook: only direct-kernel variants whose LDS footprint fits BESIDE a resident Winograd workgroup (132 KB of
+  // the CU's 160 KB), so that the small layers of one frame can share CUs with the big layers of another
+  const long long small_lds = getenv("FDT_TUNE_MAX_LDS") ? atoll(getenv("FDT_TUNE_MAX_LDS")) : 0;
   int rc = FDT_OK;
   for (auto& op : m->ops) {
     if (op.type != OP_CONV) continue;
@@ -1770,6 +1773,8 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
       const int nstages = ceil_div(op.ca.Cin, conv_geom((ConvKind)k).kc);
       for (int t = 0; t < CONV_TILE_COUNT; ++t) {
         if (!conv_supported((ConvKind)k, (ConvTile)t)) continue;
+        if (small_lds > 0 && !conv_geom((ConvKind)k).wino && (long long)conv_lds_bytes((ConvKind)k, (ConvTile)t) > small_lds)
+          continue;
         for (int split = 1; split <= 64; split *= 2) {
           if (split > 1 && (split > nstages / 2 || nstages < 8)) break;
           ConvArgs a = op.ca;
@@ -1781,6 +1786,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
         }
       }
     }
+    if (cands.empty()) continue;   // nothing to choose from (every variant filtered out): the layer keeps its kernel
     float* tmp_ws = nullptr;
     if (ws_need && hipMalloc((void**)&tmp_ws, (size_t)ws_need * 4) != hipSuccess) {
       set_error("fdt_model_autotune: workspace allocation failed");
