@@ -58,25 +58,36 @@ def facebox_main(args):
     frames_h = np.stack([uniq[i % 6] for i in range(B)])
     dev = torch.device("cuda", 0)
     frames_d = torch.from_numpy(frames_h).to(dev)
-    counts = torch.zeros(B, dtype=torch.int32, device=dev)
-    st = torch.cuda.Stream()
-    torch.cuda.set_stream(st)
-    sp = ctypes.c_void_p(st.cuda_stream)
     L = lib.lib()
     res = net.detect_frames(frames_h)          # plan (+ the GPU results of these frames for the parity leg)
     net.autotune(3)
+    # `inflight` batches in flight, each on its own handle (fdt_model_clone: shared weights) and stream: the net is a
+    # chain of ~40 short launches, so consecutive batches overlap almost completely
+    NF = args.inflight if args.inflight > 0 else 4
+    plan_text = net.export_plan()
+    nets = [net] + [net.clone() for _ in range(NF - 1)]
+    for n_ in nets[1:]:
+        n_.import_plan(plan_text)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NF)]
+    sps = [ctypes.c_void_p(s_.cuda_stream) for s_ in streams]
+    counts_k = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NF)]
+    counts = counts_k[0]
+    torch.cuda.set_stream(streams[0])
+    sp = sps[0]
 
-    def step():
-        lib.check(L.fdt_model_detect_facebox_resized(net._h, ctypes.c_void_p(frames_d.data_ptr()), 1, B, SH, SW, 0.35, 0.5,
-                                                     None, None, ctypes.c_void_p(counts.data_ptr()), sp))
-    for _ in range(max(args.warmup, 2)):
-        step()
+    def step(i=0):
+        k = i % NF
+        lib.check(L.fdt_model_detect_facebox_resized(nets[k]._h, ctypes.c_void_p(frames_d.data_ptr()), 1, B, SH, SW, 0.35,
+                                                     0.5, None, None, ctypes.c_void_p(counts_k[k].data_ptr()), sps[k]))
+    for i in range(max(args.warmup, 2 * NF)):
+        step(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    assert all(torch.equal(c, counts_k[0]) for c in counts_k), "in-flight slots disagree"
     res = net.detect_frames(frames_h)          # same kernels, host round trip: what the parity leg compares
     faces = [int(c) for c in counts.cpu()]
     assert faces == [len(p) for _, p in res], (faces, [len(p) for _, p in res])
@@ -175,7 +186,7 @@ def facebox_main(args):
                       "config": {"workload": "FaceBoxes, %dx%d u8 sources resized on the GPU to 1024x1024, batch=%d, "
                                              "decode_np+nms_np on device" % (SW, SH, B),
                                  "weights": "reference FACEBOX/faceboxes.pt", "faces_per_image": faces[:6],
-                                 "hip_graph": bool(args.graph), "device": pkg.device_name(0)},
+                                 "batches_in_flight": NF, "hip_graph": bool(args.graph), "device": pkg.device_name(0)},
                       "roofline": roof, "cpu_baseline": cpu, "parity": parity}))
 
 
@@ -275,9 +286,9 @@ def main():
                     help="1: use the committed tuned plan for this shape if there is one, else autotune (tile, split-K) "
                          "per conv layer at start-up; 2: always autotune; 0: analytic model only")
     ap.add_argument("--save-plan", type=int, default=0, help="write the autotuned plan under tuned/")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per GPU: consecutive batch-1 steps overlap on separate HIP streams "
-                         "(detection of frame i+1 runs beside the tail / tracker step of frame i)")
+                         "(detection of frame i+1 runs beside the tail / tracker step of frame i); default 3, FaceBoxes 4")
     ap.add_argument("--graph", type=int, default=1, help="replay each forward as a captured HIP graph (0: eager launches)")
     ap.add_argument("--host-frames", type=int, default=0,
                     help="also report the PCIe-inclusive rate: N frames handed over as pageable host buffers through the "
@@ -322,7 +333,7 @@ def main():
     H = args.height or args.size
     W = args.width or args.size
     sd = synth.make_state_dict(args.arch, seed=0)
-    NF = max(1, args.inflight)
+    NF = args.inflight if args.inflight > 0 else 3
     B = max(1, args.batch)
     if args.arch == "res50":
         net = importlib.import_module("face-detection-and-tracking_amd.pyramid").SFD(device=local_rank)

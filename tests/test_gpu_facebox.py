@@ -179,3 +179,38 @@ def test_traffic_and_ingest_profile(net):
     net.profile(False)
     assert [p[0] for p in prof[-2:]] == ["detect", "ingest"] and len(prof) == len(per)
     assert all(ms >= 0 for _, ms, _ in prof) and prof[-1][1] > 0
+
+
+def test_three_batches_in_flight_on_cloned_handles(net):
+    """What bench.py --arch facebox times: several batches in flight, each on its own fdt_model_clone() handle and stream,
+    4K sources resized on the GPU -- every slot returns the faces of the single-handle synchronous path, bit for bit."""
+    import ctypes
+    L = M("_lib")
+    lib = L.lib()
+    d, meta = load_npz("facebox_r2")
+    SH, SW, B = 540, 960, 4
+    yi = (np.arange(SH) * 1024) // SH
+    xi = (np.arange(SW) * 1024) // SW
+    frames = np.stack([np.ascontiguousarray(d["img%d_frame" % (b % 6)][yi][:, xi]) for b in range(B)])
+    want = net.detect_frames(frames)
+    dev = torch.device("cuda", 0)
+    fd = torch.from_numpy(frames).to(dev)
+    clones = [net.clone(), net.clone()]
+    nets = [net] + clones
+    streams = [torch.cuda.Stream(device=dev) for _ in nets]
+    counts = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in nets]
+    for rep in range(3):
+        for k, n in enumerate(nets):
+            L.check(lib.fdt_model_detect_facebox_resized(n._h, ctypes.c_void_p(fd.data_ptr()), 1, B, SH, SW, 0.35, 0.5, None,
+                                                         None, ctypes.c_void_p(counts[k].data_ptr()),
+                                                         ctypes.c_void_p(streams[k].cuda_stream)))
+    torch.cuda.synchronize()
+    for k, n in enumerate(nets):
+        c = counts[k].cpu().numpy()
+        assert c.tolist() == [len(p) for _, p in want]
+        probs = n.get_tensor("fb_probs").reshape(B, -1)
+        boxes = n.get_tensor("fb_boxes").reshape(B, -1, 4)
+        for b in range(B):
+            assert np.array_equal(probs[b, :c[b]], want[b][1]) and np.array_equal(boxes[b, :c[b]], want[b][0])
+    for c_ in clones:
+        c_.close()
