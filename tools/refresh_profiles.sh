@@ -53,7 +53,9 @@ timeout -k 10 300 python bench.py --steps 128 --warmup 16 --source 1080x1920 --h
 timeout -k 10 300 python bench.py --steps 32 --warmup 4 --height 1080 --width 1920 --cpu-frames 1 > $OUT/bench_line_res50_1920x1080.json
 timeout -k 10 300 python bench.py --steps 64 --warmup 8 --arch try3 --cpu-frames 3 > $OUT/bench_line_try3_1024.json
 timeout -k 10 300 python bench.py --steps 32 --warmup 4 --arch try3 --batch 8 --cpu-frames 3 > $OUT/bench_line_try3_1024_b8.json
-timeout -k 10 300 python bench.py --arch facebox --batch 16 --steps 50 --warmup 5 > $OUT/bench_line_facebox_4k_b16.json
+timeout -k 10 300 python bench.py --arch facebox --batch 16 --steps 100 --warmup 8 > $OUT/bench_line_facebox_4k_b16.json
+timeout -k 10 400 python bench.py --steps 32 --warmup 6 --batch 2 --cpu-frames 0 --autotune 2 --save-plan 1 > $OUT/bench_line_res50_1024_b2.json && cp face-detection-and-tracking_amd/tuned/res50_1024x1024_b2.plan $OUT/
+timeout -k 10 300 python bench.py --steps 48 --warmup 8 --height 480 --width 640 --batch 4 --cpu-frames 2 > $OUT/bench_line_res50_640x480_b4.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o ktfb --output-format csv -- python bench.py --arch facebox --batch 16 --steps 50 --warmup 5 --cpu-frames 0 > $OUT/bench_facebox_under_rocprof.log 2>&1
 cp /tmp/raw/ktfb_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_facebox_4k_b16.csv
 tail -c 600 $OUT/bench_line_res50_1024.json
