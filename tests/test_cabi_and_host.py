@@ -120,3 +120,32 @@ def test_synthetic_schema_counts(synth):
     a = synth.make_state_dict("try3", 3)["features.5.conv.3.weight"]
     b = synth.make_state_dict("try3", 3)["features.5.conv.3.weight"]
     assert np.array_equal(a, b) and a.shape == (192, 1, 3, 3)
+
+
+def test_round2_entry_points_validate_arguments_without_a_gpu():
+    lib = M("_lib")
+    L = lib.lib()
+    assert not L.fdt_model_clone(None)
+    assert b"fdt_model_clone" in L.fdt_last_error()
+    assert L.fdt_model_enable_graph(None, 1) == lib.FDT_ERR_ARG
+    assert L.fdt_tracker_step_dev_multi(None, None, 8, 7500, 2, 750, 640, 480, 0.4, None) == lib.FDT_ERR_ARG
+    t = ctypes.c_int(-1)
+    assert L.fdt_model_forward_async(None, None, 0, 1, 8, 8, 0, 0, ctypes.byref(t)) == lib.FDT_ERR_ARG
+    assert L.fdt_model_wait(None, 0, None, None, None) == lib.FDT_ERR_ARG
+    assert L.fdt_model_async_record(None, 0, None, None) == lib.FDT_ERR_ARG
+    assert L.fdt_comm_unique_id(None) == lib.FDT_ERR_ARG
+    assert not L.fdt_comm_init_rank(0, 0, None, 0) and b"fdt_comm_init_rank" in L.fdt_last_error()
+    assert not L.fdt_comm_init_all(0, None)
+    assert L.fdt_allgather_dets(None, 0, None, None, 1, None) == lib.FDT_ERR_ARG
+    assert L.fdt_comm_world(None, None, None) == lib.FDT_ERR_ARG
+    assert L.fdt_model_detect_facebox_resized(None, None, 0, 1, 2160, 3840, 0.35, 0.5, None, None, None, None) == lib.FDT_ERR_ARG
+    assert L.fdt_model_traffic(None, None, None, 0, None, None) == lib.FDT_ERR_ARG
+    L.fdt_comm_destroy(None)          # no-ops on NULL like free()
+    L.fdt_model_destroy(None)
+
+
+def test_header_documents_the_round2_surface():
+    src = open(HEADER).read()
+    for word in ("FDT_COMM_ID_BYTES 128", "fdt_tracker_step_dev_multi", "fdt_model_clone", "fdt_model_forward_async",
+                 "MyTrain_repo.py:71", "iouTracke_cal.py:119-124", "FACEBOX/My_test_facebox.py:12-36"):
+        assert word in src, word
