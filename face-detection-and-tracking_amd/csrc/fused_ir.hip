@@ -1,0 +1,273 @@
+// Fused head of a MobileNetV2 InvertedResidual block: 1x1 expand + BN + ReLU6 followed by the depthwise 3x3 (stride 1 | 2,
+// pad 1) + BN + ReLU6 (reference pyramid_mb2_try3.py:96-114: conv[0..5] of `self.conv`), in ONE kernel.
+//
+// Why: at 512^2 / 256^2 the expanded tensor is the whole cost of the block -- features.2 of try3 at batch 8 writes and
+// re-reads 805 MB of it for 134 MB of input and 201 MB of output (both launches run at 3.6-4.7 TB/s, i.e. at the HBM
+// roof).  Here the expanded activations never leave the CU:
+//   * a workgroup owns a TH x 32 output tile of one image; the (TH-1)*S+3 rows x 31*S+3 columns of the Cin-channel input
+//     under it are staged once in LDS;
+//   * per chunk of 32 hidden channels the expand is a [32 x Cin] x [Cin x positions] GEMM on v_mfma_f32_32x32x2_f32
+//     (the chunk's weights transposed into LDS as the A operand, input positions as the B operand straight from the patch;
+//     ascending-k fmaf chain, + bias, ReLU6 == the stand-alone conv kernel's arithmetic), written to a second LDS tile --
+//     ZERO where the position lies outside the image, because the depthwise conv pads the EXPANDED map;
+//   * the depthwise 3x3 reads that tile (taps in the stand-alone kernel's order, + bias, ReLU6) and stores 16-byte
+//     strips of the output.
+// 50-80 KB of LDS per workgroup -> two or three workgroups per CU, so one's GEMM phase overlaps the other's stencil
+// phase.  The 1x1 project conv that follows stays a separate launch (its input is 6x smaller than the expanded map).
+#include "common.h"
+#include "ops.h"
+
+namespace fdt {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ float g_ir_zero[4];   // source of every out-of-image / padding element of the staged patch (zero-initialised)
+
+template <int S>
+struct IrTile {
+  static constexpr int TH = (S == 1) ? 4 : 2;              // output rows per workgroup
+  static constexpr int TW = 32;                            // output columns
+  static constexpr int PH = (TH - 1) * S + 3;              // input rows under the tile
+  static constexpr int PWR = (TW - 1) * S + 3;             // input columns under the tile
+  static constexpr int PWP = (PWR + 3) / 4 * 4;            // row pitch in LDS
+  static constexpr int NPOS = PH * PWP;
+  static constexpr int NPOSP = (NPOS + 31) / 32 * 32;      // whole MFMA column tiles
+  static constexpr int NT = NPOSP / 32;
+};
+
+// grid: (tiles_x * tiles_y, 1, B); 256 threads; dynamic LDS: (Cin + 32) * NPOSP + 32 * Cin floats
+template <int S>
+__global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict__ x, int Cin, int H, int W,
+                                                        const float* __restrict__ w1, const float* __restrict__ b1,
+                                                        const float* __restrict__ wdw, const float* __restrict__ bdw,
+                                                        int hid, float* __restrict__ out, int Ho, int Wo) {
+  using T = IrTile<S>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                                   // [Cin][NPOSP]
+  float* hs = smem + (size_t)Cin * T::NPOSP;          // [32][NPOSP]
+  float* ws = hs + 32 * T::NPOSP;                     // [Cin][32]: this chunk's expand weights, k-major (A operand)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tiles_x = (Wo + T::TW - 1) / T::TW;
+  const int oy0 = (blockIdx.x / tiles_x) * T::TH, ox0 = (blockIdx.x % tiles_x) * T::TW;
+  const int b = blockIdx.z;
+  const int gy0 = oy0 * S - 1, gx0 = ox0 * S - 1;
+  const float* xb = x + (long long)b * Cin * H * W;
+
+  // ---- stage the input patch by LDS-DMA (nothing passes through VGPRs, all loads in flight together); out-of-image and
+  // pitch-padding elements read a zero word.  Element e = 256 * k + tid lands at float e: wave-uniform base + lane * 4.
+  {
+    const float* zpad = g_ir_zero;
+    const int total = Cin * T::NPOSP;
+    for (int e0 = 0; e0 < total; e0 += 256) {
+      const int e = e0 + tid;
+      const int c = e / T::NPOSP, p = e - c * T::NPOSP;
+      const int py = p / T::PWP, px = p - py * T::PWP;
+      const int gy = gy0 + py, gx = gx0 + px;
+      const bool ok = e < total && p < T::NPOS && px < T::PWR && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const float* src = ok ? xb + ((long long)c * H + gy) * W + gx : zpad;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + e0 + wave * 64), 4, 0, 0);
+    }
+  }
+  const int nchunks = (hid + 31) / 32;
+  const int ksteps = Cin >> 1;
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    // ---- this chunk's 32 x Cin expand weights -> LDS, transposed so that a wave reads one k-row per operand
+    for (int e = tid; e < 32 * Cin; e += 256) {
+      const int k = e >> 5, rr = e & 31;
+      const int hc = ch * 32 + rr;
+      ws[e] = hc < hid ? w1[(long long)hc * Cin + k] : 0.0f;
+    }
+    // this chunk's expand biases (the 16 accumulator rows of the lane) and the thread's depthwise taps: requested now,
+    // consumed after the barrier / the GEMM phase
+    float br[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int hc = ch * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      br[r] = hc < hid ? b1[hc] : 0.0f;
+    }
+    const int cl = tid >> 3, cg = tid & 7;            // depthwise phase: 32 channels x 8 column groups
+    const int hcd = ch * 32 + cl;
+    const int hcc = hcd < hid ? hcd : hid - 1;
+    float k9[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k9[i] = wdw[(long long)hcc * 9 + i];
+    const float bb = bdw[hcc];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the patch (first chunk) has landed
+    __syncthreads();
+    // ---- expand: hs[32][positions] = ReLU6(W1[chunk] . xs + b1), column tiles dealt round-robin to the four waves
+    for (int j = wave; j < T::NT; j += 4) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      const float* bcol = xs + j * 32 + l31 + (size_t)half * T::NPOSP;
+      const float* acol = ws + half * 32 + l31;
+      for (int s = 0; s < ksteps; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(acol[s * 64], bcol[(size_t)s * 2 * T::NPOSP], acc, 0, 0, 0);
+      const int p = j * 32 + l31;
+      const int py = p / T::PWP, px = p - py * T::PWP;
+      const int gy = gy0 + py, gx = gx0 + px;
+      const bool inside = p < T::NPOS && px < T::PWR && gy >= 0 && gy < H && gx >= 0 && gx < W;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[r] + br[r];
+        v = fminf(fmaxf(v, 0.0f), 6.0f);
+        hs[(size_t)row * T::NPOSP + p] = inside ? v : 0.0f;   // the depthwise conv zero-pads the EXPANDED map
+      }
+    }
+    __syncthreads();
+
+    // ---- depthwise 3x3: thread = (channel of the chunk, strip of 4 output columns), all TH rows of the tile
+    {
+      const int hc = hcd;
+      if (hc < hid) {
+        const float* hrow = hs + (size_t)cl * T::NPOSP + cg * 4 * S;
+        float acc[T::TH][4];
+#pragma unroll
+        for (int o = 0; o < T::TH; ++o)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[o][q] = 0.0f;
+        constexpr int NV = 3 * S + 3;                 // input columns per strip: S = 1: 6, S = 2: 9
+#pragma unroll
+        for (int r = 0; r < T::PH; ++r) {
+          float v[NV];
+          {   // 16-byte aligned strip start (cg * 4 * S floats, pitches are multiples of 4): two or three vector reads
+            const float4 q0 = *reinterpret_cast<const float4*>(hrow + r * T::PWP);
+            v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
+            if (S == 1) {
+              const float2 q1 = *reinterpret_cast<const float2*>(hrow + r * T::PWP + 4);
+              v[4] = q1.x; v[5] = q1.y;
+            } else {
+              const float4 q1 = *reinterpret_cast<const float4*>(hrow + r * T::PWP + 4);
+              v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+              v[NV - 1] = hrow[r * T::PWP + 8];
+            }
+          }
+#pragma unroll
+          for (int o = 0; o < T::TH; ++o) {
+            const int dy = r - o * S;
+            if (dy < 0 || dy > 2) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[o][q] = fmaf(v[q * S + dx], k9[dy * 3 + dx], acc[o][q]);
+          }
+        }
+        const int ox = ox0 + cg * 4;
+        float* ob = out + ((long long)b * hid + hc) * Ho * Wo;
+#pragma unroll
+        for (int o = 0; o < T::TH; ++o) {
+          const int oy = oy0 + o;
+          if (oy >= Ho) continue;
+          float y[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) y[q] = fminf(fmaxf(acc[o][q] + bb, 0.0f), 6.0f);
+          if (ox + 3 < Wo && (Wo & 3) == 0) {
+            *reinterpret_cast<float4*>(ob + (long long)oy * Wo + ox) = make_float4(y[0], y[1], y[2], y[3]);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (ox + q < Wo) ob[(long long)oy * Wo + ox + q] = y[q];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+size_t expand_dw_lds_bytes(int Cin, int stride) {
+  const int npp = stride == 1 ? IrTile<1>::NPOSP : IrTile<2>::NPOSP;
+  return ((size_t)(Cin + 32) * npp + 32 * (size_t)Cin) * sizeof(float);
+}
+
+int launch_expand_dw(const float* x, int B, int Cin, int H, int W, const float* w1, const float* b1, const float* wdw,
+                     const float* bdw, int hid, int stride, float* out, int Ho, int Wo, hipStream_t st) {
+  FDT_REQUIRE(stride == 1 || stride == 2, FDT_ERR_ARG, "expand_dw: stride %d", stride);
+  FDT_REQUIRE(Cin >= 2 && (Cin & 1) == 0 && hid >= 1 && B >= 1 && B <= 65535, FDT_ERR_ARG, "expand_dw: bad channel counts");
+  FDT_REQUIRE(Ho == (H - 1) / stride + 1 && Wo == (W - 1) / stride + 1, FDT_ERR_ARG, "expand_dw: output size mismatch");
+  const size_t lds = expand_dw_lds_bytes(Cin, stride);
+  FDT_REQUIRE(lds <= 160 * 1024, FDT_ERR_ARG, "expand_dw: %d input channels do not fit LDS", Cin);
+  static bool attr[2] = {false, false};   // idempotent; a race sets the same value twice
+  const int th = stride == 1 ? IrTile<1>::TH : IrTile<2>::TH;
+  dim3 grid((unsigned)(ceil_div(Wo, 32) * ceil_div(Ho, th)), 1, (unsigned)B);
+  if (stride == 1) {
+    if (!attr[0]) {
+      FDT_HIP(hipFuncSetAttribute((const void*)expand_dw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr[0] = true;
+    }
+    hipLaunchKernelGGL(expand_dw_kernel<1>, grid, dim3(256), lds, st, x, Cin, H, W, w1, b1, wdw, bdw, hid, out, Ho, Wo);
+  } else {
+    if (!attr[1]) {
+      FDT_HIP(hipFuncSetAttribute((const void*)expand_dw_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr[1] = true;
+    }
+    hipLaunchKernelGGL(expand_dw_kernel<2>, grid, dim3(256), lds, st, x, Cin, H, W, w1, b1, wdw, bdw, hid, out, Ho, Wo);
+  }
+  FDT_LAUNCH_CHECK();
+  return FDT_OK;
+}
+
+}  // namespace fdt
+
+// ---------------------------------------------------------------------------------------------------
+// Stand-alone op (host pointers): ReLU6(BN(dw3x3(ReLU6(BN(conv1x1(x)))))) with the BatchNorms already folded into
+// (w1, b1) and (wdw, bdw) -- what the fused kernel computes for conv[0..5] of an InvertedResidual with expand_ratio != 1
+// (pyramid_mb2_try3.py:96-114).  The parity tests drive this entry point on odd sizes.
+extern "C" int fdt_expand_dw(const float* x, int B, int Cin, int H, int W, const float* w1, const float* b1,
+                             const float* wdw, const float* bdw, int hid, int stride, float* out) {
+  using namespace fdt;
+  FDT_REQUIRE(x && w1 && b1 && wdw && bdw && out && B >= 1 && H >= 1 && W >= 1, FDT_ERR_ARG, "fdt_expand_dw: bad argument");
+  FDT_REQUIRE(stride == 1 || stride == 2, FDT_ERR_ARG, "fdt_expand_dw: stride must be 1 or 2");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  DevBuf dx, dw1, db1, dwd, dbd, dout;
+  const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * hid * Ho * Wo;
+  FDT_TRY(dx.alloc(nx * 4)); FDT_TRY(dw1.alloc((size_t)hid * Cin * 4)); FDT_TRY(db1.alloc((size_t)hid * 4));
+  FDT_TRY(dwd.alloc((size_t)hid * 36)); FDT_TRY(dbd.alloc((size_t)hid * 4)); FDT_TRY(dout.alloc(no * 4));
+  FDT_HIP(hipMemcpy(dx.p, x, nx * 4, hipMemcpyHostToDevice));
+  FDT_HIP(hipMemcpy(dw1.p, w1, (size_t)hid * Cin * 4, hipMemcpyHostToDevice));
+  FDT_HIP(hipMemcpy(db1.p, b1, (size_t)hid * 4, hipMemcpyHostToDevice));
+  FDT_HIP(hipMemcpy(dwd.p, wdw, (size_t)hid * 36, hipMemcpyHostToDevice));
+  FDT_HIP(hipMemcpy(dbd.p, bdw, (size_t)hid * 4, hipMemcpyHostToDevice));
+  FDT_TRY(launch_expand_dw(dx.as<float>(), B, Cin, H, W, dw1.as<float>(), db1.as<float>(), dwd.as<float>(),
+                           dbd.as<float>(), hid, stride, dout.as<float>(), Ho, Wo, 0));
+  FDT_HIP(hipDeviceSynchronize());
+  FDT_HIP(hipMemcpy(out, dout.p, no * 4, hipMemcpyDeviceToHost));
+  return FDT_OK;
+}
+
+// Tuning hook (not part of include/fdt.h): time the fused kernel on zero-filled device buffers with HIP events.
+extern "C" int fdt_debug_expand_dw_bench(int B, int Cin, int H, int W, int hid, int stride, int iters, float* ms_out) {
+  using namespace fdt;
+  FDT_REQUIRE(ms_out && iters >= 1 && (stride == 1 || stride == 2), FDT_ERR_ARG, "fdt_debug_expand_dw_bench: bad argument");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  DevBuf dx, dw1, db1, dwd, dbd, dout;
+  const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * hid * Ho * Wo;
+  FDT_TRY(dx.alloc(nx * 4)); FDT_TRY(dw1.alloc((size_t)hid * Cin * 4)); FDT_TRY(db1.alloc((size_t)hid * 4));
+  FDT_TRY(dwd.alloc((size_t)hid * 36)); FDT_TRY(dbd.alloc((size_t)hid * 4)); FDT_TRY(dout.alloc(no * 4));
+  FDT_HIP(hipMemset(dx.p, 0, nx * 4)); FDT_HIP(hipMemset(dw1.p, 0, (size_t)hid * Cin * 4));
+  FDT_HIP(hipMemset(db1.p, 0, (size_t)hid * 4)); FDT_HIP(hipMemset(dwd.p, 0, (size_t)hid * 36));
+  FDT_HIP(hipMemset(dbd.p, 0, (size_t)hid * 4));
+  hipEvent_t e0, e1;
+  FDT_HIP(hipEventCreate(&e0)); FDT_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i)
+    FDT_TRY(launch_expand_dw(dx.as<float>(), B, Cin, H, W, dw1.as<float>(), db1.as<float>(), dwd.as<float>(),
+                             dbd.as<float>(), hid, stride, dout.as<float>(), Ho, Wo, 0));
+  FDT_HIP(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i)
+    FDT_TRY(launch_expand_dw(dx.as<float>(), B, Cin, H, W, dw1.as<float>(), db1.as<float>(), dwd.as<float>(),
+                             dbd.as<float>(), hid, stride, dout.as<float>(), Ho, Wo, 0));
+  FDT_HIP(hipEventRecord(e1, 0));
+  FDT_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  FDT_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return FDT_OK;
+}

@@ -37,7 +37,7 @@ struct Tensor {
   float* d = nullptr;
 };
 
-enum OpType { OP_CONV, OP_POOL, OP_DW, OP_HEADFIN, OP_MBOXFIN, OP_PAD };
+enum OpType { OP_CONV, OP_POOL, OP_DW, OP_HEADFIN, OP_MBOXFIN, OP_PAD, OP_EXPDW };
 
 struct Op {
   OpType type;
@@ -52,6 +52,9 @@ struct Op {
   int ksize = 3, pad = 1, dil = 1;   // depthwise geometry
   const float* w = nullptr;
   const float* bias = nullptr;
+  const float* w2 = nullptr;     // OP_EXPDW: depthwise taps / bias (w, bias = the 1x1 expand)
+  const float* bias2 = nullptr;
+  int hid = 0;
   int level0 = 0, p_off = 0, anchors = 1;
   bool needs_ws = false;
 };
@@ -578,6 +581,69 @@ struct Builder {
     return out_t;
   }
 
+  // conv[0..5] of an InvertedResidual with expand_ratio != 1 as ONE kernel (fused_ir.hip): 1x1 expand + BN + ReLU6 and the
+  // depthwise 3x3 + BN + ReLU6; the expanded tensor never reaches HBM.  pyramid_mb2_try3.py:96-114.
+  int expand_dw(const std::string& p, int in_t, int hid, int stride) {
+    if (rc != FDT_OK) return -1;
+    const Tensor in = m->tensors[in_t];
+    const int Ho = (in.H - 1) / stride + 1, Wo = (in.W - 1) / stride + 1;
+    const std::string n1 = p + ".conv.0", bn1 = p + ".conv.1", n2 = p + ".conv.3", bn2 = p + ".conv.4";
+    int out_t = new_tensor(n2, hid, Ho, Wo);
+    if (out_t < 0) return -1;
+    const HostT* w1 = get(n1 + ".weight");
+    const HostT* w2 = get(n2 + ".weight");
+    std::vector<float> s1, b1, s2, b2;
+    fold(bn1, nullptr, hid, s1, b1);
+    fold(bn2, nullptr, hid, s2, b2);
+    Op op;
+    op.type = OP_EXPDW;
+    op.name = p + ".expand_dw";
+    op.in_t = in_t;
+    op.out_t = out_t;
+    op.stride = stride;
+    op.hid = hid;
+    op.flops = 2.0 * B * ((double)in.H * in.W * in.C * hid + (double)Ho * Wo * hid * 9);
+    memset(&op.ca, 0, sizeof(op.ca));
+    if (!m->dry) {
+      if (rc != FDT_OK) return -1;
+      if ((int)w1->v.size() != hid * in.C || (int)w2->v.size() != hid * 9) {
+        set_error("weight shape mismatch for the fused block %s", p.c_str());
+        return fail(FDT_ERR_STATE);
+      }
+      std::lock_guard<std::mutex> lk(m->W->mu);
+      DevW d1, d2;
+      auto it = m->W->wcache.find(p + "|expdw1");
+      if (it == m->W->wcache.end()) {
+        std::vector<float> a(w1->v), d(w2->v);
+        for (int c = 0; c < hid; ++c) {
+          for (int k = 0; k < in.C; ++k) a[(size_t)c * in.C + k] *= s1[c];
+          for (int k = 0; k < 9; ++k) d[(size_t)c * 9 + k] *= s2[c];
+        }
+        if (hipMalloc((void**)&d1.w, a.size() * 4) != hipSuccess || hipMalloc((void**)&d1.bias, (size_t)hid * 4) != hipSuccess ||
+            hipMalloc((void**)&d2.w, d.size() * 4) != hipSuccess || hipMalloc((void**)&d2.bias, (size_t)hid * 4) != hipSuccess) {
+          set_error("hipMalloc failed for %s", p.c_str());
+          return fail(FDT_ERR_HIP);
+        }
+        (void)hipMemcpy(d1.w, a.data(), a.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(d1.bias, b1.data(), (size_t)hid * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(d2.w, d.data(), d.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(d2.bias, b2.data(), (size_t)hid * 4, hipMemcpyHostToDevice);
+        m->W->wcache[p + "|expdw1"] = d1;
+        m->W->wcache[p + "|expdw2"] = d2;
+      } else {
+        d1 = it->second;
+        d2 = m->W->wcache[p + "|expdw2"];
+      }
+      op.w = d1.w;
+      op.bias = d1.bias;
+      op.w2 = d2.w;
+      op.bias2 = d2.bias;
+    }
+    m->ops.push_back(op);
+    m->flops_per_frame += op.flops / B;
+    return out_t;
+  }
+
   void mboxfin(int map_t, int anchors) {   // FACEBOX/multibox_layer.py:34-48
     if (rc != FDT_OK) return;
     Op op;
@@ -741,16 +807,28 @@ struct Builder {
     int h = x;
     int i = 0;
     const int hid = (int)std::lround((double)inp * t);
-    if (t != 1) {
-      ConvOpt o;
-      o.bias = false;
-      o.bn = p + ".conv." + std::to_string(i + 1);
-      o.act = ACT_RELU6;
-      h = conv(p + ".conv." + std::to_string(i), h, hid, CONV_1x1_S1, o);
+    // The expanded tensor is t times the input: on the large maps writing and re-reading it IS the block's cost, so the
+    // expand and the depthwise conv run as one kernel there (measured on try3 at batch 8: 319 vs 473 us for features.2,
+    // 140 vs 189 us for features.4; from 128^2 down the two separate launches are faster).  FDT_FUSE_IR=0|1 forces it.
+    const Tensor xin = m->tensors[x];
+    bool fuse = t != 1 && (inp & 1) == 0 && (stride == 1 || stride == 2) && (long long)xin.H * xin.W >= 256ll * 256;
+    if (const char* e = getenv("FDT_FUSE_IR")) fuse = t != 1 && (inp & 1) == 0 && atoi(e) != 0;
+    if (fuse && expand_dw_lds_bytes(inp, stride) > 80 * 1024) fuse = false;   // keep two workgroups per CU
+    if (fuse) {
+      h = expand_dw(p, h, hid, stride);
+      i += 6;
+    } else {
+      if (t != 1) {
+        ConvOpt o;
+        o.bias = false;
+        o.bn = p + ".conv." + std::to_string(i + 1);
+        o.act = ACT_RELU6;
+        h = conv(p + ".conv." + std::to_string(i), h, hid, CONV_1x1_S1, o);
+        i += 3;
+      }
+      h = dwconv(p + ".conv." + std::to_string(i), p + ".conv." + std::to_string(i + 1), h, stride, ACT_RELU6);
       i += 3;
     }
-    h = dwconv(p + ".conv." + std::to_string(i), p + ".conv." + std::to_string(i + 1), h, stride, ACT_RELU6);
-    i += 3;
     ConvOpt o;
     o.bias = false;
     o.bn = p + ".conv." + std::to_string(i + 1);
@@ -1178,6 +1256,13 @@ int run_ops(fdt_model* m, int B, hipStream_t st) {
         const Tensor& out = m->tensors[op.out_t];
         FDT_TRY(launch_dwconv(in.d, op.w, op.bias, B, in.C, in.H, in.W, op.ksize, op.stride, op.pad, op.dil, op.act,
                               out.d, out.H, out.W, st));
+        break;
+      }
+      case OP_EXPDW: {
+        const Tensor& in = m->tensors[op.in_t];
+        const Tensor& out = m->tensors[op.out_t];
+        FDT_TRY(launch_expand_dw(in.d, B, in.C, in.H, in.W, op.w, op.bias, op.w2, op.bias2, op.hid, op.stride, out.d, out.H,
+                                 out.W, st));
         break;
       }
       case OP_HEADFIN: {
@@ -1993,6 +2078,9 @@ extern "C" int fdt_model_traffic(fdt_model* m, double* act_bytes, double* weight
       if (op.ca.res) b += 4.0 * op.ca.B * (double)op.ca.Cout * op.ca.Hout * op.ca.Wout;
       if (op.ca.up) b += 4.0 * op.ca.B * (double)op.ca.Cout * op.ca.up_h * op.ca.up_w;
       w = 4.0 * ((double)op.ca.Cout * op.ca.Cin * g.kh * g.kw + op.ca.Cout);
+    } else if (op.type == OP_EXPDW) {
+      b = tb(op.in_t) + tb(op.out_t);
+      w = 4.0 * op.hid * (m->tensors[op.in_t].C + 1 + 9 + 1);
     } else if (op.type == OP_HEADFIN || op.type == OP_MBOXFIN) {
       b = 2.0 * tb(op.in_t);
     } else {

@@ -41,4 +41,11 @@ int launch_multibox_finalize(const float* locmap, const float* confmap, long lon
                              int H, int W, int P, int p_off, float* loc, float* conf, float* logits,
                              hipStream_t st);
 
+// Fused conv[0..5] of an InvertedResidual with expand_ratio != 1 (pyramid_mb2_try3.py:96-114): 1x1 expand + BN + ReLU6
+// + depthwise 3x3 (stride 1|2, pad 1) + BN + ReLU6; BatchNorms folded into (w1 [hid][Cin], b1) and (wdw [hid][9], bdw).
+// The expanded tensor stays in LDS (fused_ir.hip).
+int launch_expand_dw(const float* x, int B, int Cin, int H, int W, const float* w1, const float* b1, const float* wdw,
+                     const float* bdw, int hid, int stride, float* out, int Ho, int Wo, hipStream_t st);
+size_t expand_dw_lds_bytes(int Cin, int stride);
+
 }  // namespace fdt

@@ -118,6 +118,13 @@ int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const float* w_oihw
                int Cout, int ksize, int stride, int pad, int dil, const float* residual, const float* up,
                int up_h, int up_w, int act, int tile, int ksplit, float* out);
 
+/* conv[0..5] of an InvertedResidual block with expand_ratio != 1 (pyramid_mb2_try3.py:96-114): 1x1 expand + BN + ReLU6,
+ * depthwise 3x3 (stride 1 | 2, pad 1) + BN + ReLU6, as ONE kernel whose expanded tensor never leaves the CU.  The eval
+ * BatchNorms are already folded: w1 [hid][Cin], b1 [hid], wdw [hid][9], bdw [hid].  x [B,Cin,H,W] -> out [B,hid,Ho,Wo]
+ * (host pointers; the detector graphs use the same kernel on device tensors).  Cin even.                          */
+int fdt_expand_dw(const float* x, int B, int Cin, int H, int W, const float* w1, const float* b1, const float* wdw,
+                  const float* bdw, int hid, int stride, float* out);
+
 /* ------------------------------------------------------------------ IoU tracker
  * The inline tracker of iouTracke_cal.py:113-156 (per frame) and :174-177 (finalise), as a
  * device-resident state machine.  A track is {bboxes, max_score, start_frame}.  One frame's detections

@@ -179,3 +179,26 @@ def test_unknown_class_is_an_error():
     w = np.zeros((4, 4, 3, 3), np.float32)
     rc, _ = run_conv(x, w, None, 3, 3, 1, 1)
     assert rc == lib().FDT_ERR_ARG
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("shape", [(16, 96, 40, 64), (24, 144, 37, 50), (32, 100, 9, 33), (64, 384, 16, 32)])
+def test_fused_expand_depthwise(stride, shape):
+    """conv[0..5] of an InvertedResidual (pyramid_mb2_try3.py:96-114, BatchNorms folded) as one kernel vs torch: sizes that
+    are not multiples of the 32-column tile / 4-row strips, hidden widths that are not multiples of 32, batch 2."""
+    Cin, hid, H, W = shape
+    rng = np.random.default_rng(Cin * 7 + H + stride)
+    x = rng.standard_normal((2, Cin, H, W)).astype(np.float32)
+    w1 = (rng.standard_normal((hid, Cin)) / np.sqrt(Cin)).astype(np.float32)
+    b1 = rng.standard_normal(hid).astype(np.float32)
+    wd = (rng.standard_normal((hid, 9)) / 3).astype(np.float32)
+    bd = rng.standard_normal(hid).astype(np.float32)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = np.empty((2, hid, Ho, Wo), np.float32)
+    L = lib()
+    rc = L.lib().fdt_expand_dw(L.ptr(x), 2, Cin, H, W, L.ptr(w1), L.ptr(b1), L.ptr(wd), L.ptr(bd), hid, stride, L.ptr(out))
+    assert rc == 0, L.lib().fdt_last_error()
+    h = F.relu6(F.conv2d(torch.from_numpy(x), torch.from_numpy(w1)[:, :, None, None], torch.from_numpy(b1)))
+    y = F.relu6(F.conv2d(h, torch.from_numpy(wd).reshape(hid, 1, 3, 3), torch.from_numpy(bd), stride, 1, 1, hid)).numpy()
+    assert out.shape == y.shape
+    assert rel_err(out, y) < 1e-5, (shape, stride, rel_err(out, y))

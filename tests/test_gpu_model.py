@@ -357,3 +357,34 @@ def test_try3_1024_batch8_vs_reference_fixture(try3, synth):
         np.testing.assert_allclose(conf[b, sel], d["%s_conf_s%d" % (key, b)], atol=SCORE_ATOL, rtol=0)
     # and the second (graph-replayed) batched forward returns the same bits
     assert np.array_equal(try3(frames).numpy(), y)
+
+
+def test_try3_with_fused_inverted_residual_heads(try3_sd, synth, monkeypatch):
+    """The fused expand + depthwise kernel (csrc/fused_ir.hip) normally takes over only on maps of 256^2 and more; forced on
+    for every block that fits (FDT_FUSE_IR=1), the try3 stages at a small odd size still match the oracle, and the forced-off
+    graph gives the same detections."""
+    H, W = 136, 200
+    frame = synth.make_frames(1, H, W, seed=8)[0]
+    x = opb.preprocess(frame)
+    PB = M("layers").PriorBoxLayer
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FDT_FUSE_IR", mode)
+        net = M("pyramid_mb2_try3").build_sfd_mobile('test', 640, 2)
+        net.load_state_dict(try3_sd)
+        net.priorbox = PB(W, H, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256))
+        net.detect = M("layers").Detect(2, 0, 750, 0.02, 0.35)
+        outs[mode] = net(x).numpy()
+        if mode == "1":
+            o = opb.try3_forward(try3_sd, x, want=TRY3_STAGES)
+            for st in TRY3_STAGES:
+                got = net.get_tensor(st)
+                assert got.shape == o[st].shape and rel_rms(got, o[st]) < STAGE_RTOL, (st, rel_rms(got, o[st]))
+            names = [n for n, _, _ in (net.profile(True), net(x), net.profile_read())[2]]
+            # every block whose staged patch leaves room for two workgroups per CU (features.2 .. features.6)
+            assert sum(n.endswith(".expand_dw") for n in names) == 5
+            net.profile(False)
+        net.close()
+    n = int((outs["0"][0, 1, :, 0] > 0).sum())
+    d_iou, d_sc = match_detections(outs["1"][0, 1], outs["0"][0, 1], n)
+    assert n > 5 and d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
