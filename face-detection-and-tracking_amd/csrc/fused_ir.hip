@@ -14,6 +14,8 @@
 //     strips of the output.
 // 50-80 KB of LDS per workgroup -> two or three workgroups per CU, so one's GEMM phase overlaps the other's stencil
 // phase.  The 1x1 project conv that follows stays a separate launch (its input is 6x smaller than the expanded map).
+#include <atomic>
+
 #include "common.h"
 #include "ops.h"
 
@@ -37,8 +39,10 @@ struct IrTile {
   static constexpr int NT = NPOSP / 32;
 };
 
-// grid: (tiles_x * tiles_y, 1, B); 256 threads; dynamic LDS: (Cin + 32) * NPOSP + 32 * Cin floats
-template <int S>
+// grid: (tiles_x * tiles_y, 1, B); 256 threads; dynamic LDS: (Cin + 32) * NPOSP + 32 * Cin floats.
+// KS = Cin / 2 when known at compile time (the GEMM loop is then fully unrolled: all operand reads of a column tile are in
+// flight before its first MFMA), 0 = runtime loop.
+template <int S, int KS>
 __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict__ x, int Cin, int H, int W,
                                                         const float* __restrict__ w1, const float* __restrict__ b1,
                                                         const float* __restrict__ wdw, const float* __restrict__ bdw,
@@ -72,15 +76,9 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict_
     }
   }
   const int nchunks = (hid + 31) / 32;
-  const int ksteps = Cin >> 1;
+  const int ksteps = KS ? KS : (Cin >> 1);
 
   for (int ch = 0; ch < nchunks; ++ch) {
-    // ---- this chunk's 32 x Cin expand weights -> LDS, transposed so that a wave reads one k-row per operand
-    for (int e = tid; e < 32 * Cin; e += 256) {
-      const int k = e >> 5, rr = e & 31;
-      const int hc = ch * 32 + rr;
-      ws[e] = hc < hid ? w1[(long long)hc * Cin + k] : 0.0f;
-    }
     // this chunk's expand biases (the 16 accumulator rows of the lane) and the thread's depthwise taps: requested now,
     // consumed after the barrier / the GEMM phase
     float br[16];
@@ -96,27 +94,63 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 9; ++i) k9[i] = wdw[(long long)hcc * 9 + i];
     const float bb = bdw[hcc];
+    // this chunk's 32 x Cin expand weights -> LDS, transposed so that a wave reads one k-row per operand (staging all
+    // chunks at once costs a workgroup per CU on the 144-channel blocks: measured slower)
+    for (int e = tid; e < 32 * Cin; e += 256) {
+      const int k = e >> 5, rr = e & 31;
+      const int hw = ch * 32 + rr;
+      ws[e] = hw < hid ? w1[(long long)hw * Cin + k] : 0.0f;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the patch (first chunk) has landed
     __syncthreads();
     // ---- expand: hs[32][positions] = ReLU6(W1[chunk] . xs + b1), column tiles dealt round-robin to the four waves
-    for (int j = wave; j < T::NT; j += 4) {
-      f32x16 acc;
+    // A wave owns the column tiles wave, wave + 4, ...: their accumulation chains are independent, so they are advanced
+    // together (one dependent MFMA chain alone leaves the matrix pipe idle 3/4 of the time at one wave per SIMD); the A
+    // operand (weights) is shared by all of them.
+    {
+      constexpr int JT = (T::NT + 3) / 4;
+      f32x16 acc[JT];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-      const float* bcol = xs + j * 32 + l31 + (size_t)half * T::NPOSP;
+      for (int t = 0; t < JT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
       const float* acol = ws + half * 32 + l31;
-      for (int s = 0; s < ksteps; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(acol[s * 64], bcol[(size_t)s * 2 * T::NPOSP], acc, 0, 0, 0);
-      const int p = j * 32 + l31;
-      const int py = p / T::PWP, px = p - py * T::PWP;
-      const int gy = gy0 + py, gx = gx0 + px;
-      const bool inside = p < T::NPOS && px < T::PWR && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const float* bcol = xs + wave * 32 + l31 + (size_t)half * T::NPOSP;      // tile t: + t * 128 positions
+      if constexpr (KS > 0) {
+        float av[KS], bw[JT][KS];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = acc[r] + br[r];
-        v = fminf(fmaxf(v, 0.0f), 6.0f);
-        hs[(size_t)row * T::NPOSP + p] = inside ? v : 0.0f;   // the depthwise conv zero-pads the EXPANDED map
+        for (int s = 0; s < KS; ++s) {
+          av[s] = acol[s * 64];
+#pragma unroll
+          for (int t = 0; t < JT; ++t) bw[t][s] = bcol[(size_t)s * 2 * T::NPOSP + t * 128];
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+          for (int t = 0; t < JT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bw[t][s], acc[t], 0, 0, 0);
+      } else {
+        for (int s = 0; s < ksteps; ++s) {
+          const float a_ = acol[s * 64];
+#pragma unroll
+          for (int t = 0; t < JT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, bcol[(size_t)s * 2 * T::NPOSP + t * 128], acc[t], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < JT; ++t) {
+        const int j = wave + 4 * t;
+        if (j >= T::NT) continue;
+        const int p = j * 32 + l31;
+        const int py = p / T::PWP, px = p - py * T::PWP;
+        const int gy = gy0 + py, gx = gx0 + px;
+        const bool inside = p < T::NPOS && px < T::PWR && gy >= 0 && gy < H && gx >= 0 && gx < W;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = acc[t][r] + br[r];
+          v = fminf(fmaxf(v, 0.0f), 6.0f);
+          hs[(size_t)row * T::NPOSP + p] = inside ? v : 0.0f;   // the depthwise conv zero-pads the EXPANDED map
+        }
       }
     }
     __syncthreads();
@@ -182,8 +216,9 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict_
 
 }  // namespace
 
-size_t expand_dw_lds_bytes(int Cin, int stride) {
+size_t expand_dw_lds_bytes(int Cin, int stride, int hid) {
   const int npp = stride == 1 ? IrTile<1>::NPOSP : IrTile<2>::NPOSP;
+  (void)hid;
   return ((size_t)(Cin + 32) * npp + 32 * (size_t)Cin) * sizeof(float);
 }
 
@@ -192,24 +227,32 @@ int launch_expand_dw(const float* x, int B, int Cin, int H, int W, const float* 
   FDT_REQUIRE(stride == 1 || stride == 2, FDT_ERR_ARG, "expand_dw: stride %d", stride);
   FDT_REQUIRE(Cin >= 2 && (Cin & 1) == 0 && hid >= 1 && B >= 1 && B <= 65535, FDT_ERR_ARG, "expand_dw: bad channel counts");
   FDT_REQUIRE(Ho == (H - 1) / stride + 1 && Wo == (W - 1) / stride + 1, FDT_ERR_ARG, "expand_dw: output size mismatch");
-  const size_t lds = expand_dw_lds_bytes(Cin, stride);
-  FDT_REQUIRE(lds <= 160 * 1024, FDT_ERR_ARG, "expand_dw: %d input channels do not fit LDS", Cin);
-  static bool attr[2] = {false, false};   // idempotent; a race sets the same value twice
+  const size_t lds = expand_dw_lds_bytes(Cin, stride, hid);
+  FDT_REQUIRE(lds <= 160 * 1024, FDT_ERR_ARG, "expand_dw: %d -> %d channels do not fit LDS", Cin, hid);
   const int th = stride == 1 ? IrTile<1>::TH : IrTile<2>::TH;
   dim3 grid((unsigned)(ceil_div(Wo, 32) * ceil_div(Ho, th)), 1, (unsigned)B);
-  if (stride == 1) {
-    if (!attr[0]) {
-      FDT_HIP(hipFuncSetAttribute((const void*)expand_dw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr[0] = true;
-    }
-    hipLaunchKernelGGL(expand_dw_kernel<1>, grid, dim3(256), lds, st, x, Cin, H, W, w1, b1, wdw, bdw, hid, out, Ho, Wo);
-  } else {
-    if (!attr[1]) {
-      FDT_HIP(hipFuncSetAttribute((const void*)expand_dw_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr[1] = true;
-    }
-    hipLaunchKernelGGL(expand_dw_kernel<2>, grid, dim3(256), lds, st, x, Cin, H, W, w1, b1, wdw, bdw, hid, out, Ho, Wo);
+  typedef void (*Kern)(const float*, int, int, int, const float*, const float*, const float*, const float*, int, float*, int,
+                       int);
+  const int ks = Cin >> 1;
+  Kern fn = nullptr;
+  if (stride == 1)
+    fn = ks == 8 ? expand_dw_kernel<1, 8> : ks == 12 ? expand_dw_kernel<1, 12> : ks == 16 ? expand_dw_kernel<1, 16>
+                                                                                        : expand_dw_kernel<1, 0>;
+  else
+    fn = ks == 8 ? expand_dw_kernel<2, 8> : ks == 12 ? expand_dw_kernel<2, 12> : ks == 16 ? expand_dw_kernel<2, 16>
+                                                                                        : expand_dw_kernel<2, 0>;
+  // per-(function, device) attribute; set on every launch of a not-yet-seen pair (idempotent, a race sets it twice)
+  static std::atomic<unsigned long long> seen[16];
+  int dev = 0;
+  FDT_HIP(hipGetDevice(&dev));
+  const int slot = (stride - 1) * 4 + (ks == 8 ? 0 : ks == 12 ? 1 : ks == 16 ? 2 : 3);
+  if (dev < 16 && !((seen[dev].load(std::memory_order_acquire) >> slot) & 1ull)) {
+    FDT_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    seen[dev].fetch_or(1ull << slot, std::memory_order_release);
+  } else if (dev >= 16) {
+    FDT_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, x, Cin, H, W, w1, b1, wdw, bdw, hid, out, Ho, Wo);
   FDT_LAUNCH_CHECK();
   return FDT_OK;
 }

@@ -813,7 +813,7 @@ struct Builder {
     const Tensor xin = m->tensors[x];
     bool fuse = t != 1 && (inp & 1) == 0 && (stride == 1 || stride == 2) && (long long)xin.H * xin.W >= 256ll * 256;
     if (const char* e = getenv("FDT_FUSE_IR")) fuse = t != 1 && (inp & 1) == 0 && atoi(e) != 0;
-    if (fuse && expand_dw_lds_bytes(inp, stride) > 80 * 1024) fuse = false;   // keep two workgroups per CU
+    if (fuse && expand_dw_lds_bytes(inp, stride, hid) > 80 * 1024) fuse = false;   // keep two workgroups per CU
     if (fuse) {
       h = expand_dw(p, h, hid, stride);
       i += 6;

@@ -46,6 +46,6 @@ int launch_multibox_finalize(const float* locmap, const float* confmap, long lon
 // The expanded tensor stays in LDS (fused_ir.hip).
 int launch_expand_dw(const float* x, int B, int Cin, int H, int W, const float* w1, const float* b1, const float* wdw,
                      const float* bdw, int hid, int stride, float* out, int Ho, int Wo, hipStream_t st);
-size_t expand_dw_lds_bytes(int Cin, int stride);
+size_t expand_dw_lds_bytes(int Cin, int stride, int hid);
 
 }  // namespace fdt
