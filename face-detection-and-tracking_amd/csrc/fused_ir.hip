@@ -144,13 +144,20 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict_
         const int py = p / T::PWP, px = p - py * T::PWP;
         const int gy = gy0 + py, gx = gx0 + px;
         const bool inside = p < T::NPOS && px < T::PWR && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        // three passes over the 16 rows (independent instructions back to back) instead of one dependent
+        // add -> clamp -> select -> store chain per row, which an in-order SIMD with two waves cannot hide
+        float vv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-          float v = acc[t][r] + br[r];
-          v = fminf(fmaxf(v, 0.0f), 6.0f);
-          hs[(size_t)row * T::NPOSP + p] = inside ? v : 0.0f;   // the depthwise conv zero-pads the EXPANDED map
+        for (int r = 0; r < 16; ++r) vv[r] = acc[t][r] + br[r];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[r] = fminf(fmaxf(vv[r], 0.0f), 6.0f);
+        if (__ballot(!inside) != 0ull) {        // border tile: the depthwise conv zero-pads the EXPANDED map
+#pragma unroll
+          for (int r = 0; r < 16; ++r) vv[r] = inside ? vv[r] : 0.0f;
         }
+        float* hp = hs + 4 * half * T::NPOSP + p;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hp[(size_t)((r & 3) + 8 * (r >> 2)) * T::NPOSP] = vv[r];
       }
     }
     __syncthreads();
