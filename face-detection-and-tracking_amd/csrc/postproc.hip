@@ -367,13 +367,22 @@ __global__ __launch_bounds__(64) void scan_kernel(
     kept_total = kt;
     if (kept_total >= limit) break;
     // fold the kept rows into the removed bitmap of the later chunks
+    // (eight rows per round trip: one dependent load per kept row made this loop the whole kernel's time)
     for (int w = c + 1 + lane; w < nw; w += 64) {
       unsigned long long acc = 0;
       unsigned long long kb = keptbits;
       while (kb) {
-        int r = __ffsll((long long)kb) - 1;
-        kb &= kb - 1;
-        acc |= mask[(base + c * 64 + r) * nwt + w];
+        int rr[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          rr[q] = kb ? __ffsll((long long)kb) - 1 : -1;
+          kb &= kb - (kb ? 1ull : 0ull);
+        }
+        unsigned long long v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = rr[q] >= 0 ? mask[(base + c * 64 + rr[q]) * nwt + w] : 0ull;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc |= v[q];
       }
       removed[w] |= acc;
     }
