@@ -6,7 +6,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int MODE>
-__global__ __launch_bounds__(512, 2) void mix(float* out, int iters) {
+__global__ __launch_bounds__(512, 2) void mix(float* out, int iters, long long* cyc) {
+  const long long c0 = clock64();
   __shared__ float lds[16384];
   for (int i = threadIdx.x; i < 16384; i += 512) lds[i] = (float)(i & 7) * 0.125f;
   __syncthreads();
@@ -37,6 +38,7 @@ __global__ __launch_bounds__(512, 2) void mix(float* out, int iters) {
   for (int t = 0; t < 8; ++t)
     for (int r = 0; r < 16; ++r) s += acc[t][r];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *cyc = clock64() - c0;   // shader-clock cycles of one wave's lifetime
 }
 
 template <int MODE>
@@ -45,16 +47,21 @@ void run(float* d, const char* what) {
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   const int iters = 40000;
-  hipLaunchKernelGGL(mix<MODE>, dim3(256), dim3(512), 0, 0, d, 100);
+  long long* dc;
+  hipMalloc(&dc, 8);
+  hipLaunchKernelGGL(mix<MODE>, dim3(256), dim3(512), 0, 0, d, 100, dc);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL(mix<MODE>, dim3(256), dim3(512), 0, 0, d, iters);
+  hipLaunchKernelGGL(mix<MODE>, dim3(256), dim3(512), 0, 0, d, iters, dc);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
   const double flops = 256.0 * 8 * iters * 8 * (32.0 * 32 * 2 * 2);
-  printf("%-46s %.3f ms  %.1f TFLOP/s\n", what, ms, flops / ms / 1e9);
+  long long hc = 0;
+  hipMemcpy(&hc, dc, 8, hipMemcpyDeviceToHost);
+  printf("%-46s %.3f ms  %.1f TFLOP/s   shader clock %.0f MHz, %.1f cycles per MFMA per SIMD\n", what, ms, flops / ms / 1e9,
+         hc / (ms * 1e3), (double)hc / (iters * 8.0 * 2));
 }
 
 int main() {
