@@ -149,3 +149,32 @@ def test_header_documents_the_round2_surface():
     for word in ("FDT_COMM_ID_BYTES 128", "fdt_tracker_step_dev_multi", "fdt_model_clone", "fdt_model_forward_async",
                  "MyTrain_repo.py:71", "iouTracke_cal.py:119-124", "FACEBOX/My_test_facebox.py:12-36"):
         assert word in src, word
+
+
+def test_bench_host_helpers_and_committed_plans():
+    """Host-side bookkeeping of bench.py (no GPU): op-name parsing, kernel labels, CPU description; and the committed
+    plans still contain the layers whose kernels tools/refresh_profiles.sh profiles one by one (it reads kind / tile /
+    split-K from the plan, so a re-tune cannot leave the PMC files describing a kernel that is no longer used)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.parse_op("layer3.1.conv1#k10t27s1") == ("layer3.1.conv1", 10, 27, 1)
+    assert bench.parse_op("pool") == ("pool", None, None, None)
+    assert bench.kernel_label(8, 30).startswith("conv_wino4_kernel<3x3s1_wino")
+    assert bench.kernel_label(9, 22).startswith("conv_wino2_kernel<3x3d2_wino")
+    assert bench.kernel_label(0, 12) == "conv_kernel<1x1s1, tile 12>"
+    model, phys, logical = bench.cpu_info()
+    assert phys >= 1 and logical >= phys and isinstance(model, str)
+    plan_dir = os.path.join(ROOT, "face-detection-and-tracking_amd", "tuned")
+    plan = {}
+    for ln in open(os.path.join(plan_dir, "res50_1024x1024_b1.plan")):
+        f = ln.split()
+        if len(f) >= 4 and f[0] != "shape":
+            plan[f[0]] = tuple(int(v) for v in f[1:4])
+    for layer in ("conv2_SSH.conv1", "layer3.1.conv1", "layer1.0.conv3", "layer2.1.conv3"):
+        assert layer in plan, layer
+    assert plan["conv2_SSH.conv1"][0] == 8 and plan["conv2_SSH.conv1"][1] in (29, 30)     # quarter-split Winograd
+    assert len(plan) == 105                                                               # every conv layer of Res50
+    sh = open(os.path.join(ROOT, "tools", "refresh_profiles.sh")).read()
+    assert all(("plan_of " + layer) in sh for layer in ("conv2_SSH.conv1", "layer3.1.conv1", "layer1.0.conv3"))
