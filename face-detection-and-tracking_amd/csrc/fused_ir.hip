@@ -230,7 +230,7 @@ size_t expand_dw_lds_bytes(int Cin, int stride, int hid) {
 }
 
 int launch_expand_dw(const float* x, int B, int Cin, int H, int W, const float* w1, const float* b1, const float* wdw,
-                     const float* bdw, int hid, int stride, float* out, int Ho, int Wo, hipStream_t st) {
+                     const float* bdw, int hid, int stride, float* out, int Ho, int Wo, hipStream_t st, int dev) {
   FDT_REQUIRE(stride == 1 || stride == 2, FDT_ERR_ARG, "expand_dw: stride %d", stride);
   FDT_REQUIRE(Cin >= 2 && (Cin & 1) == 0 && hid >= 1 && B >= 1 && B <= 65535, FDT_ERR_ARG, "expand_dw: bad channel counts");
   FDT_REQUIRE(Ho == (H - 1) / stride + 1 && Wo == (W - 1) / stride + 1, FDT_ERR_ARG, "expand_dw: output size mismatch");
@@ -250,8 +250,7 @@ int launch_expand_dw(const float* x, int B, int Cin, int H, int W, const float* 
                                                                                         : expand_dw_kernel<2, 0>;
   // per-(function, device) attribute; set on every launch of a not-yet-seen pair (idempotent, a race sets it twice)
   static std::atomic<unsigned long long> seen[16];
-  int dev = 0;
-  FDT_HIP(hipGetDevice(&dev));
+  if (dev < 0) FDT_HIP(hipGetDevice(&dev));
   const int slot = (stride - 1) * 4 + (ks == 8 ? 0 : ks == 12 ? 1 : ks == 16 ? 2 : 3);
   if (dev < 16 && !((seen[dev].load(std::memory_order_acquire) >> slot) & 1ull)) {
     FDT_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -286,7 +285,7 @@ extern "C" int fdt_expand_dw(const float* x, int B, int Cin, int H, int W, const
   FDT_HIP(hipMemcpy(dwd.p, wdw, (size_t)hid * 36, hipMemcpyHostToDevice));
   FDT_HIP(hipMemcpy(dbd.p, bdw, (size_t)hid * 4, hipMemcpyHostToDevice));
   FDT_TRY(launch_expand_dw(dx.as<float>(), B, Cin, H, W, dw1.as<float>(), db1.as<float>(), dwd.as<float>(),
-                           dbd.as<float>(), hid, stride, dout.as<float>(), Ho, Wo, 0));
+                           dbd.as<float>(), hid, stride, dout.as<float>(), Ho, Wo, 0, -1));
   FDT_HIP(hipDeviceSynchronize());
   FDT_HIP(hipMemcpy(out, dout.p, no * 4, hipMemcpyDeviceToHost));
   return FDT_OK;
@@ -308,11 +307,11 @@ extern "C" int fdt_debug_expand_dw_bench(int B, int Cin, int H, int W, int hid, 
   FDT_HIP(hipEventCreate(&e0)); FDT_HIP(hipEventCreate(&e1));
   for (int i = 0; i < 2; ++i)
     FDT_TRY(launch_expand_dw(dx.as<float>(), B, Cin, H, W, dw1.as<float>(), db1.as<float>(), dwd.as<float>(),
-                             dbd.as<float>(), hid, stride, dout.as<float>(), Ho, Wo, 0));
+                             dbd.as<float>(), hid, stride, dout.as<float>(), Ho, Wo, 0, -1));
   FDT_HIP(hipEventRecord(e0, 0));
   for (int i = 0; i < iters; ++i)
     FDT_TRY(launch_expand_dw(dx.as<float>(), B, Cin, H, W, dw1.as<float>(), db1.as<float>(), dwd.as<float>(),
-                             dbd.as<float>(), hid, stride, dout.as<float>(), Ho, Wo, 0));
+                             dbd.as<float>(), hid, stride, dout.as<float>(), Ho, Wo, 0, -1));
   FDT_HIP(hipEventRecord(e1, 0));
   FDT_HIP(hipEventSynchronize(e1));
   float ms = 0;

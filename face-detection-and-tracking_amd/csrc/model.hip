@@ -1262,7 +1262,7 @@ int run_ops(fdt_model* m, int B, hipStream_t st) {
         const Tensor& in = m->tensors[op.in_t];
         const Tensor& out = m->tensors[op.out_t];
         FDT_TRY(launch_expand_dw(in.d, B, in.C, in.H, in.W, op.w, op.bias, op.w2, op.bias2, op.hid, op.stride, out.d, out.H,
-                                 out.W, st));
+                                 out.W, st, m->device));
         break;
       }
       case OP_HEADFIN: {

@@ -45,7 +45,7 @@ int launch_multibox_finalize(const float* locmap, const float* confmap, long lon
 // + depthwise 3x3 (stride 1|2, pad 1) + BN + ReLU6; BatchNorms folded into (w1 [hid][Cin], b1) and (wdw [hid][9], bdw).
 // The expanded tensor stays in LDS (fused_ir.hip).
 int launch_expand_dw(const float* x, int B, int Cin, int H, int W, const float* w1, const float* b1, const float* wdw,
-                     const float* bdw, int hid, int stride, float* out, int Ho, int Wo, hipStream_t st);
+                     const float* bdw, int hid, int stride, float* out, int Ho, int Wo, hipStream_t st, int device = -1);
 size_t expand_dw_lds_bytes(int Cin, int stride, int hid);
 
 }  // namespace fdt
