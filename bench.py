@@ -194,7 +194,7 @@ def facebox_main(args):
 
 
 KIND_NAMES = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2", "3x3s1_wino", "3x3d2_wino", "1x1s1_k32",
-              "1x1s1_k64", "7x7s2p1"]
+              "1x1s1_k64", "7x7s2p1", "3x3s1_n8"]
 WINO_KINDS = (8, 9)           # conv.h: CONV_3x3_S1_WINO / CONV_3x3_D2_WINO execute 16/36 of the direct MACs
 WINO_RATIO = 2.25
 
@@ -204,6 +204,8 @@ def kernel_label(kind, tile):
     if kind in WINO_KINDS:
         k = "conv_wino4_kernel" if tile in (29, 30) else ("conv_wino2_kernel" if 21 <= tile <= 24 else "conv_wino_kernel")
         return "%s<%s, tile %d>" % (k, KIND_NAMES[kind], tile)
+    if kind == 13:            # conv.h: CONV_3x3_S1_N8, the vector-ALU kernel of the narrow heads (conv_n8.h)
+        return "conv_n8_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
     return "conv_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
 
 

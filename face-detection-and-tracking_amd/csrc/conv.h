@@ -22,6 +22,7 @@ enum ConvKind {
   CONV_1x1_S1_K32,  // CONV_1x1_S1 with 32 / 64 input channels per LDS stage (fewer, longer stages for the
   CONV_1x1_S1_K64,  // small-tile, deep-K layers)
   CONV_7x7_S2_P1,   // pad 1 (stem of pyramid_mb2_try4.py:16: conv_bn with a 7x7 kernel, padding left at 1)
+  CONV_3x3_S1_N8,   // same arithmetic class as CONV_3x3_S1, 8 output channels per workgroup on the packed-f32 VALU (conv_n8.h)
   CONV_KIND_COUNT
 };
 
@@ -63,6 +64,8 @@ enum ConvTile {
   // quarter-split 8-wave Winograd (conv_wino4_kernel): 16x16 px / 8x32 px, 64 ch
   TILE_WINO4_64x64R3,
   TILE_WINO4_64x64W,
+  // packed-f32 VALU kernel for narrow heads (only valid with CONV_3x3_S1_N8): 32x64 px, 8 ch
+  TILE_N8_32x64,
   CONV_TILE_COUNT
 };
 

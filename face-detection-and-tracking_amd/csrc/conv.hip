@@ -106,6 +106,7 @@ struct Table {
     conv_fill_wino(e[CONV_3x3_S1_WINO]);
     conv_fill_wino_d2(e[CONV_3x3_D2_WINO]);
     conv_fill_1x1_s1_deep(e[CONV_1x1_S1_K32], e[CONV_1x1_S1_K64]);
+    conv_fill_n8(e[CONV_3x3_S1_N8]);
   }
 };
 
@@ -118,7 +119,7 @@ const ConvGeom kGeoms[CONV_KIND_COUNT] = {
     {1, 1, 1, 1, 0, 16, 0}, {1, 1, 2, 1, 0, 16, 0}, {3, 3, 1, 1, 1, 4, 0}, {3, 3, 1, 2, 2, 4, 0},
     {3, 3, 2, 1, 1, 4, 0},  {7, 7, 2, 1, 3, 2, 0},  {7, 7, 4, 1, 3, 2, 0}, {5, 5, 2, 1, 2, 2, 0},
     {3, 3, 1, 1, 1, 8, 1},  {3, 3, 1, 2, 2, 8, 1},  {1, 1, 1, 1, 0, 32, 0},  {1, 1, 1, 1, 0, 64, 0},
-    {7, 7, 2, 1, 1, 2, 0},
+    {7, 7, 2, 1, 1, 2, 0},  {3, 3, 1, 1, 1, 1, 0},
 };
 const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum ConvTile)
     {128, 128, 8, 16}, {128, 64, 8, 16}, {128, 32, 8, 16}, {64, 64, 8, 8},   {64, 128, 8, 8},
@@ -132,14 +133,17 @@ const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum 
     // ring of four
     {128, 128, 8, 16}, {128, 64, 8, 16}, {64, 64, 8, 8}, {64, 128, 8, 8},
     // quarter-split Winograd
-    {256, 64, 16, 16}, {256, 64, 8, 32}};
+    {256, 64, 16, 16}, {256, 64, 8, 32},
+    // packed-f32 VALU heads
+    {2048, 8, 32, 64}};
 
 }  // namespace
 
 ConvGeom conv_geom(ConvKind k) { return kGeoms[k]; }
 ConvKind conv_base_kind(ConvKind k) {
   switch (k) {
-    case CONV_3x3_S1_WINO: return CONV_3x3_S1;
+    case CONV_3x3_S1_WINO:
+    case CONV_3x3_S1_N8: return CONV_3x3_S1;
     case CONV_3x3_D2_WINO: return CONV_3x3_S1_D2;
     case CONV_1x1_S1_K32:
     case CONV_1x1_S1_K64: return CONV_1x1_S1;
@@ -163,7 +167,8 @@ void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKin
   const int ktaps = g.kh * g.kw, taps = g.wino ? 16 : ktaps, BN = tile_bn(tile), KC = g.kc;
   const int n_tiles = (Cout + BN - 1) / BN;
   const int nstages = (Cin + KC - 1) / KC;
-  const size_t wszp = ((size_t)KC * taps * BN + 1023) / 1024 * 1024;   // Layout::WSZP
+  // Layout::WSZP (dwordx4 LDS-DMA granularity); the 8-channel VALU kernel stages exactly its 72 weights (N8::WSZ)
+  const size_t wszp = BN == 8 ? (size_t)KC * taps * BN : ((size_t)KC * taps * BN + 1023) / 1024 * 1024;
   out.assign((size_t)n_tiles * nstages * wszp, 0.0f);
   for (int co = 0; co < Cout; ++co) {
     const float sc = scale ? scale[co] : 1.0f;
@@ -230,6 +235,8 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
   if (!table().attr_set[dev][kind][tile].load(std::memory_order_acquire)) {
     FDT_HIP(hipFuncSetAttribute((const void*)ke.fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)ke.lds));
+    if (ke.fn_odd)
+      FDT_HIP(hipFuncSetAttribute((const void*)ke.fn_odd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ke.lds));
     table().attr_set[dev][kind][tile].store(1, std::memory_order_release);
   }
   const int nstages = ceil_div(a.Cin, g.kc);
@@ -250,7 +257,7 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
                                                             : (long long)tiles * n_ct;
   FDT_REQUIRE(gx <= 0x7fffffffll && (long long)a.B * a.ksplit <= 65535, FDT_ERR_ARG, "launch_conv: grid too large");
   dim3 grid((unsigned)gx, 1, a.B * a.ksplit);
-  hipLaunchKernelGGL(ke.fn, grid, dim3(ke.threads), ke.lds, st, a);
+  hipLaunchKernelGGL((ke.fn_odd && (a.Win & 3)) ? ke.fn_odd : ke.fn, grid, dim3(ke.threads), ke.lds, st, a);
   FDT_LAUNCH_CHECK();
   if (a.ws) {
     const long long total = (long long)a.B * a.Cout * a.Hout * a.Wout;
@@ -310,6 +317,7 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
   }
   if (kind == CONV_3x3_S1 && tile_is_wino((ConvTile)tile)) kind = CONV_3x3_S1_WINO;
   if (kind == CONV_3x3_S1_D2 && tile_is_wino((ConvTile)tile)) kind = CONV_3x3_D2_WINO;
+  if (kind == CONV_3x3_S1 && tile == TILE_N8_32x64) kind = CONV_3x3_S1_N8;
   FDT_REQUIRE(tile >= 0 && tile < CONV_TILE_COUNT && conv_supported((ConvKind)kind, (ConvTile)tile), FDT_ERR_ARG,
               "fdt_conv2d: kernel (kind %d, tile %d) not instantiated", kind, tile);
   a.ksplit = ksplit > 0 ? ksplit : 1;

@@ -405,6 +405,7 @@ struct KernelEntry {
   void (*fn)(const ConvArgs);
   size_t lds;
   int threads = 256;
+  void (*fn_odd)(const ConvArgs) = nullptr;   // variant for Win % 4 != 0, where the class has one (conv_n8.h)
 };
 
 //                     TH  TW  BN  WM WN NBUF
@@ -471,6 +472,7 @@ void conv_fill_1x1_s1_deep(void* row_k32, void* row_k64);
 void conv_fill_3x3_s1(void* row);
 void conv_fill_3x3_s1_d2(void* row);
 void conv_fill_3x3_s2(void* row);
+void conv_fill_n8(void* row);   // conv_n8.h
 void conv_fill_stems(void* row_7x7_s2, void* row_7x7_s4, void* row_5x5_s2, void* row_7x7_s2_p1);
 
 }  // namespace fdt

@@ -385,6 +385,14 @@ struct Builder {
       op.tile = (ConvTile)hint->second.tile;
       ksplit = std::max(1, std::min(hint->second.split, ceil_div(in.C, conv_geom(kind).kc)));
       map_mode = hint->second.map;
+    } else if (kind == CONV_3x3_S1 && Ctot <= 8 && (long long)B * Ho * Wo >= 32768) {
+      // narrow loc/conf heads on the large maps: the vector-ALU kernel (conv_n8.h: 70-75 TFLOP/s against the 46 of the
+      // best MFMA variant, which pads 8 output channels to 32), split along K until ~512 workgroups are in the grid
+      kind = CONV_3x3_S1_N8;
+      op.kind = kind;
+      op.tile = TILE_N8_32x64;
+      const long long wgs = (long long)B * ceil_div(Ho, tile_th(op.tile)) * ceil_div(Wo, tile_tw(op.tile));
+      while (wgs * ksplit < 512 && ksplit * 2 <= std::min(32, in.C / 8)) ksplit *= 2;
     } else {
       choose(kind, Ctot, in.C, Ho, Wo, B, o.up_t >= 0, op.tile, ksplit);
     }
@@ -1847,8 +1855,11 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   // the CU's 160 KB), so that the small layers of one frame can share CUs with the big layers of another
   const long long small_lds = getenv("FDT_TUNE_MAX_LDS") ? atoll(getenv("FDT_TUNE_MAX_LDS")) : 0;
   int rc = FDT_OK;
+  // FDT_TUNE_ONLY=<substring>: re-measure only the layers whose name contains it (the others keep their plan entry)
+  const char* only = getenv("FDT_TUNE_ONLY");
   for (auto& op : m->ops) {
     if (op.type != OP_CONV) continue;
+    if (only && *only && op.name.find(only) == std::string::npos) continue;
     struct Cand { int kind, tile, split; float ms; };
     std::vector<Cand> cands;
     long long ws_need = 0;

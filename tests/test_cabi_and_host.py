@@ -164,6 +164,7 @@ def test_bench_host_helpers_and_committed_plans():
     assert bench.kernel_label(8, 30).startswith("conv_wino4_kernel<3x3s1_wino")
     assert bench.kernel_label(9, 22).startswith("conv_wino2_kernel<3x3d2_wino")
     assert bench.kernel_label(0, 12) == "conv_kernel<1x1s1, tile 12>"
+    assert bench.kernel_label(13, 31) == "conv_n8_kernel<3x3s1_n8, tile 31>"
     model, phys, logical = bench.cpu_info()
     assert phys >= 1 and logical >= phys and isinstance(model, str)
     plan_dir = os.path.join(ROOT, "face-detection-and-tracking_amd", "tuned")

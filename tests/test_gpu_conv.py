@@ -15,7 +15,8 @@ KINDS = {  # name: (k, stride, pad, dil)
     "1x1s1": (1, 1, 0, 1), "1x1s2": (1, 2, 0, 1), "3x3s1": (3, 1, 1, 1), "3x3d2": (3, 1, 2, 2),
     "3x3s2": (3, 2, 1, 1), "7x7s2": (7, 2, 3, 1), "7x7s4": (7, 4, 3, 1), "5x5s2": (5, 2, 2, 1),
     "7x7s2p1": (7, 2, 1, 1)}
-N_TILES = 31      # 14 direct + 11 Winograd F(2x2,3x3) (3x3 s1 / d2 only) + 4 ring-of-four (1x1 only) + 2 quarter-split Winograd
+N_TILES = 32      # 14 direct + 11 Winograd F(2x2,3x3) (3x3 s1 / d2 only) + 4 ring-of-four (1x1 only) + 2 quarter-split Winograd
+                  # + 1 packed-f32 VALU tile for narrow heads (3x3 s1 only)
 
 
 def lib():
@@ -136,6 +137,26 @@ def test_winograd_variants(tile, shape):
                 pytest.skip("variant needs more LDS than a CU has")
             assert rc == 0, lib().lib().fdt_last_error()
             assert rel_err(got, exp) < 3e-5, (tile, shape, split, rel_err(got, exp))
+
+
+@pytest.mark.parametrize("shape", [(64, 70, 132, 8), (37, 33, 50, 5), (6, 64, 64, 20), (3, 5, 7, 8)])
+def test_narrow_head_valu_kernel(shape):
+    """conv_n8.h: the loc + conf heads (8 output channels) on v_pk_fma_f32 -- several workgroup tiles, odd sizes, an odd
+    channel count (half-empty last stage), more than one 8-channel tile, residual / ReLU6 and split-K."""
+    Cin, H, W, Cout = shape
+    rng = np.random.default_rng(H * 31 + W)
+    x = rng.standard_normal((2, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((2, Cout, H, W)).astype(np.float32)
+    for kw in (dict(act=0), dict(res=res, act=2)):
+        exp = reference(x, w, b, 3, 1, 1, 1, **kw)
+        for split in (1, 2, 4):
+            rc, got = run_conv(x, w, b, 3, 1, 1, 1, tile=31, split=split, **kw)
+            if rc != 0 and b"bad split-K" in lib().lib().fdt_last_error():
+                continue
+            assert rc == 0, lib().lib().fdt_last_error()
+            assert rel_err(got, exp) < 1e-5, (shape, split, rel_err(got, exp))
 
 
 @pytest.mark.parametrize("variant", [10, 11])      # CONV_1x1_S1_K32 / _K64: 32 / 64 channels per LDS stage

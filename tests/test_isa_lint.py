@@ -17,6 +17,7 @@ CSRC = os.path.join(ROOT, "face-detection-and-tracking_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 SRC = """#include "conv_wino.h"
+#include "conv_n8.h"
 namespace fdt { namespace {
 template __global__ void conv_wino2_kernel<W_64x64W>(const ConvArgs);       // 3x3 pad 1, 8x32-pixel tile
 template __global__ void conv_wino2_kernel<W_128x32R3>(const ConvArgs);     // 32-channel tile (detection heads)
@@ -28,6 +29,8 @@ template __global__ void conv_kernel<G_1x1_S1_K32, T_64x64>(const ConvArgs);
 template __global__ void conv_kernel<G_1x1_S1, T_128x64W>(const ConvArgs);
 template __global__ void conv_kernel<G_3x3_S2, T_128x128>(const ConvArgs);
 template __global__ void conv_kernel<G_7x7_S2, T_128x64>(const ConvArgs);
+// the vector-ALU head kernel (conv_n8.h): 12 window reads + weights one tap ahead; NO scratch traffic may appear in it
+template __global__ void conv_n8_kernel<true>(const ConvArgs);
 } }
 """
 
@@ -49,6 +52,12 @@ def test_async_lds_reads_have_no_hazards(tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert ": 0 hazards" in r.stdout
+    # conv_n8_kernel<true>: a spill reloaded inside its loop would carry a vmcnt(0) that serialises the LDS-DMA pipeline
+    # (measured: no load/compute overlap at all) -- the fast variant must stay spill-free at four waves per SIMD
+    body = text.split("conv_n8_kernelILb1EEEvNS_8ConvArgsE:", 1)[1].split("s_endpgm", 1)[0]
+    assert "scratch_" not in body and body.count("v_pk_fma_f32") == 288
+    meta = text.split(".name:           _ZN3fdt12_GLOBAL__N_114conv_n8_kernelILb1EEEvNS_8ConvArgsE", 1)[1][:1200]
+    assert ".vgpr_spill_count: 0" in meta and int(meta.split(".vgpr_count:")[1].split()[0]) <= 128
 
 
 def test_lint_flags_a_use_before_the_wait(tmp_path):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Lint for the hand-issued LDS reads of the conv kernels: the 8-wave Winograd kernels (conv_wino.h: conv_wino2_kernel,
-conv_wino4_kernel) and the direct implicit-GEMM kernel (conv_kernel.h: conv_kernel).
+conv_wino4_kernel), the direct implicit-GEMM kernel (conv_kernel.h: conv_kernel) and the vector-ALU head kernel (conv_n8.h).
 
 The main loop issues ds_read* through inline asm and waits with `s_waitcnt lgkmcnt(N)`, so the compiler does not
 know those registers are written asynchronously.  This scans gfx950 assembly (hipcc -S --cuda-device-only) and
@@ -29,7 +29,7 @@ def main(path):
         m = re.match(r"^(_Z\S+):", line)
         if m:
             kernel, pending = m.group(1), []
-            in_wino2 = "conv_wino2_kernel" in kernel or "conv_wino4_kernel" in kernel or "11conv_kernelI" in kernel
+            in_wino2 = "conv_wino2_kernel" in kernel or "conv_wino4_kernel" in kernel or "11conv_kernelI" in kernel or "conv_n8_kernel" in kernel
             continue
         if not in_wino2:
             continue

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Re-measure SOME layers of every committed plan (the others keep their entry): after a new kernel variant is added for
+one layer class, e.g. the vector-ALU kernel of the loc/conf heads.
+    python tools/retune_layers.py face_loc            # all plans under tuned/
+    python tools/retune_layers.py face_loc res50_1024x1024_b1.plan ..."""
+import importlib
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    only = sys.argv[1]
+    os.environ["FDT_TUNE_ONLY"] = only
+    tuned = os.path.join(ROOT, "face-detection-and-tracking_amd", "tuned")
+    names = sys.argv[2:] or sorted(f for f in os.listdir(tuned) if f.endswith(".plan"))
+    synth = importlib.import_module("face-detection-and-tracking_amd.synth")
+    layers = importlib.import_module("face-detection-and-tracking_amd.layers")
+    for name in names:
+        m = re.fullmatch(r"(res50|try3)_(\d+)x(\d+)_b(\d+)\.plan", name)
+        arch, W, H, B = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))
+        if arch == "res50":
+            net = importlib.import_module("face-detection-and-tracking_amd.pyramid").SFD()
+            net.priorbox = layers.PriorBoxLayer(W, H)
+        else:
+            net = importlib.import_module("face-detection-and-tracking_amd.pyramid_mb2_try3").SFD_mobile()
+            net.priorbox = layers.PriorBoxLayer(W, H, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256))
+        net.load_state_dict(synth.make_state_dict(arch, 0))
+        frames = synth.make_frames(B, H, W, seed=1234)
+        path = os.path.join(tuned, name)
+        old = open(path).read()
+        net.import_plan(old)
+        net(frames)
+        net.autotune(5)
+        net(frames)
+        new = net.export_plan()
+        changed = [(a, b) for a, b in zip(old.splitlines(), new.splitlines()) if a != b]
+        with open(path, "w") as f:
+            f.write(new)
+        print("%s: %d entries changed" % (name, len(changed)), flush=True)
+        for a, b in changed:
+            print("    %s  ->  %s" % (a, b), flush=True)
+        net.close()
+
+
+if __name__ == "__main__":
+    main()
