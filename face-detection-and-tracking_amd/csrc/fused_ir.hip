@@ -19,6 +19,10 @@
 #include "common.h"
 #include "ops.h"
 
+#ifndef FDT_IR_EXP
+#define FDT_IR_EXP 0   // tuning experiments (tools/experiments/ir_variants.sh): 1 no GEMM, 2 no depthwise phase, 3 no hs writes, 4 no staging
+#endif
+
 namespace fdt {
 namespace {
 
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict_
   {
     const float* zpad = g_ir_zero;
     const int total = Cin * T::NPOSP;
-    for (int e0 = 0; e0 < total; e0 += 256) {
+    for (int e0 = 0; e0 < (FDT_IR_EXP == 4 ? 0 : total); e0 += 256) {
       const int e = e0 + tid;
       const int c = e / T::NPOSP, p = e - c * T::NPOSP;
       const int py = p / T::PWP, px = p - py * T::PWP;
@@ -116,7 +120,8 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict_
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
       const float* acol = ws + half * 32 + l31;
       const float* bcol = xs + wave * 32 + l31 + (size_t)half * T::NPOSP;      // tile t: + t * 128 positions
-      if constexpr (KS > 0) {
+      if constexpr (FDT_IR_EXP == 1) {
+      } else if constexpr (KS > 0) {
         float av[KS], bw[JT][KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict_
         }
         float* hp = hs + 4 * half * T::NPOSP + p;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hp[(size_t)((r & 3) + 8 * (r >> 2)) * T::NPOSP] = vv[r];
+        for (int r = 0; r < (FDT_IR_EXP == 3 ? 1 : 16); ++r) hp[(size_t)((r & 3) + 8 * (r >> 2)) * T::NPOSP] = vv[r];
       }
     }
     __syncthreads();
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict_
     // ---- depthwise 3x3: thread = (channel of the chunk, strip of 4 output columns), all TH rows of the tile
     {
       const int hc = hcd;
-      if (hc < hid) {
+      if (hc < hid && FDT_IR_EXP != 2) {
         const float* hrow = hs + (size_t)cl * T::NPOSP + cg * 4 * S;
         float acc[T::TH][4];
 #pragma unroll

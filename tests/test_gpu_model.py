@@ -359,6 +359,29 @@ def test_try3_1024_batch8_vs_reference_fixture(try3, synth):
     assert np.array_equal(try3(frames).numpy(), y)
 
 
+def test_try3_1024_heads_on_the_vector_alu_kernel_without_a_plan(try3_sd, synth):
+    """Without a tuned plan the builder's own rule puts the 8-channel loc/conf heads of the large maps on the vector-ALU
+    kernel (csrc/conv_n8.h); frame 0 of the batch-8 fixture, run alone, still matches the reference's numbers."""
+    d, meta = load_npz("nets_r2")
+    key = "try3_1024x1024_b8"
+    m = meta[key]
+    frame = synth.make_frames(1, 1024, 1024, seed=m["frame_seeds"][0])[0]
+    net = M("pyramid_mb2_try3").build_sfd_mobile('test', 640, 2)
+    net.load_state_dict(try3_sd)
+    net.priorbox = M("layers").PriorBoxLayer(1024, 1024, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256))
+    net.detect = M("layers").Detect(2, 0, 750, m["conf_t"], m["nms_t"])
+    y = net(frame).numpy()
+    names = [n for n, _, _ in (net.profile(True), net(frame), net.profile_read())[2]]
+    assert any(n.startswith("face_loc.0#k13t31s") for n in names), [n for n in names if n.startswith("face_loc")]
+    exp = d[key + "_out0"]
+    d_iou, d_sc = match_detections(y[0, 1], np.vstack([exp, np.zeros((750 - exp.shape[0], 5), np.float32)]), m["n_out"][0])
+    assert d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL, (d_iou, d_sc)
+    sel = d[key + "_sel"]
+    np.testing.assert_allclose(net.get_tensor("loc")[0, sel], d[key + "_loc_s0"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(net.get_tensor("conf")[0, sel], d[key + "_conf_s0"], atol=SCORE_ATOL, rtol=0)
+    net.close()
+
+
 def test_try3_with_fused_inverted_residual_heads(try3_sd, synth, monkeypatch):
     """The fused expand + depthwise kernel (csrc/fused_ir.hip) normally takes over only on maps of 256^2 and more; forced on
     for every block that fits (FDT_FUSE_IR=1), the try3 stages at a small odd size still match the oracle, and the forced-off

@@ -47,6 +47,12 @@ pmc_one 1x1_1024to256_64x64      $K_A 1024 64 64 256 0        # layer3.x.conv1
 pmc_one 1x1_64to256_256x256_res  $K_B 64 256 256 256 1        # layer1.x.conv3 (+ residual)
 pmc_one 1x1_128to512_128x128_res $K_C 128 128 128 512 1       # layer2.x.conv3 (+ residual)
 echo "conv2_SSH.conv1 $K_WINO | layer3.1.conv1 $K_A | layer1.0.conv3 $K_B | layer2.1.conv3 $K_C" > $OUT/pmc_mfma_kernels.txt
+# the vector-ALU kernel of the 8-channel heads (conv_n8.h): VALU / LDS activity instead of matrix-pipe occupancy
+K_HEAD=$(plan_of face_loc.0)
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
+  -d /tmp/raw -o valu_head --output-format csv -- python tools/one_conv.py $K_HEAD 512 256 256 8 0 8 > $OUT/pmc_valu_head_512to8_256x256_times.txt 2>&1 && \
+  python tools/summarize_pmc.py /tmp/raw/valu_head_counter_collection.csv $OUT/pmc_valu_head_512to8_256x256.csv || echo "head PMC pass failed (counters unavailable)" > $OUT/pmc_valu_head_512to8_256x256.csv
+echo "face_loc.0 $K_HEAD" >> $OUT/pmc_mfma_kernels.txt
 timeout -k 10 300 python tools/profile_layers.py > $OUT/per_layer_hip_events_res50_1024.txt
 timeout -k 10 300 python bench.py --steps 64 --warmup 8 --height 480 --width 640 --cpu-frames 2 > $OUT/bench_line_res50_640x480.json
 timeout -k 10 300 python bench.py --steps 128 --warmup 16 --source 1080x1920 --height 480 --width 640 --cpu-frames 3 --host-frames 128 > $OUT/bench_line_res50_640x480_from_1080p.json
@@ -54,7 +60,7 @@ timeout -k 10 300 python bench.py --steps 32 --warmup 4 --height 1080 --width 19
 timeout -k 10 300 python bench.py --steps 64 --warmup 8 --arch try3 --cpu-frames 3 > $OUT/bench_line_try3_1024.json
 timeout -k 10 300 python bench.py --steps 32 --warmup 4 --arch try3 --batch 8 --cpu-frames 3 > $OUT/bench_line_try3_1024_b8.json
 timeout -k 10 300 python bench.py --arch facebox --batch 16 --steps 100 --warmup 8 > $OUT/bench_line_facebox_4k_b16.json
-timeout -k 10 400 python bench.py --steps 32 --warmup 6 --batch 2 --cpu-frames 0 --autotune 2 --save-plan 1 > $OUT/bench_line_res50_1024_b2.json && cp face-detection-and-tracking_amd/tuned/res50_1024x1024_b2.plan $OUT/
+timeout -k 10 400 python bench.py --steps 32 --warmup 6 --batch 2 --cpu-frames 0 > $OUT/bench_line_res50_1024_b2.json
 timeout -k 10 300 python bench.py --steps 48 --warmup 8 --height 480 --width 640 --batch 4 --cpu-frames 2 > $OUT/bench_line_res50_640x480_b4.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o ktfb --output-format csv -- python bench.py --arch facebox --batch 16 --steps 50 --warmup 5 --cpu-frames 0 > $OUT/bench_facebox_under_rocprof.log 2>&1
 cp /tmp/raw/ktfb_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_facebox_4k_b16.csv
