@@ -255,6 +255,24 @@ class stdout_to_stderr:
         return False
 
 
+def run_with_timeout(fn, seconds):
+    """(finished, result or exception) of fn() run on a daemon thread; (False, None) if it is still running after
+    `seconds` (the thread is left behind: the caller must not wait for it again and should leave through os._exit)."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            box["r"] = fn()
+        except Exception as e:                       # noqa: BLE001 -- handed back to the caller
+            box["r"] = e
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(seconds)
+    return (not t.is_alive()), box.get("r")
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside a launcher: start the N ranks as children (before anything touches the GPU),
     relay rank 0's JSON line and exit with the launcher's code."""
@@ -370,13 +388,35 @@ def main():
     # the one exchange of the path: RCCL all-gather behind the C ABI (fdt_allgather_dets); torch.distributed only ships
     # the 128-byte communicator id and does the barrier / max-over-ranks of the timing
     exch_kind = os.environ.get("FDT_BENCH_EXCHANGE", "rccl-cabi" if backend == "nccl" else "torch")
-    comm, exch_note = None, None
+    comm, exch_note, exch_stuck = None, None, False
     if world > 1 and exch_kind == "rccl-cabi":
-        try:
+        # The communicator is built AND proven with one small all-gather before the timed path relies on it, both under a
+        # watchdog: a collective that never returns (this code path cannot be rehearsed on a one-GPU box) must cost a
+        # fallback to torch.distributed, not the whole scaling run.
+        limit = float(os.environ.get("FDT_BENCH_COMM_TIMEOUT", "120"))
+
+        def build_and_prove():
             with stdout_to_stderr():
-                comm = par.make_rccl_comm(rank, world, local_rank)
-        except Exception as e:                       # noqa: BLE001 -- reported in the JSON line, never silent
-            exch_note = "fdt_comm_init_rank failed on rank %d: %s" % (rank, e)
+                c = par.make_rccl_comm(rank, world, local_rank)
+            probe = par.RcclExchange(rank, world, 64, dev, comm=c)
+            probe.mine.fill_(float(rank))
+            s_ = torch.cuda.Stream(device=dev)
+            probe.exchange(s_.cuda_stream)
+            s_.synchronize()
+            got = probe.gathered[:, 0].cpu().tolist()
+            if got != [float(r) for r in range(world)]:
+                raise RuntimeError("probe all-gather returned %s" % got)
+            return c
+
+        done, res = run_with_timeout(build_and_prove, limit)
+        if not done:
+            exch_stuck = True
+            exch_note = "fdt_comm_init_rank / probe all-gather did not return within %.0f s on rank %d" % (limit, rank)
+        elif isinstance(res, Exception):
+            exch_note = "fdt_comm_init_rank / probe all-gather failed on rank %d: %s" % (rank, res)
+        else:
+            comm = res
+        if exch_note:
             print("bench.py: " + exch_note, file=sys.stderr)
         # every rank must use the same transport for the collective: agree on it
         ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
@@ -681,6 +721,10 @@ def main():
         L.fdt_comm_destroy(comm)
     if world > 1:
         dist.barrier()
+        if exch_stuck:            # a thread is still inside the C-ABI collective: do not run destructors behind it
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 

@@ -165,6 +165,12 @@ def test_bench_host_helpers_and_committed_plans():
     assert bench.kernel_label(9, 22).startswith("conv_wino2_kernel<3x3d2_wino")
     assert bench.kernel_label(0, 12) == "conv_kernel<1x1s1, tile 12>"
     assert bench.kernel_label(13, 31) == "conv_n8_kernel<3x3s1_n8, tile 31>"
+    # the watchdog around the multi-GPU communicator set-up: result, exception and timeout
+    import time
+    assert bench.run_with_timeout(lambda: 7, 5.0) == (True, 7)
+    done, res = bench.run_with_timeout(lambda: (_ for _ in ()).throw(ValueError("x")), 5.0)
+    assert done and isinstance(res, ValueError)
+    assert bench.run_with_timeout(lambda: time.sleep(2.0), 0.1) == (False, None)
     model, phys, logical = bench.cpu_info()
     assert phys >= 1 and logical >= phys and isinstance(model, str)
     plan_dir = os.path.join(ROOT, "face-detection-and-tracking_amd", "tuned")
