@@ -142,6 +142,36 @@ __device__ __forceinline__ void add_upsampled_x2(const float* __restrict__ u, in
   const float ly = sy - (float)y0;
   const float* u0 = u + y0 * up_w;
   const float* u1 = u + y1 * up_w;
+  if (VEC == 4 && (ox0 & 3) == 0) {
+    // Four consecutive output columns 4m .. 4m+3 read source columns 2m-1 .. 2m+2 (clamped) with the fixed weights
+    // (.25,.75) (.75,.25) (.25,.75) (.75,.25): 3 or 4 loads per source row instead of 8.  Same products and sums per
+    // element as the generic form below (at the left edge column 0 has weight 0 on its right neighbour, as there).
+    const int m2 = ox0 >> 1;                                  // 2m
+    const int xl = m2 > 0 ? m2 - 1 : 0;
+    const int xa = m2 < up_w - 1 ? m2 : up_w - 1;             // 2m, clamped (crop: the tile may hang over the map)
+    const int xb = m2 + 1 < up_w - 1 ? m2 + 1 : up_w - 1;
+    const int xr = m2 + 2 < up_w - 1 ? m2 + 2 : up_w - 1;
+    float t0[4], t1[4];
+    t0[0] = u0[xl]; t1[0] = u1[xl];
+    if ((up_w & 1) == 0 && m2 + 1 < up_w) {                   // 8-byte aligned pair (plane and row sizes are even)
+      const float2 p0 = *reinterpret_cast<const float2*>(u0 + m2), p1 = *reinterpret_cast<const float2*>(u1 + m2);
+      t0[1] = p0.x; t0[2] = p0.y; t1[1] = p1.x; t1[2] = p1.y;
+    } else {
+      t0[1] = u0[xa]; t0[2] = u0[xb]; t1[1] = u1[xa]; t1[2] = u1[xb];
+    }
+    t0[3] = u0[xr]; t1[3] = u1[xr];
+    const float l0 = m2 > 0 ? 0.75f : 0.0f;                   // column 0: sx clamps to 0 -> weight 1 on source column 0
+    const int ia[4] = {m2 > 0 ? 0 : 1, 1, 1, 2};
+    const float lx[4] = {l0, 0.25f, 0.75f, 0.25f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      // x1 = x0 + (x0 < up_w - 1): past the last source column both taps are that column (t[] is clamped the same way)
+      const float top = (1.0f - lx[e]) * t0[ia[e]] + lx[e] * t0[ia[e] + 1];
+      const float bot = (1.0f - lx[e]) * t1[ia[e]] + lx[e] * t1[ia[e] + 1];
+      v[e] += (1.0f - ly) * top + ly * bot;
+    }
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
     const float sx = fmaxf(0.5f * (ox0 + e + 0.5f) - 0.5f, 0.0f);
