@@ -43,6 +43,7 @@ def main():
     if a.autotune == 2 or (a.autotune == 1 and not os.path.exists(plan)):
         net.autotune(3)
         net(frames)
+    _, _, per_bytes = net.traffic()      # algorithmic bytes per op (inputs + output once, weights once), profile order
     net.profile(True)
     acc = None
     for r in range(a.reps + 1):
@@ -54,7 +55,8 @@ def main():
         acc = ms if acc is None else acc + ms
     acc /= a.reps
     rows = []
-    for (nm, _, fl), ms in zip(p, acc):
+    by = list(per_bytes) + [0.0] * (len(p) - len(per_bytes))
+    for ((nm, _, fl), ms), nbytes in zip(zip(p, acc), by):
         kt = ""
         if "#k" in nm:
             base, code = nm.split("#k")
@@ -62,17 +64,18 @@ def main():
             t, sp = t.split("s")
             kt = "%s %s /%s" % (KIND[int(k)], TILE[int(t)], sp)
             nm = base
-        rows.append((ms, nm, kt, fl))
+        rows.append((ms, nm, kt, fl, nbytes))
     tot = sum(r[0] for r in rows)
     conv = sum(r[0] for r in rows if r[2])
     fl = sum(r[3] for r in rows if r[2])
     print("total %.3f ms  conv %.3f ms  %.1f GFLOP  conv %.1f TFLOP/s" % (tot, conv, fl / 1e9, fl / conv / 1e9))
-    print("%-28s %-20s %9s %9s %7s" % ("op", "kernel", "ms", "GFLOP", "TF/s"))
-    for ms, nm, kt, f in sorted(rows, reverse=True)[:a.top]:
-        print("%-28s %-20s %9.3f %9.2f %7.1f" % (nm, kt, ms, f / 1e9, f / ms / 1e9 if ms > 0 else 0))
+    print("%-28s %-20s %9s %9s %7s %8s %6s" % ("op", "kernel", "ms", "GFLOP", "TF/s", "MB", "TB/s"))
+    for ms, nm, kt, f, nb in sorted(rows, reverse=True)[:a.top]:
+        print("%-28s %-20s %9.3f %9.2f %7.1f %8.1f %6.2f" % (nm, kt, ms, f / 1e9, f / ms / 1e9 if ms > 0 else 0, nb / 1e6,
+                                                          nb / ms / 1e9 if ms > 0 else 0))
     # aggregate by kernel class
     agg = {}
-    for ms, nm, kt, f in rows:
+    for ms, nm, kt, f, _ in rows:
         k = kt or nm
         a_ = agg.setdefault(k, [0.0, 0.0, 0])
         a_[0] += ms; a_[1] += f; a_[2] += 1
