@@ -156,13 +156,18 @@ __global__ __launch_bounds__(256, 4) void conv_n8_kernel(const ConvArgs a) {
     // register sets; tools/check_async_lds.py lints the ISA for a use of a register whose read is still outstanding.
     const unsigned xaddr = lds0 + (unsigned)(((it & 1) * L::BUF + (2 * ty) * L::PITCH + 4 * tx) * 4);
     const unsigned waddr = lds0 + (unsigned)(((it & 1) * L::BUF + L::XSZ) * 4);
+    // The strip's own 4 pixels are one 16-byte read; its left / right neighbour pixels are the neighbour LANE's outer strip
+    // values (DPP row shift inside the 16 lanes of a tile row) -- only the two halo columns of the tile row come from LDS, as
+    // one dword per lane at an address the 16 lanes share (broadcast, conflict-free).  Per-lane dword reads of columns 4tx+3 /
+    // 4tx+8 would touch only the 16 banks = 3 (mod 4): a 4-way conflict (measured: 38 % of the LDS-active cycles).
+    const unsigned haddr = lds0 + (unsigned)(((it & 1) * L::BUF + (2 * ty) * L::PITCH) * 4);
     float xl[4], xr[4];
     f32x4 xm[4], wa[2], wb[2];
     static_for<0, 4>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
-      lds_read_b32<(r * L::PITCH + 3) * 4>(xl[r], xaddr);
+      lds_read_b32<(r * L::PITCH + 3) * 4>(xl[r], haddr);
       lds_read_b128<(r * L::PITCH + 4) * 4>(xm[r], xaddr);
-      lds_read_b32<(r * L::PITCH + 8) * 4>(xr[r], xaddr);
+      lds_read_b32<(r * L::PITCH + L::TW + 4) * 4>(xr[r], haddr);
     });
     lds_read_b128<0>(wa[0], waddr);
     lds_read_b128<16>(wb[0], waddr);
@@ -181,6 +186,15 @@ __global__ __launch_bounds__(256, 4) void conv_n8_kernel(const ConvArgs a) {
                      : "n"(after));
       else
         asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(wa[set]), "+v"(wb[set]) : "n"(after));
+      if constexpr (t == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // lane 0 / 15 of a row keep the halo word (bound_ctrl off), the others take the neighbour's
+          // (copies first: __builtin_bit_cast of a vector-element lvalue reads element 0 with this compiler)
+          const float last = xm[r][3], first = xm[r][0];
+          xl[r] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(xl[r]), __float_as_int(last), 0x111, 0xf, 0xf, false));
+          xr[r] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(xr[r]), __float_as_int(first), 0x101, 0xf, 0xf, false));
+        }
+      }
       const f32x2 wp[4] = {f32x2{wa[set][0], wa[set][1]}, f32x2{wa[set][2], wa[set][3]}, f32x2{wb[set][0], wb[set][1]},
                            f32x2{wb[set][2], wb[set][3]}};
 #pragma unroll
