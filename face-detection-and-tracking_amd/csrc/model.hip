@@ -1857,6 +1857,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   int rc = FDT_OK;
   // FDT_TUNE_ONLY=<substring>: re-measure only the layers whose name contains it (the others keep their plan entry)
   const char* only = getenv("FDT_TUNE_ONLY");
+  const float split_penalty = getenv("FDT_TUNE_SPLIT_PENALTY") ? (float)atof(getenv("FDT_TUNE_SPLIT_PENALTY")) : 0.0f;
   for (auto& op : m->ops) {
     if (op.type != OP_CONV) continue;
     if (only && *only && op.name.find(only) == std::string::npos) continue;
@@ -1910,8 +1911,10 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
         if (it > 0) best_ms = std::min(best_ms, ms);
       }
       if (rc != FDT_OK) break;
-      c.ms = best_ms;
-      if (best_ms < best.ms) best = c;
+      // Experiment hook FDT_TUNE_SPLIT_PENALTY=p: rank candidates by ms * (1 + p * log2(split)) -- split-K buys isolated latency
+      // with extra partial-sum traffic, which a pipeline that keeps several frames in flight may not want to pay
+      c.ms = best_ms * (1.0f + split_penalty * std::log2((float)c.split));
+      if (c.ms < best.ms) best = c;
     }
     // the workgroup map of the winner (conv.h: rows / XCD-spatial / XCD-channel)
     int best_map = CONV_MAP_ROWS;
