@@ -73,6 +73,24 @@ struct DevBuf {
   }
 };
 
+// Host-blocking copy on an explicit stream.  Nothing in this library may use the legacy (null) stream: while a HIP graph is
+// being captured on ANOTHER host thread (a detector handle recording its forward), ROCm fails legacy-stream work with
+// "operation would make the legacy stream depend on a capturing blocking stream", and distinct handles / the host-pointer
+// entry points must stay usable from distinct host threads (include/fdt.h).
+static inline hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+  return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+// The calling host thread's stream for the host-pointer convenience entry points (fdt_detect, fdt_nms, fdt_conv2d, ...):
+// created on first use, one per thread and device, non-blocking, kept for the life of the thread.
+static inline hipStream_t thread_stream() {
+  thread_local hipStream_t s[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!s[dev] && hipStreamCreateWithFlags(&s[dev], hipStreamNonBlocking) != hipSuccess) s[dev] = nullptr;
+  return s[dev];
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
 

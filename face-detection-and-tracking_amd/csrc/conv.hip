@@ -281,6 +281,7 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
                           const float* bias, int Cout, int ksize, int stride, int pad, int dil,
                           const float* residual, const float* up, int up_h, int up_w, int act, int tile,
                           int ksplit, float* out) {
+  const hipStream_t st = fdt::thread_stream();   // never the legacy stream (common.h)
   using namespace fdt;
   FDT_REQUIRE(x && w_oihw && out && B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, FDT_ERR_ARG,
               "fdt_conv2d: bad argument");
@@ -326,30 +327,30 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
   const size_t n_in = (size_t)B * Cin * H * W, n_out = (size_t)B * Cout * a.Hout * a.Wout;
   DevBuf din, dw, db, dout, dres, dup, dws;
   FDT_TRY(din.alloc(n_in * 4)); FDT_TRY(dw.alloc(tiled.size() * 4)); FDT_TRY(dout.alloc(n_out * 4));
-  FDT_HIP(hipMemcpy(din.p, x, n_in * 4, hipMemcpyHostToDevice));
-  FDT_HIP(hipMemcpy(dw.p, tiled.data(), tiled.size() * 4, hipMemcpyHostToDevice));
+  FDT_HIP(copy_sync(din.p, x, n_in * 4, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(dw.p, tiled.data(), tiled.size() * 4, hipMemcpyHostToDevice, st));
   a.in = din.as<float>(); a.w = dw.as<float>(); a.out = dout.as<float>();
   if (bias) {
     FDT_TRY(db.alloc((size_t)Cout * 4));
-    FDT_HIP(hipMemcpy(db.p, bias, (size_t)Cout * 4, hipMemcpyHostToDevice));
+    FDT_HIP(copy_sync(db.p, bias, (size_t)Cout * 4, hipMemcpyHostToDevice, st));
     a.bias = db.as<float>();
   }
   if (residual) {
     FDT_TRY(dres.alloc(n_out * 4));
-    FDT_HIP(hipMemcpy(dres.p, residual, n_out * 4, hipMemcpyHostToDevice));
+    FDT_HIP(copy_sync(dres.p, residual, n_out * 4, hipMemcpyHostToDevice, st));
     a.res = dres.as<float>();
   }
   if (up) {
     FDT_REQUIRE(up_h >= 1 && up_w >= 1, FDT_ERR_ARG, "fdt_conv2d: bad upsample source size");
     const size_t n_up = (size_t)B * Cout * up_h * up_w;
     FDT_TRY(dup.alloc(n_up * 4));
-    FDT_HIP(hipMemcpy(dup.p, up, n_up * 4, hipMemcpyHostToDevice));
+    FDT_HIP(copy_sync(dup.p, up, n_up * 4, hipMemcpyHostToDevice, st));
     a.up = dup.as<float>(); a.up_h = up_h; a.up_w = up_w;
   }
   if (a.ksplit > 1) { FDT_TRY(dws.alloc((size_t)conv_ws_floats(a) * 4)); a.ws = dws.as<float>(); }
   if (const char* mm = getenv("FDT_CONV_MAP")) a.map_mode = atoi(mm);   // test hook: workgroup map (conv.h CONV_MAP_*)
-  FDT_TRY(launch_conv((ConvKind)kind, (ConvTile)tile, a, 0));
-  FDT_HIP(hipMemcpy(out, dout.p, n_out * 4, hipMemcpyDeviceToHost));
+  FDT_TRY(launch_conv((ConvKind)kind, (ConvTile)tile, a, st));
+  FDT_HIP(copy_sync(out, dout.p, n_out * 4, hipMemcpyDeviceToHost, st));
   return FDT_OK;
 }
 
@@ -358,6 +359,7 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
 // Used by tools/conv_bench.py and tools/autotune.py.
 extern "C" int fdt_debug_conv_bench(int kind, int tile, int ksplit, int B, int Cin, int Hin, int Win,
                                     int Cout, int has_res, int has_up, int act, int iters, float* ms_out) {
+  const hipStream_t st = fdt::thread_stream();   // never the legacy stream (common.h)
   using namespace fdt;
   FDT_REQUIRE(kind >= 0 && kind < CONV_KIND_COUNT && tile >= 0 && tile < CONV_TILE_COUNT && ms_out && iters >= 1,
               FDT_ERR_ARG, "fdt_debug_conv_bench: bad argument");
@@ -379,24 +381,24 @@ extern "C" int fdt_debug_conv_bench(int kind, int tile, int ksplit, int B, int C
   FDT_TRY(dout.alloc(n_out * 4));
   std::vector<float> hin(n_in);
   for (auto& v : hin) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
-  FDT_HIP(hipMemcpy(din.p, hin.data(), n_in * 4, hipMemcpyHostToDevice));
-  FDT_HIP(hipMemcpy(dw.p, tiled.data(), tiled.size() * 4, hipMemcpyHostToDevice));
-  FDT_HIP(hipMemset(db.p, 0, (size_t)Cout * 4));
+  FDT_HIP(copy_sync(din.p, hin.data(), n_in * 4, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(dw.p, tiled.data(), tiled.size() * 4, hipMemcpyHostToDevice, st));
+  FDT_HIP(hipMemsetAsync(db.p, 0, (size_t)Cout * 4, st));
   a.in = din.as<float>(); a.w = dw.as<float>(); a.bias = db.as<float>(); a.out = dout.as<float>();
-  if (has_res) { FDT_TRY(dres.alloc(n_out * 4)); FDT_HIP(hipMemset(dres.p, 0, n_out * 4)); a.res = dres.as<float>(); }
+  if (has_res) { FDT_TRY(dres.alloc(n_out * 4)); FDT_HIP(hipMemsetAsync(dres.p, 0, n_out * 4, st)); a.res = dres.as<float>(); }
   if (has_up) {
     a.up_h = (a.Hout + 1) / 2; a.up_w = (a.Wout + 1) / 2;
     FDT_TRY(dup.alloc((size_t)B * Cout * a.up_h * a.up_w * 4));
-    FDT_HIP(hipMemset(dup.p, 0, (size_t)B * Cout * a.up_h * a.up_w * 4));
+    FDT_HIP(hipMemsetAsync(dup.p, 0, (size_t)B * Cout * a.up_h * a.up_w * 4, st));
     a.up = dup.as<float>();
   }
   if (ksplit > 1) { FDT_TRY(dws.alloc((size_t)conv_ws_floats(a) * 4)); a.ws = dws.as<float>(); }
   hipEvent_t e0, e1;
   FDT_HIP(hipEventCreate(&e0)); FDT_HIP(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) FDT_TRY(launch_conv((ConvKind)kind, (ConvTile)tile, a, 0));
-  FDT_HIP(hipEventRecord(e0, 0));
-  for (int i = 0; i < iters; ++i) FDT_TRY(launch_conv((ConvKind)kind, (ConvTile)tile, a, 0));
-  FDT_HIP(hipEventRecord(e1, 0));
+  for (int i = 0; i < 2; ++i) FDT_TRY(launch_conv((ConvKind)kind, (ConvTile)tile, a, st));
+  FDT_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) FDT_TRY(launch_conv((ConvKind)kind, (ConvTile)tile, a, st));
+  FDT_HIP(hipEventRecord(e1, st));
   FDT_HIP(hipEventSynchronize(e1));
   float ms = 0;
   FDT_HIP(hipEventElapsedTime(&ms, e0, e1));

@@ -276,6 +276,7 @@ int launch_expand_dw(const float* x, int B, int Cin, int H, int W, const float* 
 // (pyramid_mb2_try3.py:96-114).  The parity tests drive this entry point on odd sizes.
 extern "C" int fdt_expand_dw(const float* x, int B, int Cin, int H, int W, const float* w1, const float* b1,
                              const float* wdw, const float* bdw, int hid, int stride, float* out) {
+  const hipStream_t st = fdt::thread_stream();   // never the legacy stream (common.h)
   using namespace fdt;
   FDT_REQUIRE(x && w1 && b1 && wdw && bdw && out && B >= 1 && H >= 1 && W >= 1, FDT_ERR_ARG, "fdt_expand_dw: bad argument");
   FDT_REQUIRE(stride == 1 || stride == 2, FDT_ERR_ARG, "fdt_expand_dw: stride must be 1 or 2");
@@ -284,20 +285,20 @@ extern "C" int fdt_expand_dw(const float* x, int B, int Cin, int H, int W, const
   const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * hid * Ho * Wo;
   FDT_TRY(dx.alloc(nx * 4)); FDT_TRY(dw1.alloc((size_t)hid * Cin * 4)); FDT_TRY(db1.alloc((size_t)hid * 4));
   FDT_TRY(dwd.alloc((size_t)hid * 36)); FDT_TRY(dbd.alloc((size_t)hid * 4)); FDT_TRY(dout.alloc(no * 4));
-  FDT_HIP(hipMemcpy(dx.p, x, nx * 4, hipMemcpyHostToDevice));
-  FDT_HIP(hipMemcpy(dw1.p, w1, (size_t)hid * Cin * 4, hipMemcpyHostToDevice));
-  FDT_HIP(hipMemcpy(db1.p, b1, (size_t)hid * 4, hipMemcpyHostToDevice));
-  FDT_HIP(hipMemcpy(dwd.p, wdw, (size_t)hid * 36, hipMemcpyHostToDevice));
-  FDT_HIP(hipMemcpy(dbd.p, bdw, (size_t)hid * 4, hipMemcpyHostToDevice));
+  FDT_HIP(copy_sync(dx.p, x, nx * 4, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(dw1.p, w1, (size_t)hid * Cin * 4, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(db1.p, b1, (size_t)hid * 4, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(dwd.p, wdw, (size_t)hid * 36, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(dbd.p, bdw, (size_t)hid * 4, hipMemcpyHostToDevice, st));
   FDT_TRY(launch_expand_dw(dx.as<float>(), B, Cin, H, W, dw1.as<float>(), db1.as<float>(), dwd.as<float>(),
-                           dbd.as<float>(), hid, stride, dout.as<float>(), Ho, Wo, 0, -1));
-  FDT_HIP(hipDeviceSynchronize());
-  FDT_HIP(hipMemcpy(out, dout.p, no * 4, hipMemcpyDeviceToHost));
+                           dbd.as<float>(), hid, stride, dout.as<float>(), Ho, Wo, st, -1));
+  FDT_HIP(copy_sync(out, dout.p, no * 4, hipMemcpyDeviceToHost, st));
   return FDT_OK;
 }
 
 // Tuning hook (not part of include/fdt.h): time the fused kernel on zero-filled device buffers with HIP events.
 extern "C" int fdt_debug_expand_dw_bench(int B, int Cin, int H, int W, int hid, int stride, int iters, float* ms_out) {
+  const hipStream_t st = fdt::thread_stream();   // never the legacy stream (common.h)
   using namespace fdt;
   FDT_REQUIRE(ms_out && iters >= 1 && (stride == 1 || stride == 2), FDT_ERR_ARG, "fdt_debug_expand_dw_bench: bad argument");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
@@ -305,19 +306,19 @@ extern "C" int fdt_debug_expand_dw_bench(int B, int Cin, int H, int W, int hid, 
   const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * hid * Ho * Wo;
   FDT_TRY(dx.alloc(nx * 4)); FDT_TRY(dw1.alloc((size_t)hid * Cin * 4)); FDT_TRY(db1.alloc((size_t)hid * 4));
   FDT_TRY(dwd.alloc((size_t)hid * 36)); FDT_TRY(dbd.alloc((size_t)hid * 4)); FDT_TRY(dout.alloc(no * 4));
-  FDT_HIP(hipMemset(dx.p, 0, nx * 4)); FDT_HIP(hipMemset(dw1.p, 0, (size_t)hid * Cin * 4));
-  FDT_HIP(hipMemset(db1.p, 0, (size_t)hid * 4)); FDT_HIP(hipMemset(dwd.p, 0, (size_t)hid * 36));
-  FDT_HIP(hipMemset(dbd.p, 0, (size_t)hid * 4));
+  FDT_HIP(hipMemsetAsync(dx.p, 0, nx * 4, st)); FDT_HIP(hipMemsetAsync(dw1.p, 0, (size_t)hid * Cin * 4, st));
+  FDT_HIP(hipMemsetAsync(db1.p, 0, (size_t)hid * 4, st)); FDT_HIP(hipMemsetAsync(dwd.p, 0, (size_t)hid * 36, st));
+  FDT_HIP(hipMemsetAsync(dbd.p, 0, (size_t)hid * 4, st));
   hipEvent_t e0, e1;
   FDT_HIP(hipEventCreate(&e0)); FDT_HIP(hipEventCreate(&e1));
   for (int i = 0; i < 2; ++i)
     FDT_TRY(launch_expand_dw(dx.as<float>(), B, Cin, H, W, dw1.as<float>(), db1.as<float>(), dwd.as<float>(),
-                             dbd.as<float>(), hid, stride, dout.as<float>(), Ho, Wo, 0, -1));
-  FDT_HIP(hipEventRecord(e0, 0));
+                             dbd.as<float>(), hid, stride, dout.as<float>(), Ho, Wo, st, -1));
+  FDT_HIP(hipEventRecord(e0, st));
   for (int i = 0; i < iters; ++i)
     FDT_TRY(launch_expand_dw(dx.as<float>(), B, Cin, H, W, dw1.as<float>(), db1.as<float>(), dwd.as<float>(),
-                             dbd.as<float>(), hid, stride, dout.as<float>(), Ho, Wo, 0, -1));
-  FDT_HIP(hipEventRecord(e1, 0));
+                             dbd.as<float>(), hid, stride, dout.as<float>(), Ho, Wo, st, -1));
+  FDT_HIP(hipEventRecord(e1, st));
   FDT_HIP(hipEventSynchronize(e1));
   float ms = 0;
   FDT_HIP(hipEventElapsedTime(&ms, e0, e1));

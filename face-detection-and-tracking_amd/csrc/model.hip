@@ -331,9 +331,9 @@ struct Builder {
     tile_weights(hw->second.w.data(), nullptr, hw->second.Cout, hw->second.Cin, kind, tile, tiled);
     DevW d;
     FDT_HIP(hipMalloc((void**)&d.w, tiled.size() * 4));
-    FDT_HIP(hipMemcpy(d.w, tiled.data(), tiled.size() * 4, hipMemcpyHostToDevice));
+    FDT_HIP(copy_sync(d.w, tiled.data(), tiled.size() * 4, hipMemcpyHostToDevice, m->stream));
     FDT_HIP(hipMalloc((void**)&d.bias, (size_t)hw->second.Cout * 4));
-    FDT_HIP(hipMemcpy(d.bias, hw->second.bias.data(), (size_t)hw->second.Cout * 4, hipMemcpyHostToDevice));
+    FDT_HIP(copy_sync(d.bias, hw->second.bias.data(), (size_t)hw->second.Cout * 4, hipMemcpyHostToDevice, m->stream));
     W.wcache[ck] = d;
     out = d;
     return FDT_OK;
@@ -575,8 +575,8 @@ struct Builder {
           set_error("hipMalloc failed for %s", name.c_str());
           return fail(FDT_ERR_HIP);
         }
-        (void)hipMemcpy(d.w, ws.data(), ws.size() * 4, hipMemcpyHostToDevice);
-        (void)hipMemcpy(d.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice);
+        (void)copy_sync(d.w, ws.data(), ws.size() * 4, hipMemcpyHostToDevice, m->stream);
+        (void)copy_sync(d.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice, m->stream);
         m->W->wcache[ck] = d;
       } else {
         d = it->second;
@@ -632,10 +632,10 @@ struct Builder {
           set_error("hipMalloc failed for %s", p.c_str());
           return fail(FDT_ERR_HIP);
         }
-        (void)hipMemcpy(d1.w, a.data(), a.size() * 4, hipMemcpyHostToDevice);
-        (void)hipMemcpy(d1.bias, b1.data(), (size_t)hid * 4, hipMemcpyHostToDevice);
-        (void)hipMemcpy(d2.w, d.data(), d.size() * 4, hipMemcpyHostToDevice);
-        (void)hipMemcpy(d2.bias, b2.data(), (size_t)hid * 4, hipMemcpyHostToDevice);
+        (void)copy_sync(d1.w, a.data(), a.size() * 4, hipMemcpyHostToDevice, m->stream);
+        (void)copy_sync(d1.bias, b1.data(), (size_t)hid * 4, hipMemcpyHostToDevice, m->stream);
+        (void)copy_sync(d2.w, d.data(), d.size() * 4, hipMemcpyHostToDevice, m->stream);
+        (void)copy_sync(d2.bias, b2.data(), (size_t)hid * 4, hipMemcpyHostToDevice, m->stream);
         m->W->wcache[p + "|expdw1"] = d1;
         m->W->wcache[p + "|expdw2"] = d2;
       } else {
@@ -1834,7 +1834,7 @@ extern "C" int fdt_model_get_tensor(fdt_model* m, const char* name, float* out, 
   if (!out) return FDT_OK;
   FDT_REQUIRE(max_elems >= n, FDT_ERR_ARG, "fdt_model_get_tensor: buffer too small (%lld < %lld)", max_elems, n);
   FDT_HIP(hipStreamSynchronize(m->stream));
-  FDT_HIP(hipMemcpy(out, src, (size_t)n * 4, hipMemcpyDeviceToHost));
+  FDT_HIP(copy_sync(out, src, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
   return FDT_OK;
 }
 

@@ -604,6 +604,7 @@ using namespace fdt;
 
 extern "C" int fdt_priorbox(int width, int height, int stride, int box, int n_scales,
                             const double* aspect_ratios, int n_ar, int f_w, int f_h, float* out) {
+  const hipStream_t st = fdt::thread_stream();   // never the legacy stream (common.h)
   FDT_REQUIRE(width > 0 && height > 0 && f_w >= 0 && f_h >= 0 && n_scales >= 0 && n_ar >= 0 && out,
               FDT_ERR_ARG, "fdt_priorbox: bad argument");
   long long total = (long long)f_w * f_h * n_scales * (1 + n_ar);
@@ -612,31 +613,33 @@ extern "C" int fdt_priorbox(int width, int height, int stride, int box, int n_sc
   FDT_TRY(d_out.alloc(total * 16));
   if (n_ar) {
     FDT_TRY(d_ar.alloc(n_ar * 8));
-    FDT_HIP(hipMemcpy(d_ar.p, aspect_ratios, n_ar * 8, hipMemcpyHostToDevice));
+    FDT_HIP(copy_sync(d_ar.p, aspect_ratios, n_ar * 8, hipMemcpyHostToDevice, st));
   }
   FDT_TRY(launch_priorbox(width, height, stride, box, n_scales, d_ar.as<double>(), n_ar, f_w, f_h,
-                          d_out.as<float>(), 0));
-  FDT_HIP(hipMemcpy(out, d_out.p, total * 16, hipMemcpyDeviceToHost));
+                          d_out.as<float>(), st));
+  FDT_HIP(copy_sync(out, d_out.p, total * 16, hipMemcpyDeviceToHost, st));
   return FDT_OK;
 }
 
 extern "C" int fdt_decode(const float* loc, const float* priors, int P, float var0, float var1,
                           float* boxes) {
+  const hipStream_t st = fdt::thread_stream();   // never the legacy stream (common.h)
   FDT_REQUIRE(P >= 0 && loc && priors && boxes, FDT_ERR_ARG, "fdt_decode: bad argument");
   if (P == 0) return FDT_OK;
   DevBuf dl, dp, dbx;
   FDT_TRY(dl.alloc((size_t)P * 16));
   FDT_TRY(dp.alloc((size_t)P * 16));
   FDT_TRY(dbx.alloc((size_t)P * 16));
-  FDT_HIP(hipMemcpy(dl.p, loc, (size_t)P * 16, hipMemcpyHostToDevice));
-  FDT_HIP(hipMemcpy(dp.p, priors, (size_t)P * 16, hipMemcpyHostToDevice));
-  FDT_TRY(launch_decode(dl.as<float>(), dp.as<float>(), P, var0, var1, dbx.as<float>(), 0));
-  FDT_HIP(hipMemcpy(boxes, dbx.p, (size_t)P * 16, hipMemcpyDeviceToHost));
+  FDT_HIP(copy_sync(dl.p, loc, (size_t)P * 16, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(dp.p, priors, (size_t)P * 16, hipMemcpyHostToDevice, st));
+  FDT_TRY(launch_decode(dl.as<float>(), dp.as<float>(), P, var0, var1, dbx.as<float>(), st));
+  FDT_HIP(copy_sync(boxes, dbx.p, (size_t)P * 16, hipMemcpyDeviceToHost, st));
   return FDT_OK;
 }
 
 extern "C" int fdt_nms(const float* boxes, const float* scores, int n, float overlap, int top_k,
                        long long* keep, int* count) {
+  const hipStream_t st = fdt::thread_stream();   // never the legacy stream (common.h)
   FDT_REQUIRE(n >= 0 && keep && count && (n == 0 || (boxes && scores)), FDT_ERR_ARG,
               "fdt_nms: bad argument");
   *count = 0;
@@ -649,12 +652,12 @@ extern "C" int fdt_nms(const float* boxes, const float* scores, int n, float ove
   FDT_TRY(ds.alloc((size_t)n * 4));
   FDT_TRY(dk.alloc((size_t)n * 8));
   FDT_TRY(dc.alloc(4));
-  FDT_HIP(hipMemcpy(db.p, boxes, (size_t)n * 16, hipMemcpyHostToDevice));
-  FDT_HIP(hipMemcpy(ds.p, scores, (size_t)n * 4, hipMemcpyHostToDevice));
+  FDT_HIP(copy_sync(db.p, boxes, (size_t)n * 16, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(ds.p, scores, (size_t)n * 4, hipMemcpyHostToDevice, st));
   FDT_TRY(launch_nms(pl, ws.p, db.as<float>(), ds.as<float>(), overlap, dk.as<long long>(),
-                     dc.as<int>(), 0));
-  FDT_HIP(hipMemcpy(keep, dk.p, (size_t)n * 8, hipMemcpyDeviceToHost));
-  FDT_HIP(hipMemcpy(count, dc.p, 4, hipMemcpyDeviceToHost));
+                     dc.as<int>(), st));
+  FDT_HIP(copy_sync(keep, dk.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  FDT_HIP(copy_sync(count, dc.p, 4, hipMemcpyDeviceToHost, st));
   return FDT_OK;
 }
 
@@ -687,6 +690,7 @@ extern "C" int fdt_detect_dev(const float* loc, const float* conf, const float* 
 extern "C" int fdt_detect(const float* loc, const float* conf, const float* priors, int B, int P,
                           int num_classes, int top_k, float conf_thresh, float nms_thresh,
                           int nms_top_k, float var0, float var1, float* out, int* counts) {
+  const hipStream_t st = fdt::thread_stream();   // never the legacy stream (common.h)
   FDT_TRY(check_detect_args(B, P, num_classes, top_k, nms_thresh, nms_top_k));
   FDT_REQUIRE(loc && conf && priors && out, FDT_ERR_ARG, "fdt_detect: null pointer");
   DetectPlan pl = make_detect_plan(B, P, nms_top_k);
@@ -698,19 +702,20 @@ extern "C" int fdt_detect(const float* loc, const float* conf, const float* prio
   FDT_TRY(dp.alloc((size_t)P * 16));
   FDT_TRY(dout.alloc(n_out * 4));
   FDT_TRY(dcnt.alloc((size_t)B * num_classes * 4));
-  FDT_HIP(hipMemcpy(dl.p, loc, (size_t)B * P * 16, hipMemcpyHostToDevice));
-  FDT_HIP(hipMemcpy(dcf.p, conf, (size_t)B * P * num_classes * 4, hipMemcpyHostToDevice));
-  FDT_HIP(hipMemcpy(dp.p, priors, (size_t)P * 16, hipMemcpyHostToDevice));
+  FDT_HIP(copy_sync(dl.p, loc, (size_t)B * P * 16, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(dcf.p, conf, (size_t)B * P * num_classes * 4, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(dp.p, priors, (size_t)P * 16, hipMemcpyHostToDevice, st));
   FDT_TRY(launch_detect(pl, ws.p, dl.as<float>(), dcf.as<float>(), dp.as<float>(), num_classes,
                         top_k, conf_thresh, nms_thresh, var0, var1, dout.as<float>(),
-                        dcnt.as<int>(), 0));
-  FDT_HIP(hipMemcpy(out, dout.p, n_out * 4, hipMemcpyDeviceToHost));
+                        dcnt.as<int>(), st));
+  FDT_HIP(copy_sync(out, dout.p, n_out * 4, hipMemcpyDeviceToHost, st));
   if (counts)
-    FDT_HIP(hipMemcpy(counts, dcnt.p, (size_t)B * num_classes * 4, hipMemcpyDeviceToHost));
+    FDT_HIP(copy_sync(counts, dcnt.p, (size_t)B * num_classes * 4, hipMemcpyDeviceToHost, st));
   return FDT_OK;
 }
 
 extern "C" int fdt_pairwise_iou(const void* a, int A, const void* b, int B, int dtype, void* out) {
+  const hipStream_t st = fdt::thread_stream();   // never the legacy stream (common.h)
   FDT_REQUIRE(A >= 0 && B >= 0 && (dtype == FDT_F32 || dtype == FDT_F64), FDT_ERR_ARG,
               "fdt_pairwise_iou: bad argument");
   if (A == 0 || B == 0) return FDT_OK;
@@ -720,25 +725,27 @@ extern "C" int fdt_pairwise_iou(const void* a, int A, const void* b, int B, int 
   FDT_TRY(da.alloc((size_t)A * 4 * es));
   FDT_TRY(db.alloc((size_t)B * 4 * es));
   FDT_TRY(dout.alloc((size_t)A * B * es));
-  FDT_HIP(hipMemcpy(da.p, a, (size_t)A * 4 * es, hipMemcpyHostToDevice));
-  FDT_HIP(hipMemcpy(db.p, b, (size_t)B * 4 * es, hipMemcpyHostToDevice));
-  FDT_TRY(launch_pairwise_iou(da.p, A, db.p, B, dtype, dout.p, 0));
-  FDT_HIP(hipMemcpy(out, dout.p, (size_t)A * B * es, hipMemcpyDeviceToHost));
+  FDT_HIP(copy_sync(da.p, a, (size_t)A * 4 * es, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(db.p, b, (size_t)B * 4 * es, hipMemcpyHostToDevice, st));
+  FDT_TRY(launch_pairwise_iou(da.p, A, db.p, B, dtype, dout.p, st));
+  FDT_HIP(copy_sync(out, dout.p, (size_t)A * B * es, hipMemcpyDeviceToHost, st));
   return FDT_OK;
 }
 
 extern "C" int fdt_facebox_anchors(float* out) {
+  const hipStream_t st = fdt::thread_stream();   // never the legacy stream (common.h)
   FDT_REQUIRE(out, FDT_ERR_ARG, "fdt_facebox_anchors: null pointer");
   DevBuf d;
   FDT_TRY(d.alloc(21824 * 16));
-  FDT_TRY(launch_facebox_anchors(d.as<float>(), 0));
-  FDT_HIP(hipMemcpy(out, d.p, 21824 * 16, hipMemcpyDeviceToHost));
+  FDT_TRY(launch_facebox_anchors(d.as<float>(), st));
+  FDT_HIP(copy_sync(out, d.p, 21824 * 16, hipMemcpyDeviceToHost, st));
   return FDT_OK;
 }
 
 extern "C" int fdt_facebox_decode(const float* loc, const float* conf, const float* anchors, int P,
                                   float conf_thresh, float nms_thresh, float* boxes, float* probs,
                                   int* count) {
+  const hipStream_t st = fdt::thread_stream();   // never the legacy stream (common.h)
   FDT_REQUIRE(P >= 1 && loc && conf && anchors && boxes && probs && count, FDT_ERR_ARG,
               "fdt_facebox_decode: bad argument");
   DetectPlan pl = make_detect_plan(1, P, P);
@@ -750,13 +757,13 @@ extern "C" int fdt_facebox_decode(const float* loc, const float* conf, const flo
   FDT_TRY(db.alloc((size_t)P * 16));
   FDT_TRY(dp.alloc((size_t)P * 4));
   FDT_TRY(dn.alloc(4));
-  FDT_HIP(hipMemcpy(dl.p, loc, (size_t)P * 16, hipMemcpyHostToDevice));
-  FDT_HIP(hipMemcpy(dc.p, conf, (size_t)P * 8, hipMemcpyHostToDevice));
-  FDT_HIP(hipMemcpy(da.p, anchors, (size_t)P * 16, hipMemcpyHostToDevice));
+  FDT_HIP(copy_sync(dl.p, loc, (size_t)P * 16, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(dc.p, conf, (size_t)P * 8, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(da.p, anchors, (size_t)P * 16, hipMemcpyHostToDevice, st));
   FDT_TRY(launch_facebox_decode(pl, ws.p, dl.as<float>(), dc.as<float>(), da.as<float>(), conf_thresh,
-                                nms_thresh, db.as<float>(), dp.as<float>(), dn.as<int>(), 0));
-  FDT_HIP(hipMemcpy(count, dn.p, 4, hipMemcpyDeviceToHost));
-  FDT_HIP(hipMemcpy(boxes, db.p, (size_t)P * 16, hipMemcpyDeviceToHost));
-  FDT_HIP(hipMemcpy(probs, dp.p, (size_t)P * 4, hipMemcpyDeviceToHost));
+                                nms_thresh, db.as<float>(), dp.as<float>(), dn.as<int>(), st));
+  FDT_HIP(copy_sync(count, dn.p, 4, hipMemcpyDeviceToHost, st));
+  FDT_HIP(copy_sync(boxes, db.p, (size_t)P * 16, hipMemcpyDeviceToHost, st));
+  FDT_HIP(copy_sync(probs, dp.p, (size_t)P * 4, hipMemcpyDeviceToHost, st));
   return FDT_OK;
 }

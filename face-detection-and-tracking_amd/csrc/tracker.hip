@@ -504,6 +504,14 @@ struct fdt_tracker {
 namespace {
 using fdt::set_error;
 
+// Host-blocking copy / fill on the tracker's own stream, never on the legacy stream: ROCm refuses legacy-stream work while a
+// HIP graph is being captured on another host thread (a detector handle capturing its first forward), and the periodic log
+// flush of a running pipeline can fall exactly there.
+hipError_t copy_sync(fdt_tracker* t, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, t->own_stream);
+  return e != hipSuccess ? e : hipStreamSynchronize(t->own_stream);
+}
+
 int find_live(fdt_tracker* t, int id) {
   for (size_t i = 0; i < t->live_ids.size(); ++i)
     if (t->live_ids[i] == id) return (int)i;
@@ -515,10 +523,10 @@ int flush_log(fdt_tracker* t) {
   hipStream_t st = t->last_stream ? t->last_stream : t->own_stream;
   FDT_HIP(hipStreamSynchronize(st));
   fdt::TrkState hs;
-  FDT_HIP(hipMemcpy(&hs, t->d_state, sizeof(hs), hipMemcpyDeviceToHost));
+  FDT_HIP(copy_sync(t, &hs, t->d_state, sizeof(hs), hipMemcpyDeviceToHost));
   FDT_REQUIRE(!hs.overflow, FDT_ERR_STATE, "fdt_tracker: event log overflow");
   t->h_log.resize((size_t)hs.log_cursor);
-  if (hs.log_cursor) FDT_HIP(hipMemcpy(t->h_log.data(), t->d_log, hs.log_cursor, hipMemcpyDeviceToHost));
+  if (hs.log_cursor) FDT_HIP(copy_sync(t, t->h_log.data(), t->d_log, hs.log_cursor, hipMemcpyDeviceToHost));
   long long off = 0;
   while (off < hs.log_cursor) {
     const int* hdr = (const int*)(t->h_log.data() + off);
@@ -560,8 +568,7 @@ int flush_log(fdt_tracker* t) {
     off += (rec + 7) & ~7ll;
   }
   long long zero = 0;
-  FDT_HIP(hipMemcpy((char*)t->d_state + offsetof(fdt::TrkState, log_cursor), &zero, 8,
-                    hipMemcpyHostToDevice));
+  FDT_HIP(copy_sync(t, (char*)t->d_state + offsetof(fdt::TrkState, log_cursor), &zero, 8, hipMemcpyHostToDevice));
   t->frames_in_log = 0;
   return FDT_OK;
 }
@@ -616,7 +623,8 @@ extern "C" fdt_tracker* fdt_tracker_create(double sigma_iou, double sigma_h, int
             hipMalloc((void**)&t->d_log, t->log_cap) == hipSuccess &&
             hipMalloc((void**)&t->d_dets_in, (size_t)max_dets * 40) == hipSuccess &&
             hipMalloc(&t->d_sets, per_set * 2) == hipSuccess &&
-            hipMemset(t->d_state, 0, sizeof(fdt::TrkState)) == hipSuccess &&
+            hipMemsetAsync(t->d_state, 0, sizeof(fdt::TrkState), t->own_stream) == hipSuccess &&
+            hipStreamSynchronize(t->own_stream) == hipSuccess &&
             hipFuncSetAttribute((const void*)fdt::track_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 max_dets * fdt::TRK_LDS_PER_SLOT) == hipSuccess;
   if (!ok) {
@@ -649,7 +657,8 @@ extern "C" int fdt_tracker_reset(fdt_tracker* t) {
   FDT_REQUIRE(t, FDT_ERR_ARG, "fdt_tracker_reset: null handle");
   hipStream_t st = t->last_stream ? t->last_stream : t->own_stream;
   FDT_HIP(hipStreamSynchronize(st));
-  FDT_HIP(hipMemset(t->d_state, 0, sizeof(fdt::TrkState)));
+  FDT_HIP(hipMemsetAsync(t->d_state, 0, sizeof(fdt::TrkState), t->own_stream));
+  FDT_HIP(hipStreamSynchronize(t->own_stream));
   t->live.clear();
   t->live_ids.clear();
   t->finished.clear();
@@ -700,10 +709,10 @@ extern "C" int fdt_tracker_finish(fdt_tracker* t) {
   FDT_TRY(flush_log(t));
   // iouTracke_cal.py:174-175: surviving active tracks, in active-list order (device order)
   fdt::TrkState hs;
-  FDT_HIP(hipMemcpy(&hs, t->d_state, sizeof(hs), hipMemcpyDeviceToHost));
+  FDT_HIP(copy_sync(t, &hs, t->d_state, sizeof(hs), hipMemcpyDeviceToHost));
   std::vector<int> ids(hs.n_active);
   if (hs.n_active)
-    FDT_HIP(hipMemcpy(ids.data(), t->set[t->cur].id, (size_t)hs.n_active * 4, hipMemcpyDeviceToHost));
+    FDT_HIP(copy_sync(t, ids.data(), t->set[t->cur].id, (size_t)hs.n_active * 4, hipMemcpyDeviceToHost));
   for (int id : ids) {
     int p = find_live(t, id);
     FDT_REQUIRE(p >= 0, FDT_ERR_STATE, "fdt_tracker_finish: active track %d missing on host", id);

@@ -66,6 +66,61 @@ def test_clone_shares_weights_and_matches(res50, synth):
     assert np.array_equal(y0, y2)
 
 
+def test_distinct_handles_on_distinct_host_threads(res50, res50_sd, synth):
+    """include/fdt.h: a handle is not thread-safe, but DISTINCT handles may be driven from distinct host threads at the same
+    time (SURVEY.md 8(b) Threading) -- two clones sharing one weight copy plus one independent model, each on its own
+    thread, first forwards (plan, weight upload, graph capture) racing each other; every result equals the one the same
+    handle gives single-threaded, and fdt_last_error is per thread."""
+    import threading
+    L = M("_lib")
+    H, W = 128, 160
+    PB, Det = M("layers").PriorBoxLayer, M("layers").Detect
+    res50.priorbox = PB(W, H); res50.firstTime = True
+    res50.detect = Det(2, 0, 750, 0.05, 0.35)
+    frames = [synth.make_frames(6, H, W, seed=40 + t) for t in range(3)]
+    res50(frames[0][0])                                   # the parent must have run before it can be cloned
+    want = [[res50(f).numpy().copy() for f in fr] for fr in frames]       # same weights for all three handles
+    other = M("pyramid").build_sfd('test', 640, 2)
+    other.load_state_dict(res50_sd)
+    other.priorbox = PB(W, H); other.detect = Det(2, 0, 750, 0.05, 0.35)
+    nets = [res50.clone(), res50.clone(), other]           # none of them has run a forward yet
+    got, errs, msgs = [None] * 3, [], [None] * 3
+    start = threading.Barrier(3)
+
+    def work(t):
+        try:
+            start.wait()
+            outs = []
+            for rep in range(3):                           # eager first pass, then graph replays
+                outs = [nets[t](f).numpy().copy() for f in frames[t]]
+                if t == 2:                                 # a host-pointer entry point between the forwards: it must not
+                    a = np.array([[0, 0, 2, 2], [1, 1, 3, 3]], np.float64)    # touch the legacy stream while the other
+                    iou = np.empty((2, 2), np.float64)                          # threads capture their graphs
+                    L.check(L.lib().fdt_pairwise_iou(L.ptr(a), 2, L.ptr(a), 2, 1, L.ptr(iou)))   # 1 = FDT_F64
+                    assert iou[0, 0] == 1.0 and iou[0, 1] == 1.0 / 7.0
+            got[t] = outs
+            if t == 1:                                     # this thread fails a call; the others must not see its message
+                rc = L.lib().fdt_priorbox(0, 0, 0, 0, 0, None, 0, 0, 0, None)
+                assert rc != 0
+            start.wait()
+            msgs[t] = L.lib().fdt_last_error() or b""
+        except Exception as e:                             # noqa: BLE001 -- re-raised on the main thread
+            errs.append((t, e))
+            start.abort()
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(120)
+    assert not errs, errs
+    for t in range(3):
+        assert got[t] is not None and all(np.array_equal(a, b) for a, b in zip(got[t], want[t])), t
+    assert msgs[1] and not msgs[0] and not msgs[2], msgs
+    for n in nets:
+        n.close()
+
+
 def test_graph_replay_equals_eager(res50, synth):
     H, W = 136, 200
     res50.priorbox = M("layers").PriorBoxLayer(W, H); res50.firstTime = True
