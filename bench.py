@@ -455,6 +455,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # initialisation, not a step: plan construction, weight tiling and HIP-graph capture of every in-flight handle happen
+    # here (the compile step of this runtime), so that the W warm-up and K timed steps are steady-state steps whatever W is
+    pipe.prime(frames_of(0))
     for i in range(args.warmup):
         pipe.step(i, frames_of(i))
     sync_all()
@@ -703,6 +706,7 @@ def main():
                                                   B),
                        "frames_per_step": world * B, "frames_in_flight_per_gpu": NF, "kernel_plan": plan_src,
                        "hip_graph": bool(args.graph), "weight_copies_per_gpu": 1,
+                       "primed": "plan + HIP-graph capture of every in-flight handle before the warm-up steps (initialisation)",
                        "parallelism": "frame-parallel x%d%s" % (
                            world, (", all-gather of box lists: " + ("RCCL via fdt_allgather_dets (C ABI)" if comm is not None
                                                                     else "torch.distributed " + backend)) if world > 1 else ""),

@@ -52,6 +52,31 @@ class DetectTrackPipeline:
         self.trk_done = [torch.cuda.Event() for _ in range(self.NF)]
         self._L = _lib.lib()
 
+    def _forward(self, k, frames_dev):
+        """The forward of slot k as step() enqueues it (same handle, record, counts and stream: the HIP graph a handle
+        captures is keyed by exactly these)."""
+        L, fp, net = self._L, self.fps[k], self.nets[k]
+        if self.source_hw:
+            _lib.check(L.fdt_model_forward_resized(net._h, ctypes.c_void_p(frames_dev.data_ptr()), 1, self.B,
+                                                   self.source_hw[0], self.source_hw[1], self.H, self.W,
+                                                   ctypes.c_void_p(fp.mine.data_ptr()),
+                                                   ctypes.c_void_p(self.counts[k].data_ptr()), self.sp_det[k]))
+        else:
+            _lib.check(L.fdt_model_forward_dev(net._h, ctypes.c_void_p(frames_dev.data_ptr()),
+                                               _lib.FRAME_U8_HWC_BGR, self.B, self.H, self.W,
+                                               ctypes.c_void_p(fp.mine.data_ptr()),
+                                               ctypes.c_void_p(self.counts[k].data_ptr()), self.sp_det[k]))
+
+    def prime(self, frames_dev):
+        """One-time initialisation, the equivalent of a compile step: every slot runs its forward twice on `frames_dev`
+        (the first builds the plan and uploads the tiled weights, the second is captured into the slot's HIP graph), so that
+        no step() -- warm-up or timed -- pays for plan construction or graph capture.  The tracker is not fed."""
+        for k in range(self.NF):
+            with torch.cuda.stream(self.det_streams[k]):
+                self._forward(k, frames_dev)
+                self._forward(k, frames_dev)
+        torch.cuda.synchronize(self.dev)
+
     def step(self, i, frames_dev):
         """Enqueue step i: `frames_dev` = torch uint8 tensor [B, h, w, 3] on the device (raw source frames when
         `source_hw` is set: they are resized on the GPU inside the step, iouTracke_cal.py:123)."""
@@ -60,16 +85,7 @@ class DetectTrackPipeline:
         st = self.det_streams[k]
         with torch.cuda.stream(st):
             st.wait_event(self.trk_done[k])             # slot k's record was consumed (step i - inflight)
-            if self.source_hw:
-                _lib.check(L.fdt_model_forward_resized(net._h, ctypes.c_void_p(frames_dev.data_ptr()), 1, self.B,
-                                                       self.source_hw[0], self.source_hw[1], self.H, self.W,
-                                                       ctypes.c_void_p(fp.mine.data_ptr()),
-                                                       ctypes.c_void_p(self.counts[k].data_ptr()), self.sp_det[k]))
-            else:
-                _lib.check(L.fdt_model_forward_dev(net._h, ctypes.c_void_p(frames_dev.data_ptr()),
-                                                   _lib.FRAME_U8_HWC_BGR, self.B, self.H, self.W,
-                                                   ctypes.c_void_p(fp.mine.data_ptr()),
-                                                   ctypes.c_void_p(self.counts[k].data_ptr()), self.sp_det[k]))
+            self._forward(k, frames_dev)
             self.det_done[k].record(st)
         with torch.cuda.stream(self.trk_stream):
             self.trk_stream.wait_event(self.det_done[k])
