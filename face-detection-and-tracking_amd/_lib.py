@@ -91,6 +91,7 @@ SIGNATURES = {
     "fdt_model_forward_async": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _c_int_p]),
     "fdt_model_async_record": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _vp]),
     "fdt_model_wait": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "fdt_model_release": (C.c_int, [_vp, C.c_int, _vp]),
     "fdt_model_forward_raw": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "fdt_model_detect_facebox": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                            _vp, _vp, _vp]),

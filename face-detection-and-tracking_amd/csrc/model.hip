@@ -100,7 +100,7 @@ struct GraphKey {   // everything a captured forward bakes in besides the plan i
 };
 
 // One ticket of the pipelined host ingest (fdt_model_forward_async): pinned staging for the frame(s) and the Detect
-// record, the device-side copies, and the events that order copy stream -> compute stream -> consumer.
+// record, the device-side copies, and the events that tell the host / a consumer stream how far the ticket has got.
 struct AsyncSlot {
   void* h_in = nullptr;
   void* d_in = nullptr;
@@ -110,6 +110,7 @@ struct AsyncSlot {
   size_t out_floats = 0, n_counts = 0;
   hipEvent_t copied = nullptr, fwd = nullptr, done = nullptr, consumed = nullptr;
   bool busy = false, consumed_pending = false;
+  bool released = false;   // retired by fdt_model_release: its forward may still be running when the slot is issued again
   int ticket = -1;
   void release() {
     if (h_in) (void)hipHostFree(h_in);
@@ -128,7 +129,6 @@ constexpr int kAsyncSlots = 2;
 struct fdt_model {
   int arch = 0, device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t copy_stream = nullptr;   // H2D of the async ingest, created on first use
   AsyncSlot slots[kAsyncSlots];
   int next_ticket = 0;
   std::shared_ptr<WeightStore> W = std::make_shared<WeightStore>();
@@ -179,7 +179,6 @@ struct fdt_model {
     for (auto e : ev) (void)hipEventDestroy(e);
     if (d_src_u8) (void)hipFree(d_src_u8);
     for (auto& sl : slots) sl.release();
-    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (stream) (void)hipStreamDestroy(stream);
   }
   void drop_graphs() {
@@ -1665,9 +1664,9 @@ extern "C" int fdt_model_forward_dev(fdt_model* m, const void* frames_dev, int f
 
 // ---------------------------------------------------------------------------------- pipelined host ingest
 // iouTracke_cal.py:119-124 hands the detector host arrays (cv2 frames).  forward_async copies the caller's pageable
-// buffer into a pinned slot (the caller may reuse its buffer at once), enqueues H2D on the handle's copy stream, the
-// forward on its compute stream and the D2H of the Detect record, and returns a ticket.  Two tickets per handle may be
-// in flight: the copy of frame n+1 overlaps the forward of frame n.
+// buffer into a pinned slot (the caller may reuse its buffer at once), enqueues the H2D, the forward and the D2H of the
+// Detect record on the handle's stream, and returns a ticket.  Two tickets per handle may be in flight; the copy overlaps
+// the forwards of the OTHER handles in flight.
 extern "C" int fdt_model_forward_async(fdt_model* m, const void* frames, int format, int B, int H, int W, int src_h,
                                        int src_w, int* ticket) {
   FDT_REQUIRE(m && frames && ticket, FDT_ERR_ARG, "fdt_model_forward_async: null argument");
@@ -1680,7 +1679,6 @@ extern "C" int fdt_model_forward_async(fdt_model* m, const void* frames, int for
   AsyncSlot& s = m->slots[m->next_ticket % kAsyncSlots];
   FDT_REQUIRE(!s.busy, FDT_ERR_STATE, "fdt_model_forward_async: ticket %d is still in flight; fdt_model_wait it first",
               s.ticket);
-  if (!m->copy_stream) FDT_HIP(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
   if (!s.copied) {
     for (hipEvent_t* e : {&s.copied, &s.fwd, &s.done, &s.consumed})
       FDT_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -1705,10 +1703,21 @@ extern "C" int fdt_model_forward_async(fdt_model* m, const void* frames, int for
     s.out_floats = out_floats;
     s.n_counts = n_counts;
   }
+  if (s.released) {
+    // the ticket this slot carried last was retired without a host wait (fdt_model_release): its forward may still be
+    // queued, and its H2D sits behind the forward before it on the same stream -- the pinned buffer is free once that copy
+    // has run (the device buffer is protected by stream order)
+    FDT_HIP(hipEventSynchronize(s.copied));
+    s.released = false;
+  }
   memcpy(s.h_in, frames, in_bytes);
-  FDT_HIP(hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, m->copy_stream));
-  FDT_HIP(hipEventRecord(s.copied, m->copy_stream));
-  FDT_HIP(hipStreamWaitEvent(m->stream, s.copied, 0));
+  // The copy goes on the COMPUTE stream, in front of its forward.  A separate copy stream can be mapped onto the hardware
+  // queue of ANOTHER handle's compute stream (streams share GPU_MAX_HW_QUEUES = 4 queues): its packets then wait behind a
+  // whole forward of that handle, and the forward that needs the copy with them -- measured as a GPU 10 % slower than the
+  // device-resident pipeline whatever the host did (tools/experiments/host_path_breakdown.py).  With two or more handles
+  // in flight the 3 MB copy overlaps the other handles' forwards anyway.
+  FDT_HIP(hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, m->stream));
+  FDT_HIP(hipEventRecord(s.copied, m->stream));
   if (s.consumed_pending) {            // the last consumer of this slot's device record (e.g. the tracker)
     FDT_HIP(hipStreamWaitEvent(m->stream, s.consumed, 0));
     s.consumed_pending = false;
@@ -1758,6 +1767,23 @@ extern "C" int fdt_model_wait(fdt_model* m, int ticket, float* out, int* counts,
   if (out) memcpy(out, s->h_out, s->out_floats * 4);
   if (counts) memcpy(counts, s->h_counts, s->n_counts * 4);
   s->busy = false;
+  return FDT_OK;
+}
+
+// Retirement WITHOUT a host wait, for callers that consume the record on the device only (fdt_model_async_record +
+// fdt_tracker_step_dev): nothing is copied back to the caller and the host does not block on the forward, so it can keep
+// every handle's queue full; the slot's next forward_async is ordered on the device behind this ticket's forward and
+// behind whatever `consumer_stream` holds now.  A host that waited for every frame (fdt_model_wait) left the GPU 10 %
+// slower than the device-resident pipeline (tools/experiments/host_path_breakdown.py).
+extern "C" int fdt_model_release(fdt_model* m, int ticket, void* consumer_stream) {
+  AsyncSlot* s = find_ticket(m, ticket);
+  FDT_REQUIRE(s, FDT_ERR_ARG, "fdt_model_release: ticket %d is not in flight", ticket);
+  if (consumer_stream) {
+    FDT_HIP(hipEventRecord(s->consumed, (hipStream_t)consumer_stream));
+    s->consumed_pending = true;
+  }
+  s->busy = false;
+  s->released = true;
   return FDT_OK;
 }
 

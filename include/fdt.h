@@ -194,18 +194,20 @@ int fdt_model_forward_dev(fdt_model* m, const void* frames_dev, int format, int 
 int fdt_model_forward_resized(fdt_model* m, const void* frames, int frames_on_device, int B, int src_h,
                               int src_w, int H, int W, float* out, int* counts, void* stream);
 /* Pipelined host ingest (iouTracke_cal.py:119-124: frames reach the detector as host arrays).  forward_async copies the
- * caller's (pageable) frames into a pinned slot -- the caller may reuse its buffer at once --, enqueues the H2D copy on
- * the handle's copy stream, the forward (+ the device-side resize when src_h x src_w differs from H x W; 0 = none) on
- * its compute stream and the D2H of the Detect record, and returns a ticket without waiting.  Two tickets per handle
- * may be in flight (the copy of frame n+1 overlaps the forward of frame n); more frames in flight = more
- * fdt_model_clone handles.  fdt_model_wait blocks until the ticket's record [B,2,top_k,5] / counts [B,2] are on the
- * host (out / counts may be NULL) and frees the slot.  fdt_model_async_record hands the record over ON THE DEVICE:
- * consumer_stream waits for the forward, *record_dev stays valid until fdt_model_wait, whose consumer_stream argument
- * (may be NULL) orders what was enqueued there before the slot's next forward.                                       */
+ * caller's (pageable) frames into a pinned slot -- the caller may reuse its buffer at once --, enqueues the H2D copy, the
+ * forward (+ the device-side resize when src_h x src_w differs from H x W; 0 = none) and the D2H of the Detect record
+ * on the handle's stream and returns a ticket without waiting.  Two tickets per handle may be in flight; more frames in
+ * flight = more fdt_model_clone handles (whose forwards the copy then overlaps).  fdt_model_wait blocks until the
+ * ticket's record [B,2,top_k,5] / counts [B,2] are on the host (out / counts may be NULL) and frees the slot.
+ * fdt_model_async_record hands the record over ON THE DEVICE: consumer_stream waits for the forward, *record_dev stays
+ * valid until the ticket is retired; the consumer_stream argument of fdt_model_wait / fdt_model_release (may be NULL)
+ * orders what was enqueued there before the slot's next forward.  fdt_model_release retires a ticket WITHOUT a host
+ * wait and without copying anything back (device-side consumers only).                                                */
 int fdt_model_forward_async(fdt_model* m, const void* frames, int format, int B, int H, int W, int src_h, int src_w,
                             int* ticket);
 int fdt_model_async_record(fdt_model* m, int ticket, float** record_dev, void* consumer_stream);
 int fdt_model_wait(fdt_model* m, int ticket, float* out, int* counts, void* consumer_stream);
+int fdt_model_release(fdt_model* m, int ticket, void* consumer_stream);
 /* Network output without Detect: loc [B,P,4], conf [B,P,2].  PyramidBox: conf is softmaxed
  * (pyramid.py:332).  FaceBox.forward (FACEBOX/networks.py:87-116): conf is the raw conf_preds.       */
 int fdt_model_forward_raw(fdt_model* m, const void* frames, int format, int B, int H, int W,

@@ -133,6 +133,7 @@ def test_round2_entry_points_validate_arguments_without_a_gpu():
     assert L.fdt_model_forward_async(None, None, 0, 1, 8, 8, 0, 0, ctypes.byref(t)) == lib.FDT_ERR_ARG
     assert L.fdt_model_wait(None, 0, None, None, None) == lib.FDT_ERR_ARG
     assert L.fdt_model_async_record(None, 0, None, None) == lib.FDT_ERR_ARG
+    assert L.fdt_model_release(None, 0, None) == lib.FDT_ERR_ARG
     assert L.fdt_comm_unique_id(None) == lib.FDT_ERR_ARG
     assert not L.fdt_comm_init_rank(0, 0, None, 0) and b"fdt_comm_init_rank" in L.fdt_last_error()
     assert not L.fdt_comm_init_all(0, None)

@@ -323,6 +323,56 @@ def test_async_host_ingest_matches_sync(res50, synth):
     trk.close()
 
 
+def test_async_ingest_release_without_host_wait(res50, synth):
+    """fdt_model_release: tickets retired with no host wait (the record is consumed on the device by the tracker only); the
+    host runs ahead of the GPU, slots are re-issued while their previous forward may still be queued, and the tracks still
+    equal the oracle's on the synchronous records.  Two handles, so four tickets are in flight."""
+    L = M("_lib")
+    lib = L.lib()
+    H, W, N = 128, 160, 40
+    res50.priorbox = M("layers").PriorBoxLayer(W, H); res50.firstTime = True
+    res50.detect = M("layers").Detect(2, 0, 750, 0.05, 0.35)
+    frames = moving_frames(synth, N, H, W, seed=11)
+    seq = [res50(f).numpy() for f in frames]
+    ref = opp.IouTracker(0.4, 0.6, 3)
+    for y in seq:
+        with np.errstate(all="ignore"):
+            ref.step(opp.unpack_detections(y, W, H, 0.4))
+    nets = [res50, res50.clone()]
+    trk = M("tracker").IouTracker(0.4, 0.6, 3, max_dets=1500, log_frames=64)
+    st = torch.cuda.Stream()
+    sp = ctypes.c_void_p(st.cuda_stream)
+    pending = []
+
+    def retire():
+        k, t = pending.pop(0)
+        rec = ctypes.c_void_p(0)
+        L.check(lib.fdt_model_async_record(nets[k]._h, t, ctypes.byref(rec), sp))
+        trk.step_dev(rec, 2, 750, W, H, 0.4, sp)
+        L.check(lib.fdt_model_release(nets[k]._h, t, sp))
+
+    for i in range(N):
+        if len(pending) == 4:
+            retire()
+        t = ctypes.c_int(-1)
+        buf = frames[i].copy()
+        L.check(lib.fdt_model_forward_async(nets[i % 2]._h, L.ptr(buf), L.FRAME_U8_HWC_BGR, 1, H, W, 0, 0, ctypes.byref(t)))
+        buf[:] = 0
+        pending.append((i % 2, t.value))
+    while pending:
+        retire()
+    assert tracks_key(trk.finish()) == tracks_key(ref.finish())
+    assert lib.fdt_model_release(res50._h, 0, None) == L.FDT_ERR_ARG                 # already retired
+    # a released slot can be waited on again after its next use (mixing the two retirements is allowed)
+    t = ctypes.c_int(-1)
+    L.check(lib.fdt_model_forward_async(res50._h, L.ptr(frames[0]), L.FRAME_U8_HWC_BGR, 1, H, W, 0, 0, ctypes.byref(t)))
+    out = np.empty((1, 2, 750, 5), np.float32)
+    L.check(lib.fdt_model_wait(res50._h, t.value, L.ptr(out), None, None))
+    assert np.array_equal(out, seq[0])
+    trk.close()
+    nets[1].close()
+
+
 def test_async_ingest_with_device_resize(res50, synth):
     L = M("_lib")
     lib = L.lib()
