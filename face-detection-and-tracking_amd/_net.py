@@ -162,6 +162,8 @@ class DetectorNet:
         raw BGR frames (mean subtraction then happens on the GPU)."""
         if not self._loaded:
             raise RuntimeError("weights not loaded: call load_state_dict / load_weights first")
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            return self._call_device(x)
         x, fmt, B, H, W = self._prepare(x)
         self._sync_attributes(H, W)
         out = np.empty((B, 2, self.detect.top_k, 5), dtype=np.float32)
@@ -171,6 +173,32 @@ class DetectorNet:
         self.last_counts = counts
         self.priors = torch.from_numpy(self.get_tensor("priors")[0])
         return torch.from_numpy(out)
+
+    def _call_device(self, x):
+        """`net(x.cuda())` as the reference writes it (iouTracke_cal.py:49-50, My_test.py:37-39): the frames already live in
+        HBM, so they are consumed there (fdt_model_forward_dev on the handle's stream) instead of bouncing through the host.
+        Returns the same CPU tensor as the host path (detection.py:48 creates the output on the default device)."""
+        x = x.detach()
+        if x.dtype == torch.uint8:
+            if x.dim() == 3:
+                x = x[None]
+            x = x.contiguous()
+            fmt, (B, H, W, _) = _lib.FRAME_U8_HWC_BGR, x.shape
+        else:
+            x = x.to(torch.float32).contiguous()
+            fmt, (B, _, H, W) = _lib.FRAME_F32_NCHW, x.shape
+        if x.device.index not in (None, self._device):
+            raise ValueError("input is on cuda:%s but the model was built for cuda:%d" % (x.device.index, self._device))
+        self._sync_attributes(H, W)
+        out = torch.empty((B, 2, self.detect.top_k, 5), dtype=torch.float32, device=x.device)
+        counts = torch.zeros((B, 2), dtype=torch.int32, device=x.device)
+        torch.cuda.current_stream(x.device).synchronize()       # x is complete; the forward runs on the handle's own stream
+        _lib.check(_lib.lib().fdt_model_forward_dev(self._h, C.c_void_p(x.data_ptr()), fmt, B, H, W,
+                                                    C.c_void_p(out.data_ptr()), C.c_void_p(counts.data_ptr()), None))
+        torch.cuda.synchronize(x.device)
+        self.last_counts = counts.cpu().numpy()
+        self.priors = torch.from_numpy(self.get_tensor("priors")[0])
+        return out.cpu()
 
     forward = __call__
 

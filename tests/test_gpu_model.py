@@ -6,6 +6,7 @@ import importlib
 
 import numpy as np
 import pytest
+import torch
 
 from conftest import load_npz
 from oracle import postproc as opp
@@ -120,6 +121,23 @@ def test_res50_batch2_equals_two_singles(res50, synth):
         assert n > 5
         d_iou, d_sc = match_detections(got, exp, n)
         assert d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
+
+
+def test_cuda_tensor_inputs_equal_host_inputs(res50, synth):
+    """`net(x.cuda())` as the reference writes it (iouTracke_cal.py:49-50): f32 NCHW and u8 HWC tensors that already live on
+    the GPU are consumed there and give the bits of the host-array call."""
+    H, W = 128, 160
+    res50.priorbox = M("layers").PriorBoxLayer(W, H); res50.firstTime = True
+    res50.detect = M("layers").Detect(2, 0, 750, 0.05, 0.35)
+    frames = synth.make_frames(2, H, W, seed=21)
+    x = np.stack([opb.preprocess(f)[0] for f in frames])              # [2,3,H,W] f32, mean-subtracted BGR
+    want_f32, want_u8 = res50(x).numpy(), res50(frames).numpy()
+    dev = torch.device("cuda", 0)
+    assert np.array_equal(res50(torch.from_numpy(x).to(dev)).numpy(), want_f32)
+    assert np.array_equal(res50(torch.from_numpy(frames).to(dev)).numpy(), want_u8)
+    assert np.array_equal(res50(torch.from_numpy(x)).numpy(), want_f32)                     # CPU tensor
+    y = res50(torch.from_numpy(x[:1]).to(dev).double())                                     # converted like the host path
+    assert np.array_equal(y.numpy(), res50(x[:1]).numpy()) and not y.is_cuda and res50.last_counts.shape == (1, 2)
 
 
 def test_load_state_dict_strictness(res50_sd):
