@@ -22,6 +22,10 @@
 #pragma once
 #include "conv_kernel.h"
 
+#ifndef FDT_N8_EXP
+#define FDT_N8_EXP 0   // tuning experiments (tools/experiments/n8_variants.sh): 1 no LDS-DMA after the first stages, 2 one tap of nine
+#endif
+
 namespace fdt {
 namespace {
 
@@ -140,9 +144,6 @@ __global__ __launch_bounds__(256, 4) void conv_n8_kernel(const ConvArgs a) {
     // the buffer stage it + 1 overwrites was last read by THIS wave in iteration it - 1: those reads have returned (their
     // values fed FMAs that precede this point in program order)
     __builtin_amdgcn_sched_barrier(0);
-#ifndef FDT_N8_EXP
-#define FDT_N8_EXP 0
-#endif
     if (it + 1 < nst && (FDT_N8_EXP != 1 || it == 0)) {
       stage(s_begin + it + 1, (it + 1) & 1);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VEC ? L::NV : L::ND) : "memory");
