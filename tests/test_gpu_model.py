@@ -140,6 +140,32 @@ def test_cuda_tensor_inputs_equal_host_inputs(res50, synth):
     assert np.array_equal(y.numpy(), res50(x[:1]).numpy()) and not y.is_cuda and res50.last_counts.shape == (1, 2)
 
 
+def test_one_handle_through_many_configurations(res50, res50_sd, synth):
+    """The mutable attributes the reference's callers poke (My_test.py:31-36: priorbox, firstTime, detect) changed between
+    calls on ONE handle -- record size (top_k 750 / 200 / 30 / 1200), thresholds, frame size down to 40x56 (1x1 maps at the
+    last levels), an odd batch -- each configuration run three times (eager, captured, replayed) and compared with the oracle."""
+    def check(H, W, topk, conf, nms, B=1):
+        res50.priorbox = M("layers").PriorBoxLayer(W, H); res50.firstTime = True
+        res50.detect = M("layers").Detect(2, 0, topk, conf, nms)
+        fr = synth.make_frames(B, H, W, seed=3)
+        for _ in range(3):
+            y = res50(fr).numpy()
+        assert y.shape == (B, 2, topk, 5)
+        for b in range(B):
+            exp = opb.detect_frame(res50_sd, fr[b], "res50", detect=opp.Detect(2, 0, topk, conf, nms))
+            n = int((exp[0, 1, :, 0] > 0).sum())
+            d_iou, d_sc = match_detections(y[b, 1], exp[0, 1], n)
+            assert d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL, (H, W, topk, b, d_iou, d_sc)
+        return n
+    assert check(128, 160, 750, 0.05, 0.35) > 10
+    check(128, 160, 200, 0.05, 0.35)                    # smaller record, same plan
+    assert check(128, 160, 30, 0.02, 0.5) == 30         # more survivors than top_k keeps
+    check(128, 160, 750, 0.05, 0.35)                    # and back
+    check(40, 56, 750, 0.05, 0.35)
+    check(128, 160, 750, 0.05, 0.35, B=5)
+    assert check(128, 160, 1200, 0.01, 0.6) > 100       # a record larger than the usual 750
+
+
 def test_load_state_dict_strictness(res50_sd):
     net = M("pyramid").build_sfd('test', 640, 2)
     sd = dict(res50_sd); sd.pop("layer1.0.conv1.weight")
