@@ -109,6 +109,25 @@ def test_detect_batch_and_error():
     assert rc == lib.FDT_ERR_ARG and b"nms_threshold" in lib.lib().fdt_last_error()
 
 
+def test_detect_with_nan_scores_and_boxes_terminates_like_the_oracle():
+    """NaN scores fail `score > conf_thresh` (detection.py:64) and drop out; NaN boxes survive the mask and meet the greedy
+    scan, whose `IoU < overlap` keep test (box_utils.py:339) is false for NaN -- the HIP Detect keeps exactly the rows the
+    oracle keeps and does not hang on them.  An all-NaN frame through the net gives an empty record."""
+    rng = np.random.default_rng(1)
+    P = 500
+    loc = rng.standard_normal((1, P, 4)).astype(np.float32)
+    conf = rng.random((1, P, 2)).astype(np.float32)
+    conf[0, ::7, 1] = np.nan
+    loc[0, ::11] = np.nan
+    pri = rng.random((P, 4)).astype(np.float32)
+    got = M("layers").Detect(2, 0, 750, 0.3, 0.5)(loc, conf, pri).numpy()
+    with np.errstate(all="ignore"):
+        exp = np.asarray(opp.Detect(2, 0, 750, 0.3, 0.5)(loc, conf, pri))
+    n = int((exp[0, 1, :, 0] > 0).sum())
+    assert n > 50 and int((got[0, 1, :, 0] > 0).sum()) == n
+    assert np.array_equal(got[0, 1, :n, 0], exp[0, 1, :n, 0])
+
+
 @pytest.mark.parametrize("P,ncl,thr", [(87360, 400, 0.3), (87360, 3000, 0.01), (25600, 50, 0.3)])
 def test_detect_full_size_vs_oracle(P, ncl, thr):
     """BASELINE size (P = 87 360 priors @1024x1024): HIP Detect == oracle on seeded inputs, incl. an
