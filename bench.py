@@ -311,7 +311,8 @@ def main():
     ap.add_argument("--save-plan", type=int, default=0, help="write the autotuned plan under tuned/")
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per GPU: consecutive batch-1 steps overlap on separate HIP streams "
-                         "(detection of frame i+1 runs beside the tail / tracker step of frame i); default 3, FaceBoxes 4")
+                         "(detection of frame i+1 runs beside the tail / tracker step of frame i); default 4 for Res50 at batch 1, "
+                         "else 3; FaceBoxes 4")
     ap.add_argument("--graph", type=int, default=1, help="replay each forward as a captured HIP graph (0: eager launches)")
     ap.add_argument("--host-frames", type=int, default=0,
                     help="also report the PCIe-inclusive rate: N frames handed over as pageable host buffers through the "
@@ -356,8 +357,10 @@ def main():
     H = args.height or args.size
     W = args.width or args.size
     sd = synth.make_state_dict(args.arch, seed=0)
-    NF = args.inflight if args.inflight > 0 else 3
     B = max(1, args.batch)
+    # frames in flight: measured optimum (A/B on the box, three repetitions): Res50 at batch 1 four (1024^2: 217.5 vs 215.2
+    # frames/s, 640x480: 506 vs 490; five is worse), batched forwards and try3 three (640x480 batch 4: 651 vs 626)
+    NF = args.inflight if args.inflight > 0 else (4 if (args.arch == "res50" and B == 1) else 3)
     if args.arch == "res50":
         net = importlib.import_module("face-detection-and-tracking_amd.pyramid").SFD(device=local_rank)
         net.priorbox = layers.PriorBoxLayer(W, H)
@@ -739,7 +742,7 @@ def host_frames_rate(args, lib, pipe, frames_h, H, W, SH, SW):
     L = lib.lib()
     trk = importlib.import_module("face-detection-and-tracking_amd.tracker")
     tracker = trk.IouTracker(0.4, 0.6, 5, max_dets=2 * pipe.top_k, log_frames=256)
-    NF, U = pipe.NF, frames_h.shape[0]
+    NF, U = min(pipe.NF, 3), frames_h.shape[0]     # three handles x two tickets: measured optimum of this path (four: -7 %)
     n = args.host_frames
     pending = []                     # (net index, ticket) in frame order
     sp = pipe.sp_trk

@@ -23,8 +23,8 @@ B="python bench.py --steps 48 --warmup 8 --cpu-frames 0"
 timeout -k 10 400 python bench.py --steps 64 --warmup 8 --host-frames 64 > $OUT/bench_line_res50_1024.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt --output-format csv -- $B > $OUT/bench_under_rocprof.log 2>&1
 cp /tmp/raw/kt_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv
-# that command runs 6 priming + 8 warm-up + 48 timed + 56 parity (sequential re-run) + 5 profiled forwards
-python tools/rocprof_conv_summary.py $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv 123 $OUT/bench_line_res50_1024.json > $OUT/rocprof_vs_bench.txt
+# that command runs 8 priming + 8 warm-up + 48 timed + 56 parity (sequential re-run) + 5 profiled forwards
+python tools/rocprof_conv_summary.py $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv 125 $OUT/bench_line_res50_1024.json > $OUT/rocprof_vs_bench.txt
 P="python bench.py --steps 8 --warmup 2 --cpu-frames 0 --inflight 1 --profile-frames 1 --graph 0"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/raw -o pmc_$C --output-format csv -- $P > /tmp/raw/pmc_$C.log 2>&1
