@@ -15,7 +15,9 @@
  *     "_dev" entry points take device pointers plus a hipStream_t (as void*; NULL = the
  *     handle's own stream) and only enqueue work.
  *   - caller owns every in/out buffer; the library owns weights and workspaces.
- *   - a handle is not thread-safe; distinct handles may be used from distinct threads.
+ *   - a handle is not thread-safe; distinct handles (fdt_model_clone handles included) may be used from distinct
+ *     threads at the same time, and so may the host entry points.  The library never uses the legacy (null) stream:
+ *     host entry points run on a private stream of the calling thread, handles on their own stream.
  */
 #ifndef FDT_H_
 #define FDT_H_
