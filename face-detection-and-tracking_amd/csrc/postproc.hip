@@ -684,7 +684,7 @@ extern "C" int fdt_detect_dev(const float* loc, const float* conf, const float* 
   FDT_REQUIRE(workspace && workspace_bytes >= pl.bytes, FDT_ERR_ARG,
               "fdt_detect_dev: workspace too small (%lld < %lld)", workspace_bytes, pl.bytes);
   return launch_detect(pl, workspace, loc, conf, priors, num_classes, top_k, conf_thresh,
-                       nms_thresh, var0, var1, out, counts, (hipStream_t)stream);
+                       nms_thresh, var0, var1, out, counts, stream ? (hipStream_t)stream : fdt::thread_stream());
 }
 
 extern "C" int fdt_detect(const float* loc, const float* conf, const float* priors, int B, int P,
