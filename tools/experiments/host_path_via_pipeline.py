@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate when host frames are staged into a device ring on a copy stream and consumed by the device-resident
-pipeline (DetectTrackPipeline.step), i.e. without a host wait per frame -- compare with host_path_breakdown.py."""
+pipeline (DetectTrackPipeline.step), i.e. without a host wait per frame -- compare with host_path_breakdown.py.
+TIMING EXPERIMENT ONLY: the ring slots are reused without waiting for their last reader (results are not checked)."""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
