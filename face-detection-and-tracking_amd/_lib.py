@@ -39,6 +39,7 @@ SIGNATURES = {
     "fdt_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "fdt_set_device": (C.c_int, [C.c_int]),
     "fdt_device_synchronize": (C.c_int, []),
+    "fdt_thread_stream": (C.c_int, [C.POINTER(_vp)]),
     "fdt_device_mem_info": (C.c_int, [_c_i64_p, _c_i64_p]),
     "fdt_priorbox": (C.c_int, [C.c_int] * 5 + [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     "fdt_decode": (C.c_int, [_vp, _vp, C.c_int, C.c_float, C.c_float, _vp]),
@@ -50,6 +51,7 @@ SIGNATURES = {
                                  C.c_longlong, _vp]),
     "fdt_detect_workspace_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "fdt_pairwise_iou": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp]),
+    "fdt_pairwise_distance": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp]),
     "fdt_conv2d": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "fdt_expand_dw": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),

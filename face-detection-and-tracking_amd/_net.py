@@ -50,6 +50,8 @@ class DetectorNet:
             raise _lib.FdtError(_lib.FDT_ERR_HIP, (_lib.lib().fdt_last_error() or b"").decode())
         c.firstTime = True
         c._prior_shape = None
+        c._dev_out = {}
+        c.__dict__.pop("_plan_key", None)
         return c
 
     def enable_graph(self, on=True):
@@ -190,8 +192,15 @@ class DetectorNet:
         if x.device.index not in (None, self._device):
             raise ValueError("input is on cuda:%s but the model was built for cuda:%d" % (x.device.index, self._device))
         self._sync_attributes(H, W)
-        out = torch.empty((B, 2, self.detect.top_k, 5), dtype=torch.float32, device=x.device)
-        counts = torch.zeros((B, 2), dtype=torch.int32, device=x.device)
+        # persistent output buffers per (B, top_k): the handle's captured HIP graph is keyed by these addresses, so a fresh
+        # tensor per call would pay a capture + instantiate every time instead of a replay
+        key = (B, int(self.detect.top_k), x.device.index)
+        bufs = self.__dict__.setdefault("_dev_out", {})
+        if key not in bufs:
+            bufs.clear()
+            bufs[key] = (torch.empty((B, 2, key[1], 5), dtype=torch.float32, device=x.device),
+                         torch.zeros((B, 2), dtype=torch.int32, device=x.device))
+        out, counts = bufs[key]
         torch.cuda.current_stream(x.device).synchronize()       # x is complete; the forward runs on the handle's own stream
         _lib.check(_lib.lib().fdt_model_forward_dev(self._h, C.c_void_p(x.data_ptr()), fmt, B, H, W,
                                                     C.c_void_p(out.data_ptr()), C.c_void_p(counts.data_ptr()), None))
@@ -268,6 +277,18 @@ class DetectorNet:
 
     def import_plan(self, text):
         _lib.check(_lib.lib().fdt_model_import_plan(self._h, text.encode()))
+
+    _ARCH_NAMES = {_lib.ARCH_RES50: "res50", _lib.ARCH_TRY3: "try3", _lib.ARCH_FACEBOX: "facebox", _lib.ARCH_TRY4: "try4",
+                   _lib.ARCH_TRY5: "try5", _lib.ARCH_TRY1: "try1", _lib.ARCH_TRY2: "try2"}
+
+    def tuned_plan_text(self, H, W, B=1):
+        """The committed autotuner result for (arch, W x H, batch) under tuned/, or None: per-layer (kernel class, tile,
+        split-K, workgroup map) measured on MI355X.  What bench.py imports; the entry points use it so that they run the
+        same kernels (an un-planned shape falls back to the analytic choice of `Builder::choose`)."""
+        import os
+        f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned",
+                         "%s_%dx%d_b%d.plan" % (self._ARCH_NAMES[self._arch], W, H, B))
+        return open(f).read() if os.path.exists(f) else None
 
     def flops_per_frame(self):
         f = C.c_double(0)

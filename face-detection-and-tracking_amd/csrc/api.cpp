@@ -35,6 +35,24 @@ extern "C" int fdt_set_device(int dev) {
   return FDT_OK;
 }
 
+namespace fdt {
+hipStream_t thread_stream() {
+  thread_local hipStream_t s[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!s[dev] && hipStreamCreateWithFlags(&s[dev], hipStreamNonBlocking) != hipSuccess) s[dev] = nullptr;
+  return s[dev];
+}
+}  // namespace fdt
+
+extern "C" int fdt_thread_stream(void** stream) {
+  FDT_REQUIRE(stream, FDT_ERR_ARG, "fdt_thread_stream: null output");
+  const hipStream_t st = fdt::thread_stream();
+  FDT_REQUIRE(st, FDT_ERR_HIP, "fdt_thread_stream: could not create the calling thread's private stream");
+  *stream = (void*)st;
+  return FDT_OK;
+}
+
 extern "C" int fdt_device_synchronize(void) {
   FDT_HIP(hipDeviceSynchronize());
   return FDT_OK;

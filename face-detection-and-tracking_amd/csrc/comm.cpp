@@ -107,8 +107,11 @@ extern "C" int fdt_allgather_dets(fdt_comm* c, int local_index, const float* loc
   FDT_REQUIRE(local_index >= 0 && local_index < (int)c->comms.size(), FDT_ERR_ARG,
               "fdt_allgather_dets: local index %d out of range (%d local devices)", local_index, (int)c->comms.size());
   if (c->comms.size() > 1) FDT_HIP(hipSetDevice(c->devices[local_index]));
-  FDT_NCCL(ncclAllGather(local_dev, all_dev, (size_t)floats_per_rank, ncclFloat32, c->comms[local_index],
-                         (hipStream_t)stream));
+  // NULL = the calling thread's private stream (fdt_thread_stream), never the legacy stream: legacy-stream work fails while
+  // another host thread captures a HIP graph (fdt.h, threading contract)
+  const hipStream_t st = stream ? (hipStream_t)stream : fdt::thread_stream();
+  FDT_REQUIRE(st, FDT_ERR_HIP, "fdt_allgather_dets: could not create the calling thread's private stream");
+  FDT_NCCL(ncclAllGather(local_dev, all_dev, (size_t)floats_per_rank, ncclFloat32, c->comms[local_index], st));
   return FDT_OK;
 }
 

@@ -81,15 +81,11 @@ static inline hipError_t copy_sync(void* dst, const void* src, size_t bytes, hip
   const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
   return e != hipSuccess ? e : hipStreamSynchronize(st);
 }
-// The calling host thread's stream for the host-pointer convenience entry points (fdt_detect, fdt_nms, fdt_conv2d, ...):
-// created on first use, one per thread and device, non-blocking, kept for the life of the thread.
-static inline hipStream_t thread_stream() {
-  thread_local hipStream_t s[16] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (!s[dev] && hipStreamCreateWithFlags(&s[dev], hipStreamNonBlocking) != hipSuccess) s[dev] = nullptr;
-  return s[dev];
-}
+// The calling host thread's stream for the host-pointer convenience entry points (fdt_detect, fdt_nms, fdt_conv2d, ...) and
+// for a NULL `stream` argument of the handle-less "_dev" entry points: created on first use, one per thread and device,
+// non-blocking, kept for the life of the thread (api.cpp; exported as fdt_thread_stream).  nullptr = creation failed: callers
+// turn that into FDT_ERR_HIP, never into legacy-stream work.
+hipStream_t thread_stream();
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }

@@ -325,6 +325,7 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
   std::vector<float> tiled;
   tile_weights(w_oihw, nullptr, Cout, Cin, (ConvKind)kind, (ConvTile)tile, tiled);
   const size_t n_in = (size_t)B * Cin * H * W, n_out = (size_t)B * Cout * a.Hout * a.Wout;
+  FDT_REQUIRE(st, FDT_ERR_HIP, "%s: could not create the calling thread's private stream", __func__);
   DevBuf din, dw, db, dout, dres, dup, dws;
   FDT_TRY(din.alloc(n_in * 4)); FDT_TRY(dw.alloc(tiled.size() * 4)); FDT_TRY(dout.alloc(n_out * 4));
   FDT_HIP(copy_sync(din.p, x, n_in * 4, hipMemcpyHostToDevice, st));
@@ -375,6 +376,7 @@ extern "C" int fdt_debug_conv_bench(int kind, int tile, int ksplit, int B, int C
   unsigned s = 12345u;
   for (auto& v : w) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
   tile_weights(w.data(), nullptr, Cout, Cin, (ConvKind)kind, (ConvTile)tile, tiled);
+  FDT_REQUIRE(st, FDT_ERR_HIP, "%s: could not create the calling thread's private stream", __func__);
   DevBuf din, dw, db, dout, dres, dup, dws;
   const size_t n_in = (size_t)B * Cin * Hin * Win, n_out = (size_t)B * Cout * a.Hout * a.Wout;
   FDT_TRY(din.alloc(n_in * 4)); FDT_TRY(dw.alloc(tiled.size() * 4)); FDT_TRY(db.alloc((size_t)Cout * 4));

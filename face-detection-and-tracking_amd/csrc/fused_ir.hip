@@ -281,6 +281,7 @@ extern "C" int fdt_expand_dw(const float* x, int B, int Cin, int H, int W, const
   FDT_REQUIRE(x && w1 && b1 && wdw && bdw && out && B >= 1 && H >= 1 && W >= 1, FDT_ERR_ARG, "fdt_expand_dw: bad argument");
   FDT_REQUIRE(stride == 1 || stride == 2, FDT_ERR_ARG, "fdt_expand_dw: stride must be 1 or 2");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  FDT_REQUIRE(st, FDT_ERR_HIP, "%s: could not create the calling thread's private stream", __func__);
   DevBuf dx, dw1, db1, dwd, dbd, dout;
   const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * hid * Ho * Wo;
   FDT_TRY(dx.alloc(nx * 4)); FDT_TRY(dw1.alloc((size_t)hid * Cin * 4)); FDT_TRY(db1.alloc((size_t)hid * 4));
@@ -302,6 +303,7 @@ extern "C" int fdt_debug_expand_dw_bench(int B, int Cin, int H, int W, int hid, 
   using namespace fdt;
   FDT_REQUIRE(ms_out && iters >= 1 && (stride == 1 || stride == 2), FDT_ERR_ARG, "fdt_debug_expand_dw_bench: bad argument");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  FDT_REQUIRE(st, FDT_ERR_HIP, "%s: could not create the calling thread's private stream", __func__);
   DevBuf dx, dw1, db1, dwd, dbd, dout;
   const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * hid * Ho * Wo;
   FDT_TRY(dx.alloc(nx * 4)); FDT_TRY(dw1.alloc((size_t)hid * Cin * 4)); FDT_TRY(db1.alloc((size_t)hid * 4));

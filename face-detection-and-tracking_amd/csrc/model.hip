@@ -89,6 +89,7 @@ struct WeightStore {
   ~WeightStore() { drop_device(); }
 };
 
+constexpr size_t kMaxGraphs = 16;   // captured graphs kept per handle
 struct GraphKey {   // everything a captured forward bakes in besides the plan itself
   const void* out;
   const void* counts;
@@ -150,6 +151,8 @@ struct fdt_model {
   // the launches of a forward after the ingest kernel (convs ... Detect), captured once per (plan, output buffers,
   // thresholds) and replayed with one hipGraphLaunch: the small-frame configs are bound by launch issue otherwise
   std::map<GraphKey, hipGraphExec_t> graphs;
+  std::map<GraphKey, unsigned long long> graph_used;   // last replay of each graph (LRU eviction at kMaxGraphs)
+  unsigned long long graph_clock = 0;
   int plan_runs = 0;          // eager forwards since the plan was (re)built; capture starts at the second
   bool use_graph = true;
   struct Hint { int kind, tile, split, map; };
@@ -184,6 +187,7 @@ struct fdt_model {
   void drop_graphs() {
     for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
     graphs.clear();
+    graph_used.clear();
     plan_runs = 0;
   }
   void free_plan() {
@@ -1367,10 +1371,22 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
                        run_detect ? 1 : 0, m->conf_t, m->nms_t};
     auto it = m->graphs.find(key);
     if (it != m->graphs.end()) {
+      m->graph_used[key] = ++m->graph_clock;
       FDT_HIP(hipGraphLaunch(it->second, st));
       return FDT_OK;
     }
-    if (m->plan_runs >= 1 && m->graphs.size() < 16) {
+    if (m->plan_runs >= 1) {
+      if (m->graphs.size() >= kMaxGraphs) {
+        // a caller that rotates its output buffers: evict the least recently replayed graph instead of silently running
+        // eager from the 17th buffer on.  The victim may still be executing (on any stream it was replayed on).
+        auto victim = m->graphs.begin();
+        for (auto g = m->graphs.begin(); g != m->graphs.end(); ++g)
+          if (m->graph_used[g->first] < m->graph_used[victim->first]) victim = g;
+        FDT_HIP(hipDeviceSynchronize());
+        (void)hipGraphExecDestroy(victim->second);
+        m->graph_used.erase(victim->first);
+        m->graphs.erase(victim);
+      }
       FDT_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
       const int rc = body();
       hipGraph_t g = nullptr;
@@ -1385,6 +1401,7 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
       (void)hipGraphDestroy(g);
       FDT_REQUIRE(ie == hipSuccess && ex, FDT_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
       m->graphs[key] = ex;
+      m->graph_used[key] = ++m->graph_clock;
       FDT_HIP(hipGraphLaunch(ex, st));
       return FDT_OK;
     }
@@ -1748,7 +1765,9 @@ extern "C" int fdt_model_async_record(fdt_model* m, int ticket, float** record_d
   AsyncSlot* s = find_ticket(m, ticket);
   FDT_REQUIRE(s, FDT_ERR_ARG, "fdt_model_async_record: ticket %d is not in flight", ticket);
   FDT_REQUIRE(record_dev, FDT_ERR_ARG, "fdt_model_async_record: null output");
-  FDT_HIP(hipStreamWaitEvent((hipStream_t)consumer_stream, s->fwd, 0));
+  const hipStream_t cs = consumer_stream ? (hipStream_t)consumer_stream : fdt::thread_stream();   // never the legacy stream
+  FDT_REQUIRE(cs, FDT_ERR_HIP, "fdt_model_async_record: could not create the calling thread's private stream");
+  FDT_HIP(hipStreamWaitEvent(cs, s->fwd, 0));
   *record_dev = s->d_out;
   return FDT_OK;
 }

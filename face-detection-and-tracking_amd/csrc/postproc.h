@@ -26,7 +26,8 @@ int launch_facebox_decode(const DetectPlan& pl, void* ws, const float* loc, cons
                           const float* anchors, float conf_t, float nms_t, float* boxes, float* probs,
                           int* counts, hipStream_t st);
 int launch_facebox_anchors(float* out, hipStream_t st);
+// measure 0: calculate_iou, 1: calculate_distance (utils/calc_performance.py:54-74 / :34-51)
 int launch_pairwise_iou(const void* a, int A, const void* b, int B, int dtype, void* out,
-                        hipStream_t st);
+                        hipStream_t st, int measure = 0);
 
 }  // namespace fdt

@@ -428,6 +428,43 @@ __global__ void pairwise_iou_kernel(const T* __restrict__ a, int A, const T* __r
   out[(long long)i * B + j] = iou_one<T>(av, bv);
 }
 
+// calculate_distance(box_a, box_b)  utils/calc_performance.py:34-51, the association measure of the tracker's
+// use_iou = False branch (iouTracke_cal.py:136-138): with w/h extents d = box[2:] - box[:2] and centres c = (box[2:] + box[:2]) / 2,
+//   delt_z = ((da.x - db.x) + (da.y - db.y)) / 2;   dis = (delt_z^2 + (cb.x - ca.x)^2 + (cb.y - ca.y)^2) ** 0.25
+// in the reference's operand order (this TU is compiled with -ffp-contract=off).  `** 0.25` is numpy's pow, which is
+// libm / SIMD-library dependent (within 1 ulp, NOT correctly rounded: measured 5 % of f64 inputs off by one ulp in the build
+// container's numpy 2.2); here the fourth root IS correctly rounded -- two IEEE square roots plus one exact-residual Newton
+// step -- so it agrees with any faithful pow to 1 ulp and with a correctly rounded one bit for bit.
+__device__ __forceinline__ double root4_cr(double x) {
+  const double r = sqrt(sqrt(x));
+  if (!(r > 0.0) || r > 1.7e308) return r;           // 0, NaN, inf: sqrt already gave numpy's answer
+  const double r2 = r * r, r2e = fma(r, r, -r2);      // r^2 = r2 + r2e exactly
+  const double r4 = r2 * r2, r4e = fma(r2, r2, -r4) + 2.0 * r2 * r2e;
+  const double e = (x - r4) - r4e;                    // x - r^4, to well below an ulp of x
+  return r + e / (4.0 * r2 * r);
+}
+template <typename T>
+__device__ __forceinline__ T distance_one(const T* a, const T* b) {
+  const T adx = a[2] - a[0], ady = a[3] - a[1], bdx = b[2] - b[0], bdy = b[3] - b[1];
+  const T cax = (a[2] + a[0]) / (T)2, cay = (a[3] + a[1]) / (T)2;
+  const T cbx = (b[2] + b[0]) / (T)2, cby = (b[3] + b[1]) / (T)2;
+  const T dx = cbx - cax, dy = cby - cay;
+  const T dz = ((adx - bdx) + (ady - bdy)) / (T)2;
+  const T dis = dz * dz + dx * dx + dy * dy;
+  return (T)root4_cr((double)dis);
+}
+
+template <typename T>
+__global__ void pairwise_distance_kernel(const T* __restrict__ a, int A, const T* __restrict__ b, int B,
+                                         T* __restrict__ out) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int i = blockIdx.y;
+  if (j >= B || i >= A) return;
+  T av[4] = {a[i * 4 + 0], a[i * 4 + 1], a[i * 4 + 2], a[i * 4 + 3]};
+  T bv[4] = {b[j * 4 + 0], b[j * 4 + 1], b[j * 4 + 2], b[j * 4 + 3]};
+  out[(long long)i * B + j] = distance_one<T>(av, bv);
+}
+
 inline long long align_up(long long x, long long a) { return (x + a - 1) / a * a; }
 
 }  // namespace
@@ -584,9 +621,19 @@ int launch_facebox_anchors(float* out, hipStream_t st) {
 }
 
 int launch_pairwise_iou(const void* a, int A, const void* b, int B, int dtype, void* out,
-                        hipStream_t st) {
+                        hipStream_t st, int measure) {
   if (A == 0 || B == 0) return FDT_OK;
   dim3 grid(ceil_div(B, 64), A);
+  if (measure == 1) {
+    if (dtype == FDT_F64)
+      hipLaunchKernelGGL(pairwise_distance_kernel<double>, grid, dim3(64), 0, st, (const double*)a, A,
+                         (const double*)b, B, (double*)out);
+    else
+      hipLaunchKernelGGL(pairwise_distance_kernel<float>, grid, dim3(64), 0, st, (const float*)a, A,
+                         (const float*)b, B, (float*)out);
+    FDT_LAUNCH_CHECK();
+    return FDT_OK;
+  }
   if (dtype == FDT_F64)
     hipLaunchKernelGGL(pairwise_iou_kernel<double>, grid, dim3(64), 0, st, (const double*)a, A,
                        (const double*)b, B, (double*)out);
@@ -609,6 +656,7 @@ extern "C" int fdt_priorbox(int width, int height, int stride, int box, int n_sc
               FDT_ERR_ARG, "fdt_priorbox: bad argument");
   long long total = (long long)f_w * f_h * n_scales * (1 + n_ar);
   if (total == 0) return FDT_OK;
+  FDT_REQUIRE(st, FDT_ERR_HIP, "%s: could not create the calling thread's private stream", __func__);
   DevBuf d_out, d_ar;
   FDT_TRY(d_out.alloc(total * 16));
   if (n_ar) {
@@ -626,6 +674,7 @@ extern "C" int fdt_decode(const float* loc, const float* priors, int P, float va
   const hipStream_t st = fdt::thread_stream();   // never the legacy stream (common.h)
   FDT_REQUIRE(P >= 0 && loc && priors && boxes, FDT_ERR_ARG, "fdt_decode: bad argument");
   if (P == 0) return FDT_OK;
+  FDT_REQUIRE(st, FDT_ERR_HIP, "%s: could not create the calling thread's private stream", __func__);
   DevBuf dl, dp, dbx;
   FDT_TRY(dl.alloc((size_t)P * 16));
   FDT_TRY(dp.alloc((size_t)P * 16));
@@ -646,6 +695,7 @@ extern "C" int fdt_nms(const float* boxes, const float* scores, int n, float ove
   if (n == 0) return FDT_OK;  // box_utils.py:290-291
   FDT_REQUIRE(top_k >= 1, FDT_ERR_ARG, "fdt_nms: top_k must be >= 1");
   DetectPlan pl = make_detect_plan(1, n, top_k);
+  FDT_REQUIRE(st, FDT_ERR_HIP, "%s: could not create the calling thread's private stream", __func__);
   DevBuf ws, db, ds, dk, dc;
   FDT_TRY(ws.alloc(pl.bytes));
   FDT_TRY(db.alloc((size_t)n * 16));
@@ -683,8 +733,10 @@ extern "C" int fdt_detect_dev(const float* loc, const float* conf, const float* 
   DetectPlan pl = make_detect_plan(B, P, nms_top_k);
   FDT_REQUIRE(workspace && workspace_bytes >= pl.bytes, FDT_ERR_ARG,
               "fdt_detect_dev: workspace too small (%lld < %lld)", workspace_bytes, pl.bytes);
+  const hipStream_t st = stream ? (hipStream_t)stream : fdt::thread_stream();   // NULL = fdt_thread_stream(), fdt.h
+  FDT_REQUIRE(st, FDT_ERR_HIP, "fdt_detect_dev: could not create the calling thread's private stream");
   return launch_detect(pl, workspace, loc, conf, priors, num_classes, top_k, conf_thresh,
-                       nms_thresh, var0, var1, out, counts, stream ? (hipStream_t)stream : fdt::thread_stream());
+                       nms_thresh, var0, var1, out, counts, st);
 }
 
 extern "C" int fdt_detect(const float* loc, const float* conf, const float* priors, int B, int P,
@@ -694,6 +746,7 @@ extern "C" int fdt_detect(const float* loc, const float* conf, const float* prio
   FDT_TRY(check_detect_args(B, P, num_classes, top_k, nms_thresh, nms_top_k));
   FDT_REQUIRE(loc && conf && priors && out, FDT_ERR_ARG, "fdt_detect: null pointer");
   DetectPlan pl = make_detect_plan(B, P, nms_top_k);
+  FDT_REQUIRE(st, FDT_ERR_HIP, "%s: could not create the calling thread's private stream", __func__);
   DevBuf ws, dl, dcf, dp, dout, dcnt;
   size_t n_out = (size_t)B * num_classes * top_k * 5;
   FDT_TRY(ws.alloc(pl.bytes));
@@ -714,27 +767,35 @@ extern "C" int fdt_detect(const float* loc, const float* conf, const float* prio
   return FDT_OK;
 }
 
-extern "C" int fdt_pairwise_iou(const void* a, int A, const void* b, int B, int dtype, void* out) {
+static int pairwise_host(const void* a, int A, const void* b, int B, int dtype, void* out, int measure) {
   const hipStream_t st = fdt::thread_stream();   // never the legacy stream (common.h)
   FDT_REQUIRE(A >= 0 && B >= 0 && (dtype == FDT_F32 || dtype == FDT_F64), FDT_ERR_ARG,
-              "fdt_pairwise_iou: bad argument");
+              "fdt_pairwise_iou / fdt_pairwise_distance: bad argument");
   if (A == 0 || B == 0) return FDT_OK;
-  FDT_REQUIRE(a && b && out, FDT_ERR_ARG, "fdt_pairwise_iou: null pointer");
+  FDT_REQUIRE(a && b && out, FDT_ERR_ARG, "fdt_pairwise_iou / fdt_pairwise_distance: null pointer");
   size_t es = dtype == FDT_F64 ? 8 : 4;
+  FDT_REQUIRE(st, FDT_ERR_HIP, "%s: could not create the calling thread's private stream", __func__);
   DevBuf da, db, dout;
   FDT_TRY(da.alloc((size_t)A * 4 * es));
   FDT_TRY(db.alloc((size_t)B * 4 * es));
   FDT_TRY(dout.alloc((size_t)A * B * es));
   FDT_HIP(copy_sync(da.p, a, (size_t)A * 4 * es, hipMemcpyHostToDevice, st));
   FDT_HIP(copy_sync(db.p, b, (size_t)B * 4 * es, hipMemcpyHostToDevice, st));
-  FDT_TRY(launch_pairwise_iou(da.p, A, db.p, B, dtype, dout.p, st));
+  FDT_TRY(launch_pairwise_iou(da.p, A, db.p, B, dtype, dout.p, st, measure));
   FDT_HIP(copy_sync(out, dout.p, (size_t)A * B * es, hipMemcpyDeviceToHost, st));
   return FDT_OK;
+}
+extern "C" int fdt_pairwise_iou(const void* a, int A, const void* b, int B, int dtype, void* out) {
+  return pairwise_host(a, A, b, B, dtype, out, 0);
+}
+extern "C" int fdt_pairwise_distance(const void* a, int A, const void* b, int B, int dtype, void* out) {
+  return pairwise_host(a, A, b, B, dtype, out, 1);
 }
 
 extern "C" int fdt_facebox_anchors(float* out) {
   const hipStream_t st = fdt::thread_stream();   // never the legacy stream (common.h)
   FDT_REQUIRE(out, FDT_ERR_ARG, "fdt_facebox_anchors: null pointer");
+  FDT_REQUIRE(st, FDT_ERR_HIP, "%s: could not create the calling thread's private stream", __func__);
   DevBuf d;
   FDT_TRY(d.alloc(21824 * 16));
   FDT_TRY(launch_facebox_anchors(d.as<float>(), st));
@@ -749,6 +810,7 @@ extern "C" int fdt_facebox_decode(const float* loc, const float* conf, const flo
   FDT_REQUIRE(P >= 1 && loc && conf && anchors && boxes && probs && count, FDT_ERR_ARG,
               "fdt_facebox_decode: bad argument");
   DetectPlan pl = make_detect_plan(1, P, P);
+  FDT_REQUIRE(st, FDT_ERR_HIP, "%s: could not create the calling thread's private stream", __func__);
   DevBuf ws, dl, dc, da, db, dp, dn;
   FDT_TRY(ws.alloc(pl.bytes));
   FDT_TRY(dl.alloc((size_t)P * 16));

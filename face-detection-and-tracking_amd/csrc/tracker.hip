@@ -11,6 +11,7 @@
 // Bit-exactness: IoU is f64 in the operand order of utils/calc_performance.py:4-31,54-74 (this file is
 // compiled with -ffp-contract=off); arg-max follows numpy (first maximum, NaN wins); `>` tests are
 // strict like the reference (:134, :146, :174).
+#include <atomic>
 #include <vector>
 
 #include "common.h"
@@ -595,6 +596,22 @@ int step_common(fdt_tracker* t, const double* dets_dev, int n, const float* det_
 }
 }  // namespace
 
+namespace fdt {
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-(function, device) setting: it is raised ONCE per device to the
+// constant ceiling, never to a tracker's own size (a second, smaller tracker must not lower it under a live larger one).
+static hipError_t set_track_kernel_lds(int bytes) {
+  static std::atomic<unsigned char> done[16];
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+  if (done[dev].load(std::memory_order_acquire)) return hipSuccess;
+  e = hipFuncSetAttribute((const void*)track_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done[dev].store(1, std::memory_order_release);
+  return e;
+}
+}  // namespace fdt
+
 extern "C" fdt_tracker* fdt_tracker_create(double sigma_iou, double sigma_h, int t_min, int max_dets,
                                            int log_frames) {
   if (max_dets < 1 || log_frames < 1) {
@@ -625,8 +642,7 @@ extern "C" fdt_tracker* fdt_tracker_create(double sigma_iou, double sigma_h, int
             hipMalloc(&t->d_sets, per_set * 2) == hipSuccess &&
             hipMemsetAsync(t->d_state, 0, sizeof(fdt::TrkState), t->own_stream) == hipSuccess &&
             hipStreamSynchronize(t->own_stream) == hipSuccess &&
-            hipFuncSetAttribute((const void*)fdt::track_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                max_dets * fdt::TRK_LDS_PER_SLOT) == hipSuccess;
+            fdt::set_track_kernel_lds((int)kDynLds) == hipSuccess;
   if (!ok) {
     set_error("fdt_tracker_create: HIP allocation failed: %s", hipGetErrorString(hipGetLastError()));
     fdt_tracker_destroy(t);

@@ -12,8 +12,9 @@
  *   - every function returns FDT_OK (0) or a negative FDT_ERR_* code; the message for the
  *     calling thread's last failure is fdt_last_error().
  *   - "host" entry points take host pointers, copy in/out and synchronise before returning.
- *     "_dev" entry points take device pointers plus a hipStream_t (as void*; NULL = the
- *     handle's own stream) and only enqueue work.
+ *     "_dev" entry points take device pointers plus a hipStream_t (as void*) and only enqueue work.  NULL = the
+ *     handle's own stream where the call has a handle (fdt_model_*, fdt_tracker_*), else the calling thread's
+ *     private stream (fdt_thread_stream); never the legacy stream.
  *   - caller owns every in/out buffer; the library owns weights and workspaces.
  *   - a handle is not thread-safe; distinct handles (fdt_model_clone handles included) may be used from distinct
  *     threads at the same time, and so may the host entry points.  The library never uses the legacy (null) stream:
@@ -60,6 +61,11 @@ int fdt_device_count(int* n);
 int fdt_device_name(int dev, char* buf, int buflen);
 int fdt_set_device(int dev);
 int fdt_device_synchronize(void);
+/* The calling host thread's private non-blocking stream (hipStream_t as void*): what the host entry points run on
+ * and what a NULL `stream` argument of a handle-less "_dev" entry point (fdt_detect_dev, fdt_allgather_dets, the
+ * consumer_stream of fdt_model_async_record) means.  A caller that passed NULL orders later work behind the
+ * library's by using / synchronising this stream.                                                            */
+int fdt_thread_stream(void** stream);
 /* free / total HBM of the current device (hipMemGetInfo) */
 int fdt_device_mem_info(long long* free_bytes, long long* total_bytes);
 
@@ -100,6 +106,11 @@ long long fdt_detect_workspace_bytes(int B, int P, int nms_top_k);
  * a [A,4], b [B,4] (x1,y1,x2,y2) -> out [A,B]; dtype FDT_F32 / FDT_F64 follows the input
  * like numpy does (the tracker feeds f64).  0/0 -> NaN, no epsilon.                          */
 int fdt_pairwise_iou(const void* a, int A, const void* b, int B, int dtype, void* out);
+/* calculate_distance(box_a, box_b)  utils/calc_performance.py:34-51: the association measure of the tracker's
+ * `use_iou = False` branch (iouTracke_cal.py:136-138).  Same shapes / dtypes as fdt_pairwise_iou.  The final
+ * `dis ** 0.25` is correctly rounded here; numpy's pow is only faithful (1 ulp, libm dependent), so parity with a
+ * reference run is stated as 1 ulp.                                                    */
+int fdt_pairwise_distance(const void* a, int A, const void* b, int B, int dtype, void* out);
 
 /* FaceBoxes anchors: DataEncoder.__init__  FACEBOX/encoderl.py:12-48.  out [21824,4] (cx,cy,w,h)/1024. */
 int fdt_facebox_anchors(float* out);

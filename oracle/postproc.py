@@ -205,6 +205,24 @@ def calculate_iou(box_a, box_b):
         return inter / union
 
 
+def calculate_distance(box_a, box_b):
+    """Restates reference utils/calc_performance.py:34-51 ([A,4]x[B,4] -> [A,B]): fourth root of
+    (mean extent difference)^2 + (centre difference)^2, numpy broadcasting in the reference's operand order."""
+    box_a = np.asarray(box_a)
+    box_b = np.asarray(box_b)
+    a_hi, a_lo = box_a[:, None, 2:], box_a[:, None, :2]          # the reference calls these *_x1y1 / *_x2y2 (:37-40)
+    b_hi, b_lo = box_b[None, :, 2:], box_b[None, :, :2]
+    a_dxdy = a_hi - a_lo
+    b_dxdy = b_hi - b_lo
+    ca_xy = (a_hi + a_lo) / 2
+    cb_xy = (b_hi + b_lo) / 2
+    delt_xy = cb_xy - ca_xy
+    delt_dxdy = a_dxdy - b_dxdy
+    delt_z = (delt_dxdy[:, :, 0] + delt_dxdy[:, :, 1]) / 2
+    dis = delt_z * delt_z + delt_xy[:, :, 0] * delt_xy[:, :, 0] + delt_xy[:, :, 1] * delt_xy[:, :, 1]
+    return dis ** 0.25
+
+
 def calc_pr(predict, truth, iou_thresh=0.5):
     """Restates reference utils/calc_performance.py:77-92."""
     truth = np.hstack((truth[:, :2], truth[:, 2:] + truth[:, :2]))
@@ -239,8 +257,9 @@ def unpack_detections(detections, width, height, score_thresh=0.4, shrink=1):
 class IouTracker:
     """Restates the inline tracker of reference iouTracke_cal.py:113-156,174-177."""
 
-    def __init__(self, sigma_iou=0.4, sigma_h=0.6, t_min=5):
+    def __init__(self, sigma_iou=0.4, sigma_h=0.6, t_min=5, use_iou=True, sigma_dis=8):
         self.sigma_iou, self.sigma_h, self.t_min = sigma_iou, sigma_h, t_min
+        self.use_iou, self.sigma_dis = use_iou, sigma_dis        # :23,:26 (module-level configuration)
         self.frame_num = 0
         self.tracks_active = []
         self.tracks_finished = []
@@ -251,9 +270,14 @@ class IouTracker:
         updated = []
         for track in self.tracks_active:                         # :129
             if len(dets) > 0:                                    # :130 (no else: track dropped)
-                iou = calculate_iou(np.array(dets)[:, :4], np.array([track['bboxes'][-1]]))
-                best = int(iou.argmax())                         # :133 (NaN wins argmax)
-                matched = iou[best] > self.sigma_iou             # :134
+                if self.use_iou:
+                    iou = calculate_iou(np.array(dets)[:, :4], np.array([track['bboxes'][-1]]))
+                    best = int(iou.argmax())                     # :133 (NaN wins argmax)
+                    matched = iou[best] > self.sigma_iou         # :134
+                else:
+                    dis = calculate_distance(np.array(dets)[:, :4], np.array([track['bboxes'][-1]]))
+                    best = int(dis.argmin())                     # :137 (NaN wins argmin too)
+                    matched = dis[best] < self.sigma_dis         # :138
                 if matched:
                     track['bboxes'].append(dets[best][:4])
                     track['max_score'] = max(track['max_score'], dets[best][4])

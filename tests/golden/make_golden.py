@@ -512,10 +512,20 @@ def gen_nets_r2():
     """C1 (Res50 640x640, My_test.py's size) and C3 (try3 1024x1024 BATCH 8: eight seeded frames through ONE call of the
     reference module, pyramid_mb2_try3.py:218-340) -> tests/golden/nets_r2.npz.  Stored per image: the Detect rows, a
     strided sample of the pre-Detect loc / conf, and their sha256."""
+    _gen_net_cases("nets_r2", (("res50", 640, 640, [640]), ("try3", 1024, 1024, [2000 + i for i in range(8)])))
+
+
+def gen_nets_r3():
+    """C4' (Res50 at the NATIVE 1080 x 1920 frame size of BASELINE config 4's source video: one forward of the reference
+    module, pyramid.py:218-351) -> tests/golden/nets_r3.npz, same layout as nets_r2."""
+    _gen_net_cases("nets_r3", (("res50", 1080, 1920, [1080]),))
+
+
+def _gen_net_cases(fname, cases):
     from layers import PriorBoxLayer, Detect
     from oracle import pyramidbox as opb
     out, meta = {}, {}
-    for arch, H, W, seeds in (("res50", 640, 640, [640]), ("try3", 1024, 1024, [2000 + i for i in range(8)])):
+    for arch, H, W, seeds in cases:
         sd = synth.make_state_dict(arch, seed=0)
         net = _ref_net(arch, sd)
         frames = np.stack([synth.make_frames(1, H, W, seed=sv)[0] for sv in seeds])
@@ -553,7 +563,7 @@ def gen_nets_r2():
                      "loc_sha": sha(cap["loc"]), "conf_sha": sha(cap["conf"])}
         print(key, meta[key])
     out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
-    save("nets_r2", **out)
+    save(fname, **out)
 
 
 def gen_facebox_r2():
@@ -594,6 +604,59 @@ def gen_facebox_r2():
     save("facebox_r2", **out)
 
 
+# ----------------------------------------------------------------------------- use_iou = False
+def gen_distance():
+    """calculate_distance (reference utils/calc_performance.py:34-51) on seeded boxes, and the inline tracker run with
+    `use_iou = False` (iouTracke_cal.py:136-138) on sequences of the tracker fixture's generator."""
+    from utils.calc_performance import calculate_iou, calculate_distance
+    rng = np.random.default_rng(11)
+    out = {}
+
+    def boxes(n, dtype, scale=640.0):
+        xy = rng.uniform(0, scale * 0.8, (n, 2))
+        wh = rng.uniform(4, scale * 0.3, (n, 2))
+        return np.concatenate([xy, xy + wh], 1).astype(dtype)
+    for dt, nm in ((np.float64, "f64"), (np.float32, "f32")):
+        a, b = boxes(41, dt), boxes(67, dt)
+        a[5] = b[7]                        # identical box -> distance 0
+        a[6] = [10, 10, 10, 10]
+        b[9] = [10, 10, 10, 10]            # both degenerate at the same point -> 0
+        b[10] = [0, 0, 0, 0]
+        out["dis_%s_a" % nm], out["dis_%s_b" % nm] = a, b
+        out["dis_%s_out" % nm] = calculate_distance(a, b)
+    save("distance", **out)
+
+    body, final = _tracker_sources()
+    rngt = np.random.default_rng(123)
+    seqs = {
+        "walk": make_track_sequence(rngt, 60, 4),
+        "crowd": make_track_sequence(rngt, 40, 12, p_drop=0.2, jitter=6.0, birth=0.2),
+        "gaps": make_track_sequence(rngt, 50, 3, p_drop=0.3, empty_frames=(10, 11, 30)),
+        "fast": make_track_sequence(rngt, 60, 5, p_drop=0.1, jitter=5.0),   # steps around sigma_dis = 8
+    }
+    result = {}
+    for name, frames in seqs.items():
+        ns = dict(np=np, calculate_iou=calculate_iou, calculate_distance=calculate_distance,
+                  use_iou=False, sigma_iou=0.4, sigma_dis=8, sigma_h=0.6, t_min=5,
+                  tracks_active=[], tracks_finished=[], frame_num=0)
+        for det0 in frames:
+            ns["frame_num"] += 1
+            ns["det0"] = det0
+            exec(body, ns)
+        exec(final, ns)
+        result[name] = {
+            "frames": [f.tolist() for f in frames],
+            "frame_dtypes": [str(f.dtype) for f in frames],
+            "tracks": [{"bboxes": [list(map(float, b)) for b in t["bboxes"]],
+                        "max_score": float(t["max_score"]), "start_frame": int(t["start_frame"])}
+                       for t in ns["tracks_finished"]],
+        }
+        print("tracker(use_iou=False)", name, "frames", len(frames), "tracks", len(result[name]["tracks"]))
+    with open(os.path.join(HERE, "tracker_dis.json"), "w") as f:
+        json.dump({"sequences": result}, f)
+    print("wrote tracker_dis.json", os.path.getsize(os.path.join(HERE, "tracker_dis.json")))
+
+
 def gen_tp_fp_fixture():
     """gen_tp_fp (reference draw_curve/draw_pr_roc.py:5-19).  The module runs its plotting script on import, so -- as for
     the inline tracker -- the function's own lines are read from the reference file at generation time and exec'd."""
@@ -617,8 +680,8 @@ def gen_tp_fp_fixture():
 
 
 GENS = {"facebox": gen_facebox, "priors": gen_priors, "detect": gen_detect, "iou": gen_iou, "tracker": gen_tracker, "nets": gen_nets,
-        "nets45": gen_nets45, "nets12": gen_nets12, "nets_r2": gen_nets_r2,
-        "facebox_r2": gen_facebox_r2, "tp_fp": gen_tp_fp_fixture}
+        "nets45": gen_nets45, "nets12": gen_nets12, "nets_r2": gen_nets_r2, "nets_r3": gen_nets_r3,
+        "facebox_r2": gen_facebox_r2, "tp_fp": gen_tp_fp_fixture, "distance": gen_distance}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

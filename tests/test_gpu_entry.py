@@ -37,8 +37,20 @@ def test_detect_face_matches_oracle_unpack(entry, synth):
     y = entry.net(fr).numpy()
     exp = opp.unpack_detections(y, 160, 128, 0.4)
     assert det.dtype == exp.dtype and np.array_equal(det, exp) and det.shape[0] > 3
-    with pytest.raises(NotImplementedError):
-        entry.detect_face(fr, 2)
+
+
+@pytest.mark.parametrize("shrink", [0.5, 2])
+def test_detect_face_with_shrink(entry, synth, shrink):
+    """reference :37-38 + :76-79: the frame is resized by `shrink` before the net (here on the GPU, bit-exact vs the oracle's
+    restatement of cv2's 8-bit INTER_LINEAR path; cv2 parity itself unpinned) and the boxes are divided by it afterwards."""
+    from oracle import ingest
+    src = synth.make_frames(1, int(128 / shrink), int(160 / shrink), seed=31)[0]
+    entry.net.firstTime = True
+    det = entry.detect_face(src, shrink)
+    small = ingest.resize_linear_u8(src, 160, 128)
+    y = entry.net(small).numpy()
+    exp = opp.unpack_detections(y, 160, 128, 0.4, shrink=shrink)
+    assert det.dtype == exp.dtype and np.array_equal(det, exp) and det.shape[0] > 3
 
 
 def test_track_device_resident_equals_host_and_oracle(entry, synth, tmp_path):
@@ -58,6 +70,61 @@ def test_track_device_resident_equals_host_and_oracle(entry, synth, tmp_path):
     entry.save_tracks(t_dev, p)
     back = np.load(p, allow_pickle=True).tolist()
     assert back == t_dev and set(back[0]) == {"bboxes", "max_score", "start_frame"}
+
+
+def _ref_tracks(entry, frames, **kw):
+    ref = opp.IouTracker(entry.sigma_iou, entry.sigma_h, entry.t_min, **kw)
+    for f in frames:
+        with np.errstate(all="ignore"):
+            ref.step(entry.detect_face(f, 1))
+    return [{"bboxes": [list(map(float, b)) for b in t["bboxes"]], "max_score": float(t["max_score"]),
+             "start_frame": t["start_frame"]} for t in ref.finish()]
+
+
+def test_track_pipelined_equals_synchronous_and_oracle(entry, synth):
+    """track() IS the pipelined async-ingest path (N handles x 2 tickets, pinned ring, device hand-over, no host wait per
+    frame): tracks bit-equal to the one-handle synchronous path and to the oracle tracker -- for 1..4 handles in flight and
+    for batched forwards, incl. a last partial batch (21 frames, batch 2 and 4)."""
+    frames = frames_sequence(synth)
+    t_ref = _ref_tracks(entry, frames)
+    assert len(t_ref) > 3
+    assert entry.track(frames, pipelined=False) == t_ref
+    for inflight in (1, 2, 3, 4):
+        assert entry.track(frames, inflight=inflight) == t_ref, inflight
+    assert entry.track(iter(frames)) == t_ref                       # any iterable
+    for batch in (2, 4):
+        assert entry.track(frames, inflight=2, batch=batch) == t_ref, batch
+    assert entry.track([]) == []
+    with pytest.raises(ValueError):
+        entry.track(frames[:2] + [frames[0][:64]])                  # frame shape changes mid-sequence
+
+
+def test_track_from_source_frames_resized_on_the_gpu(entry, synth):
+    """reference :123: image = cv2.resize(image, (W, H)) in front of detect_face -- track(frames, size=(W, H)) does it on the
+    GPU inside the pipelined ingest; same tracks as resizing with the oracle's restatement on the host first."""
+    from oracle import ingest
+    rng = np.random.default_rng(5)
+    base = [rng.integers(0, 256, (270, 480, 3), dtype=np.uint8) for _ in range(3)]
+    src = [base[i // 7] for i in range(21)]
+    small = [ingest.resize_linear_u8(f, 160, 128) for f in base]
+    t_ref = _ref_tracks(entry, [small[i // 7] for i in range(21)])
+    assert len(t_ref) > 3
+    assert entry.track(src, size=(160, 128)) == t_ref
+    assert entry.track(src, size=(160, 128), pipelined=False) == t_ref
+    assert entry.track(src, size=(160, 128), batch=2) == t_ref
+
+
+def test_track_with_distance_measure(entry, synth):
+    """use_iou = False (reference :136-138): fdt_pairwise_distance + argmin / `< sigma_dis`; tracks equal the oracle
+    tracker's on the same detections."""
+    frames = frames_sequence(synth)
+    entry.use_iou = False
+    try:
+        got = entry.track(frames)
+    finally:
+        entry.use_iou = True
+    exp = _ref_tracks(entry, frames, use_iou=False, sigma_dis=entry.sigma_dis)
+    assert len(exp) > 3 and got == exp
 
 
 def test_my_test_evaluation_harness(synth):
@@ -102,3 +169,38 @@ def test_device_side_resize_ingest(entry, synth):
     # identity size goes through the same kernel and must be the identity
     y_id = entry.net.forward_resized(small, (160, 128)).numpy()
     assert np.array_equal(y_id, y_ref)
+
+
+def test_c4_full_size_1080p_source_to_640x480(synth, res50_sd):
+    """BASELINE config 4 at its real sizes: a 1080 x 1920 u8 source frame resized on the GPU to the 640 x 480 network input
+    (iouTracke_cal.py:123).  The resized + mean-subtracted `input` tensor is bit-exact against the oracle's restatement of
+    cv2's 8-bit INTER_LINEAR path (cv2 parity itself unpinned); detections match the oracle's forward of the host-resized
+    frame within the north_star tolerance; the pipelined entry point gives the synchronous path's tracks."""
+    from oracle import ingest
+    from oracle import pyramidbox as opb
+    cal = M("iouTracke_cal")
+    old_net = cal.net
+    cal.load_net(res50_sd, 640, 480, which='repo')
+    try:
+        net = cal.net
+        net.detect = M("layers").Detect(2, 0, 750, 0.05, 0.35)
+        src = synth.make_frames(1, 1080, 1920, seed=1080)[0]
+        small = ingest.resize_linear_u8(src, 640, 480)
+        assert small.shape == (480, 640, 3)
+        y = net.forward_resized(src, (640, 480)).numpy()
+        assert np.array_equal(net.get_tensor("input")[0], opb.preprocess(small)[0])
+        exp = opb.detect_frame(res50_sd, small, "res50", detect=opp.Detect(2, 0, 750, 0.05, 0.35))
+        n = int((exp[0, 1, :, 0] > 0).sum())
+        assert n > 20 and int((y[0, 1, :, 0] > 0).sum()) == n
+        iou = opp.calculate_iou(exp[0, 1, :n, 1:].astype(np.float64), y[0, 1, :n, 1:].astype(np.float64))
+        assert (1 - iou.max(1)).max() <= 1e-3 and np.abs(y[0, 1, iou.argmax(1), 0] - exp[0, 1, :n, 0]).max() <= 1e-4
+        # and through the entry point: 1080p sources in, the committed 640x480 plan, three handles in flight
+        net.detect = M("layers").Detect(2, 0, 750, 0.3, 0.5)
+        srcs = [src, synth.make_frames(1, 1080, 1920, seed=1081)[0]]
+        seq = [srcs[i // 4] for i in range(8)]
+        t_pipe = cal.track(seq, size=(640, 480))
+        t_sync = cal.track(seq, size=(640, 480), pipelined=False)
+        assert t_pipe == t_sync
+    finally:
+        cal.net.close()
+        cal.net = old_net

@@ -374,6 +374,32 @@ def test_res50_640x640_vs_reference_fixture(res50, synth):
     np.testing.assert_allclose(res50.get_tensor("conf")[0, sel], d[key + "_conf_s0"], atol=SCORE_ATOL, rtol=0)
 
 
+def test_res50_native_1080p_vs_reference_fixture(res50, synth):
+    """BASELINE config 4's source size run natively (no resize): Res50 at 1080 x 1920 against the reference's own forward of
+    the same seeded frame (tests/golden/nets_r3.npz: P = 172 845 priors, 602 candidates, 390 detections), with the
+    committed plan bench.py uses for this shape."""
+    import os
+    d, meta = load_npz("nets_r3")
+    key = "res50_1080x1920_b1"
+    m = meta[key]
+    frame = synth.make_frames(1, 1080, 1920, seed=m["frame_seeds"][0])[0]
+    res50.priorbox = M("layers").PriorBoxLayer(1920, 1080); res50.firstTime = True
+    res50.detect = M("layers").Detect(2, 0, 750, m["conf_t"], m["nms_t"])
+    plan = res50.tuned_plan_text(1080, 1920, 1)
+    assert plan is not None
+    res50.import_plan(plan)
+    y = res50(frame).numpy()
+    assert int(res50.get_tensor("loc").shape[1]) == m["P"]
+    exp = d[key + "_out0"]
+    d_iou, d_sc = match_detections(y[0, 1], np.vstack([exp, np.zeros((750 - exp.shape[0], 5), np.float32)]),
+                                   m["n_out"][0])
+    assert d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL, (d_iou, d_sc)
+    sel = d[key + "_sel"]
+    np.testing.assert_allclose(res50.get_tensor("loc")[0, sel], d[key + "_loc_s0"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(res50.get_tensor("conf")[0, sel], d[key + "_conf_s0"], atol=SCORE_ATOL, rtol=0)
+    assert np.array_equal(res50(frame).numpy(), y)              # graph replay: same bits
+
+
 def test_try3_1024_batch8_vs_reference_fixture(try3, synth):
     """Config 3 of BASELINE.json: ONE batched forward of eight 1024x1024 frames (the depthwise / batched conv plan that
     bench.py --arch try3 --batch 8 times) against the reference's own batch-8 forward, per image."""

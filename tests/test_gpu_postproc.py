@@ -176,6 +176,36 @@ def test_pairwise_iou_bit_exact(nm):
     assert got.dtype == exp.dtype and np.array_equal(got, exp, equal_nan=True)
 
 
+@pytest.mark.parametrize("nm", ["f64", "f32"])
+def test_pairwise_distance_vs_reference_fixture(nm):
+    """calculate_distance (reference utils/calc_performance.py:34-51).  The reference's `dis ** 0.25` is numpy's pow --
+    faithful, not correctly rounded, and host dependent -- so parity is stated as 1 ulp; the kernel's own fourth root is
+    correctly rounded (checked against exact rational arithmetic on a sample)."""
+    from fractions import Fraction
+    d, _ = load_npz("distance")
+    a, b = d["dis_%s_a" % nm], d["dis_%s_b" % nm]
+    got = M("utils.calc_performance").calculate_distance(a, b)
+    exp = d["dis_%s_out" % nm]
+    assert got.dtype == exp.dtype and got.shape == exp.shape
+    it = np.int64 if nm == "f64" else np.int32
+    ulps = np.abs(got.view(it).astype(np.int64) - exp.view(it).astype(np.int64))
+    assert ulps.max() <= 1 and (ulps == 0).mean() > 0.8
+    assert got[5, 7] == 0 and got[6, 9] == 0
+    if nm == "f64":
+        # correctly rounded: no neighbouring double is closer to the exact fourth root of the f64 radicand
+        o = opp.calculate_distance(a, b)                      # only for the radicand's operand order
+        for i, j in [(0, 0), (3, 11), (17, 40), (40, 66), (22, 5)]:
+            ad, bd = a[i], b[j]
+            dz = ((ad[2] - ad[0]) - (bd[2] - bd[0]) + ((ad[3] - ad[1]) - (bd[3] - bd[1]))) / 2
+            dx = (bd[2] + bd[0]) / 2 - (ad[2] + ad[0]) / 2
+            dy = (bd[3] + bd[1]) / 2 - (ad[3] + ad[1]) / 2
+            x = Fraction(float(dz * dz + dx * dx + dy * dy))
+            y = float(got[i, j])
+            lo, hi = float(np.nextafter(y, -np.inf)), float(np.nextafter(y, np.inf))
+            assert ((Fraction(lo) + Fraction(y)) / 2) ** 4 <= x <= ((Fraction(y) + Fraction(hi)) / 2) ** 4, (i, j)
+            assert abs(o[i, j] - y) <= abs(y) * 2.3e-16
+
+
 def test_pairwise_iou_big_and_calc_pr():
     d, _ = load_npz("iou")
     cp = M("utils.calc_performance")
