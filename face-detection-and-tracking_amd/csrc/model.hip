@@ -185,6 +185,10 @@ struct fdt_model {
     if (stream) (void)hipStreamDestroy(stream);
   }
   void drop_graphs() {
+    // A replay may still be executing on a CALLER's stream (fdt_model_forward_dev / the pipeline's per-slot streams), which a
+    // synchronise of this handle's own stream does not cover: destroying a hipGraphExec_t under a replay in flight is a
+    // use-after-free inside the runtime (an intermittent host-side crash, not a kernel fault).  Plan changes are rare.
+    if (!graphs.empty()) (void)hipDeviceSynchronize();
     for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
     graphs.clear();
     graph_used.clear();
