@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfdt_hip.so")
+# FDT_LIB: another build of the same library (kernel experiments: tools/experiments/*_variants.sh); default = the in-tree one
+LIB_PATH = os.environ.get("FDT_LIB") or os.path.join(_HERE, "csrc", "libfdt_hip.so")
 
 FDT_OK = 0
 FDT_ERR_ARG, FDT_ERR_HIP, FDT_ERR_STATE, FDT_ERR_NAME = -1, -2, -3, -4

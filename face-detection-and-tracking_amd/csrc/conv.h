@@ -23,6 +23,7 @@ enum ConvKind {
   CONV_1x1_S1_K64,  // small-tile, deep-K layers)
   CONV_7x7_S2_P1,   // pad 1 (stem of pyramid_mb2_try4.py:16: conv_bn with a 7x7 kernel, padding left at 1)
   CONV_3x3_S1_N8,   // same arithmetic class as CONV_3x3_S1, 8 output channels per workgroup on the packed-f32 VALU (conv_n8.h)
+  CONV_3x3_S1_WINO44,  // same arithmetic class as CONV_3x3_S1, Winograd F(4x4,3x3): 36 taps, two input channels per stage (conv_wino44.h)
   CONV_KIND_COUNT
 };
 
@@ -66,6 +67,8 @@ enum ConvTile {
   TILE_WINO4_64x64W,
   // packed-f32 VALU kernel for narrow heads (only valid with CONV_3x3_S1_N8): 32x64 px, 8 ch
   TILE_N8_32x64,
+  // Winograd F(4x4,3x3) (only valid with CONV_3x3_S1_WINO44): 16x32 px (4 x 8 tiles of 4x4), 64 ch, eight waves
+  TILE_WINO44_32x64,
   CONV_TILE_COUNT
 };
 
@@ -73,7 +76,7 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2 };
 
 struct ConvGeom {   // static description of one kernel class
   int kh, kw, stride, dil, pad, kc;   // kc = input channels per LDS stage
-  int wino;                           // 1: weights are stored Winograd-transformed (16 taps)
+  int wino;                           // 1: weights are stored Winograd-transformed, F(2x2,3x3): 16 taps; 2: F(4x4,3x3): 36 taps
 };
 // The kind a layer's arithmetic belongs to (CONV_3x3_S1_WINO -> CONV_3x3_S1).
 ConvKind conv_base_kind(ConvKind k);

@@ -28,6 +28,7 @@
 
 #include "conv_kernel.h"
 #include "conv_wino.h"
+#include "conv_wino44.h"
 
 namespace fdt {
 namespace {
@@ -107,6 +108,7 @@ struct Table {
     conv_fill_wino_d2(e[CONV_3x3_D2_WINO]);
     conv_fill_1x1_s1_deep(e[CONV_1x1_S1_K32], e[CONV_1x1_S1_K64]);
     conv_fill_n8(e[CONV_3x3_S1_N8]);
+    conv_fill_wino44(e[CONV_3x3_S1_WINO44]);
   }
 };
 
@@ -119,7 +121,7 @@ const ConvGeom kGeoms[CONV_KIND_COUNT] = {
     {1, 1, 1, 1, 0, 16, 0}, {1, 1, 2, 1, 0, 16, 0}, {3, 3, 1, 1, 1, 4, 0}, {3, 3, 1, 2, 2, 4, 0},
     {3, 3, 2, 1, 1, 4, 0},  {7, 7, 2, 1, 3, 2, 0},  {7, 7, 4, 1, 3, 2, 0}, {5, 5, 2, 1, 2, 2, 0},
     {3, 3, 1, 1, 1, 8, 1},  {3, 3, 1, 2, 2, 8, 1},  {1, 1, 1, 1, 0, 32, 0},  {1, 1, 1, 1, 0, 64, 0},
-    {7, 7, 2, 1, 1, 2, 0},  {3, 3, 1, 1, 1, 1, 0},
+    {7, 7, 2, 1, 1, 2, 0},  {3, 3, 1, 1, 1, 1, 0},  {3, 3, 1, 1, 1, 2, 2},
 };
 const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum ConvTile)
     {128, 128, 8, 16}, {128, 64, 8, 16}, {128, 32, 8, 16}, {64, 64, 8, 8},   {64, 128, 8, 8},
@@ -135,7 +137,9 @@ const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum 
     // quarter-split Winograd
     {256, 64, 16, 16}, {256, 64, 8, 32},
     // packed-f32 VALU heads
-    {2048, 8, 32, 64}};
+    {2048, 8, 32, 64},
+    // Winograd F(4x4,3x3)
+    {512, 64, 16, 32}};
 
 }  // namespace
 
@@ -143,6 +147,7 @@ ConvGeom conv_geom(ConvKind k) { return kGeoms[k]; }
 ConvKind conv_base_kind(ConvKind k) {
   switch (k) {
     case CONV_3x3_S1_WINO:
+    case CONV_3x3_S1_WINO44:
     case CONV_3x3_S1_N8: return CONV_3x3_S1;
     case CONV_3x3_D2_WINO: return CONV_3x3_S1_D2;
     case CONV_1x1_S1_K32:
@@ -153,6 +158,7 @@ ConvKind conv_base_kind(ConvKind k) {
 bool tile_is_wino(ConvTile t) {
   return (t >= TILE_WINO_64x64 && t <= TILE_WINO8_64x64W) || t == TILE_WINO4_64x64R3 || t == TILE_WINO4_64x64W;
 }
+bool tile_is_wino44(ConvTile t) { return t == TILE_WINO44_32x64; }
 int tile_bm(ConvTile t) { return kTileDims[t][0]; }
 int tile_bn(ConvTile t) { return kTileDims[t][1]; }
 int tile_th(ConvTile t) { return kTileDims[t][2]; }
@@ -164,11 +170,12 @@ size_t conv_lds_bytes(ConvKind kind, ConvTile tile) { return table().e[kind][til
 void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKind kind, ConvTile tile,
                   std::vector<float>& out) {
   const ConvGeom g = conv_geom(kind);
-  const int ktaps = g.kh * g.kw, taps = g.wino ? 16 : ktaps, BN = tile_bn(tile), KC = g.kc;
+  const int ktaps = g.kh * g.kw, taps = g.wino == 2 ? 36 : g.wino ? 16 : ktaps, BN = tile_bn(tile), KC = g.kc;
   const int n_tiles = (Cout + BN - 1) / BN;
   const int nstages = (Cin + KC - 1) / KC;
   // Layout::WSZP (dwordx4 LDS-DMA granularity); the 8-channel VALU kernel stages exactly its 72 weights (N8::WSZ)
-  const size_t wszp = BN == 8 ? (size_t)KC * taps * BN : ((size_t)KC * taps * BN + 1023) / 1024 * 1024;
+  // ... and the F(4x4,3x3) kernel exactly its 2 x 36 x 64 (W44::WSZ: 2 x 8 KB + 2 KB of LDS-DMA per k-step)
+  const size_t wszp = (BN == 8 || g.wino == 2) ? (size_t)KC * taps * BN : ((size_t)KC * taps * BN + 1023) / 1024 * 1024;
   out.assign((size_t)n_tiles * nstages * wszp, 0.0f);
   for (int co = 0; co < Cout; ++co) {
     const float sc = scale ? scale[co] : 1.0f;
@@ -179,6 +186,19 @@ void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKin
       float* dst = out.data() + ((size_t)nt * nstages + s) * wszp + ((size_t)c * taps) * BN + n;
       if (!g.wino) {
         for (int t = 0; t < taps; ++t) dst[(size_t)t * BN] = src[t] * sc;
+      } else if (g.wino == 2) {
+        // F(4x4,3x3): U = G g G^T, G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1] (points 0, +-1,
+        // +-2, inf), in f64 with one rounding to f32
+        static const double G6[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                        {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+        double gk[3][3], tmp[6][3];
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) gk[i][j] = (double)src[i * 3 + j] * (double)sc;
+        for (int i = 0; i < 6; ++i)
+          for (int j = 0; j < 3; ++j) tmp[i][j] = G6[i][0] * gk[0][j] + G6[i][1] * gk[1][j] + G6[i][2] * gk[2][j];
+        for (int i = 0; i < 6; ++i)
+          for (int j = 0; j < 6; ++j)
+            dst[(size_t)(i * 6 + j) * BN] = (float)(tmp[i][0] * G6[j][0] + tmp[i][1] * G6[j][1] + tmp[i][2] * G6[j][2]);
       } else {
         // U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], in f64 with one rounding to f32
         double gk[3][3], tmp[4][3], U[4][4];
@@ -317,6 +337,7 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
     kind = alt;
   }
   if (kind == CONV_3x3_S1 && tile_is_wino((ConvTile)tile)) kind = CONV_3x3_S1_WINO;
+  if (kind == CONV_3x3_S1 && tile_is_wino44((ConvTile)tile)) kind = CONV_3x3_S1_WINO44;
   if (kind == CONV_3x3_S1_D2 && tile_is_wino((ConvTile)tile)) kind = CONV_3x3_D2_WINO;
   if (kind == CONV_3x3_S1 && tile == TILE_N8_32x64) kind = CONV_3x3_S1_N8;
   FDT_REQUIRE(tile >= 0 && tile < CONV_TILE_COUNT && conv_supported((ConvKind)kind, (ConvTile)tile), FDT_ERR_ARG,

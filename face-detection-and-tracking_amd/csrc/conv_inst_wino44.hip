@@ -1,0 +1,9 @@
+// Instantiation of the Winograd F(4x4,3x3) kernel.
+#include "conv_wino44.h"
+
+namespace fdt {
+void conv_fill_wino44(void* row) {
+  KernelEntry* r = (KernelEntry*)row;
+  r[TILE_WINO44_32x64] = wino44_entry<W44>();
+}
+}  // namespace fdt

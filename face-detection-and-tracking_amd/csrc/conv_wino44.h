@@ -1,0 +1,467 @@
+// conv_wino44.h -- Winograd F(4x4,3x3) variant of the 3x3 / stride 1 / pad 1 convolution on the f32 matrix cores:
+// 36 multiplies per 4x4 output tile instead of 144 (4x fewer MFMA FLOPs than the direct form, 1.78x fewer than the
+// F(2x2,3x3) kernels of conv_wino.h), exact-arithmetic equivalent of nn.Conv2d(k=3, s=1, p=1) up to the f32 rounding of the
+// transforms (measured 2.7e-6 relative RMS per layer against 4.3e-7 for F(2x2,3x3): the interpolation points 0, +-1, +-2
+// put factors up to 8 into A^T and 5 into B^T).
+//
+//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A        (per 4x4 output tile, per output channel; 6x6 = 36 positions)
+//
+// Why the F(2x2) design does not carry over, and what this one does instead:
+//  * 36 positions x (64 couts x 32 tiles) are 72 accumulator tiles of 32x32 -- 9 per wave with eight waves (144 registers,
+//    two waves per SIMD).  A wave therefore owns a GROUP OF POSITIONS (nine of the 36) for half of the couts, not a row of the
+//    grid, and cannot form its own B operands from the raw window: the input transform runs once per (tile, channel) --
+//    six waves each produce one ROW of B^T d B for all 32 tiles x 2 channels of a k-step (lane = (channel, tile), exactly the
+//    MFMA B-operand layout) and write it to a V buffer in LDS; all eight waves then read A (weights U) and B (V) from LDS.
+//  * Everything is pipelined by k-step (two input channels = one MFMA k-depth): at the barrier of k-step s the weights U(s),
+//    U(s+1) and the raw patch R(s+2) have landed (LDS-DMA rings of 4 / 3 slots, issued three / four k-steps ahead, counted
+//    vmcnt), V(s), V(s+1) are written, and the MFMA operands of k-step s already sit in registers (prefetched during k-step
+//    s-1) -- so nothing waits for LDS behind the barrier; during the nine MFMAs of k-step s a wave transforms its row for
+//    k-step s+2 and prefetches the operands of s+1.
+//  * The operand stream is 1.9x the F(2x2) kernel's per MFMA cycle (18 KB of weights + 5 KB of patch per 1152 matrix-pipe
+//    cycles of a SIMD pair): tools/microbench/ldsdma_feed.hip measured that the L2 -> LDS path sustains it (35 GB/s per CU
+//    beside 102-108 TFLOP/s of LDS-fed MFMAs).
+//  * Output transform: a wave folds its nine positions into two 4-vectors per accumulator element (the rows of M A it
+//    touches), the four position groups meet through LDS (two rounds of 128 KB), and every wave finishes whole 4x4 tiles of
+//    a quarter of the channels: bias / residual / ReLU and 16-byte row stores.
+#pragma once
+#include <type_traits>
+
+#include "conv_wino.h"
+
+namespace fdt {
+namespace {
+
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(f32x4& v, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536 && OFF % 16 == 0, "ds_read_b128 offset");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_b64(f32x2& v, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536 && OFF % 8 == 0, "ds_read_b64 offset");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+template <int O0, int O1>
+__device__ __forceinline__ void lds_write2st64_b32(unsigned addr, float x, float y) {   // offsets in units of 64 dwords
+  static_assert(O0 >= 0 && O0 < 256 && O1 >= 0 && O1 < 256, "ds_write2st64 offsets");
+  asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(x), "v"(y), "n"(O0), "n"(O1) : "memory");
+}
+
+struct W44 {
+  static constexpr int TTH = 4, TTW = 8;                 // 4 x 8 tiles of 4x4 outputs
+  static constexpr int TH = 4 * TTH, TW = 4 * TTW;       // 16 x 32 output pixels per workgroup
+  static constexpr int BN = 64;                          // output channels per workgroup
+  static constexpr int PH = TH + 2, PWU = TW + 2, PW = 36;   // staged patch: 18 rows of 34 pixels, row pitch 36 (16-byte rows)
+  static constexpr int XPLANE = PH * PW;                 // 648 floats per channel
+  static constexpr int XSZ = 2 * XPLANE;                 // two channels per k-step
+  static constexpr int XSZP = 1536;                      // 3 dword LDS-DMA instructions x 512 threads
+  static constexpr int WSZ = 2 * 36 * BN;                // 4608 floats of transformed weights per k-step: 2 x (8 waves x 1 KB) + 2 KB
+  static constexpr int VSZ = 36 * 64;                    // transformed input of a k-step: [position][channel][tile]
+  static constexpr int U_SLOTS = 4, R_SLOTS = 3, V_SLOTS = 3;
+  static constexpr int U0 = 0, R0 = U_SLOTS * WSZ, V0 = R0 + R_SLOTS * XSZP, RING = V0 + V_SLOTS * VSZ;
+  static constexpr int EXCH = 2 * 4 * 8 * 8 * 64;        // epilogue exchange: [cout half][group][8 regs][8 values][lane]
+  static constexpr size_t LDS_BYTES = (size_t)(RING > EXCH ? RING : EXCH) * sizeof(float);
+  static constexpr int LOADS = 6;                        // LDS-DMA instructions per wave per k-step (3 weights + 3 patch)
+  static_assert(XSZ <= XSZP && WSZ == 2 * 2048 + 512, "staging plan");
+};
+
+template <class T>
+__global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pg = wave >> 1, h = wave & 1;                  // MFMA role: positions 9 pg .. 9 pg + 8, couts 32 h .. 32 h + 31
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int tiles_x = (a.Wout + T::TW - 1) / T::TW;
+  FDT_BLOCK_MAP(a, sp_tile, n_tile);
+  const int oy0 = (sp_tile / tiles_x) * T::TH;
+  const int ox0 = (sp_tile % tiles_x) * T::TW;
+  const int b = blockIdx.z / a.ksplit;
+  const int ks = blockIdx.z - b * a.ksplit;
+
+  const int HW = a.Hin * a.Win;                            // stride 1, pad 1: Hout == Hin
+  const float* in_b = a.in + (long long)b * a.Cin * HW;
+  const int nstages = (a.Cin + 1) / 2;
+  const float* w_t = a.w + (long long)n_tile * nstages * T::WSZ;
+  const int s_begin = (int)((long long)nstages * ks / a.ksplit);
+  const int s_end = (int)((long long)nstages * (ks + 1) / a.ksplit);
+  const int nst = s_end - s_begin;
+
+  const float* zpad = g_zero_pad;
+  asm volatile("" : "+s"(zpad));
+  int goff[3];
+  unsigned okmask = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int e = tid + 512 * k;
+    const int c = e / T::XPLANE;
+    const int r = e - c * T::XPLANE;
+    const int yy = r / T::PW, xx = r - yy * T::PW;
+    const int gy = oy0 - 1 + yy, gx = ox0 - 1 + xx;
+    const bool ok = (e < T::XSZ) && xx < T::PWU && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+    goff[k] = ok ? (c * HW + gy * a.Win + gx) : 0;
+    if (ok) okmask |= (1u << k) | ((unsigned)c << (4 + k));   // bit k: in image; bit 4 + k: which of the two channels
+  }
+
+  // LDS-DMA of one k-step: weights U(su) into ring slot `us`, raw patch R(sr) into ring slot `rs`.  k-steps past the end of
+  // this workgroup's share are fetched from the zero word, so that the (always even) number of loop passes can run over them.
+  auto issue = [&](int su, int us, int sr, int rs) {
+    {
+      const bool v = su < nst;
+      const float* src = w_t + (long long)(s_begin + su) * T::WSZ;
+      float* U_ = smem + T::U0 + us * T::WSZ;
+      glds16(v ? src + wave * 256 + lane * 4 : zpad, U_ + wave * 256);
+      glds16(v ? src + 2048 + wave * 256 + lane * 4 : zpad, U_ + 2048 + wave * 256);
+      glds4(v ? src + 4096 + wave * 64 + lane : zpad, U_ + 4096 + wave * 64);
+    }
+    {
+      const bool v = sr < nst;
+      const int c0 = (s_begin + sr) * 2;
+      const float* src = in_b + (long long)c0 * HW;
+      const int crem = a.Cin - c0;
+      float* R_ = smem + T::R0 + rs * T::XSZP + wave * 64;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const bool ok = v && ((okmask >> k) & 1u) && (int)((okmask >> (4 + k)) & 1u) < crem;
+        glds4(ok ? src + goff[k] : zpad, R_ + 512 * k);
+      }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+  // transform role: lane = (channel = half, tile = l31); the tile's 6x6 window starts at (4 ty, 4 tx) of the staged patch
+  const int ty = l31 >> 3, tx = l31 & 7;
+  const unsigned xbase = lds0 + (unsigned)(T::R0 + half * T::XPLANE + 4 * ty * T::PW + 4 * tx) * 4u;
+  const unsigned vwbase = lds0 + (unsigned)(T::V0 + lane) * 4u;
+  // MFMA role
+  const unsigned abase = lds0 + (unsigned)(T::U0 + half * 36 * T::BN + pg * 9 * T::BN + h * 32 + l31) * 4u;
+  const unsigned bbase = lds0 + (unsigned)(T::V0 + pg * 9 * 64 + lane) * 4u;
+
+  struct Ops {
+    f32x2 a[4], b[4];
+    float a8, b8;
+  };
+  auto load_ops = [&](Ops& o, int us, int vs) {
+    const unsigned aa = abase + (unsigned)(us * T::WSZ) * 4u, bb = bbase + (unsigned)(vs * T::VSZ) * 4u;
+    lds_read2st64_b32<0, 1>(o.a[0], aa);
+    lds_read2st64_b32<0, 1>(o.b[0], bb);
+    lds_read2st64_b32<2, 3>(o.a[1], aa);
+    lds_read2st64_b32<2, 3>(o.b[1], bb);
+    lds_read2st64_b32<4, 5>(o.a[2], aa);
+    lds_read2st64_b32<4, 5>(o.b[2], bb);
+    lds_read2st64_b32<6, 7>(o.a[3], aa);
+    lds_read2st64_b32<6, 7>(o.b[3], bb);
+    lds_read_b32<8 * 256>(o.a8, aa);
+    lds_read_b32<8 * 256>(o.b8, bb);
+  };
+  constexpr int NOPS = 10;
+  auto wait_ops = [&](Ops& o, auto newer_c) {
+    constexpr int N_ = decltype(newer_c)::value;
+    asm volatile("s_waitcnt lgkmcnt(%10)"
+                 : "+v"(o.a[0]), "+v"(o.a[1]), "+v"(o.a[2]), "+v"(o.a[3]), "+v"(o.b[0]), "+v"(o.b[1]), "+v"(o.b[2]), "+v"(o.b[3]),
+                   "+v"(o.a8), "+v"(o.b8)
+                 : "n"(N_));
+  };
+  auto mfma_q = [&](const Ops& o, auto qc) {
+    constexpr int q = decltype(qc)::value;
+    if constexpr (q < 8)
+      acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[q >> 1][q & 1], o.b[q >> 1][q & 1], acc[q], 0, 0, 0);
+    else
+      acc[8] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a8, o.b8, acc[8], 0, 0, 0);
+  };
+
+  // One row of V = B^T d B for this lane's (channel, tile):  B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0;
+  //                                                                0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+  struct Raw {
+    f32x4 lo[4];      // columns 0..3 of the window rows this role needs
+    f32x2 hi[4];      // columns 4, 5
+  };
+  auto six = [](const float (&t)[6], float (&v)[6]) {   // v = B^T t
+    const float p = fmaf(-4.0f, t[2], t[4]), q = fmaf(-4.0f, t[1], t[3]);
+    const float c = t[4] - t[2], d = t[3] - t[1];
+    v[0] = fmaf(4.0f, t[0], fmaf(-5.0f, t[2], t[4]));
+    v[1] = p + q;
+    v[2] = p - q;
+    v[3] = fmaf(2.0f, d, c);
+    v[4] = fmaf(-2.0f, d, c);
+    v[5] = fmaf(4.0f, t[1], fmaf(-5.0f, t[3], t[5]));
+  };
+
+  auto main_loop = [&](auto role_c) {
+    constexpr int ROLE = decltype(role_c)::value;                  // 0..5: row of B^T d this wave produces; 6: none
+    constexpr int R0_ = (ROLE == 0) ? 0 : 1;                       // first window row needed
+    constexpr int RSTEP = (ROLE == 0 || ROLE == 5) ? 2 : 1;        // rows 0,2,4 / 1,2,3,4 / 1,3,5
+    constexpr int NROW = (ROLE == 0 || ROLE == 5) ? 3 : 4;
+    constexpr int NRAW = (ROLE < 6) ? 2 * NROW : 0;
+    auto raw_reads = [&](Raw& w, int rs) {
+      if constexpr (ROLE < 6) {
+        const unsigned xa = xbase + (unsigned)(rs * T::XSZP) * 4u;
+        lds_read_b128<(R0_ + 0 * RSTEP) * T::PW * 4>(w.lo[0], xa);
+        lds_read_b64<((R0_ + 0 * RSTEP) * T::PW + 4) * 4>(w.hi[0], xa);
+        lds_read_b128<(R0_ + 1 * RSTEP) * T::PW * 4>(w.lo[1], xa);
+        lds_read_b64<((R0_ + 1 * RSTEP) * T::PW + 4) * 4>(w.hi[1], xa);
+        lds_read_b128<(R0_ + 2 * RSTEP) * T::PW * 4>(w.lo[2], xa);
+        lds_read_b64<((R0_ + 2 * RSTEP) * T::PW + 4) * 4>(w.hi[2], xa);
+        if constexpr (NROW == 4) {
+          lds_read_b128<(R0_ + 3 * RSTEP) * T::PW * 4>(w.lo[3], xa);
+          lds_read_b64<((R0_ + 3 * RSTEP) * T::PW + 4) * 4>(w.hi[3], xa);
+        }
+      }
+    };
+    auto wait_raw = [&](Raw& w, auto newer_c) {
+      constexpr int N_ = decltype(newer_c)::value;
+      if constexpr (ROLE < 6) {
+        if constexpr (NROW == 4)
+          asm volatile("s_waitcnt lgkmcnt(%8)"
+                       : "+v"(w.lo[0]), "+v"(w.lo[1]), "+v"(w.lo[2]), "+v"(w.lo[3]), "+v"(w.hi[0]), "+v"(w.hi[1]), "+v"(w.hi[2]),
+                         "+v"(w.hi[3])
+                       : "n"(N_));
+        else
+          asm volatile("s_waitcnt lgkmcnt(%6)"
+                       : "+v"(w.lo[0]), "+v"(w.lo[1]), "+v"(w.lo[2]), "+v"(w.hi[0]), "+v"(w.hi[1]), "+v"(w.hi[2])
+                       : "n"(N_));
+      }
+    };
+    auto transform_store = [&](const Raw& w, int vs) {
+      if constexpr (ROLE < 6) {
+        float t[6], v[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          float d[4];
+#pragma unroll
+          for (int i = 0; i < NROW; ++i) d[i] = c < 4 ? w.lo[i][c] : w.hi[i][c - 4];
+          if constexpr (ROLE == 0 || ROLE == 5)
+            t[c] = fmaf(4.0f, d[0], fmaf(-5.0f, d[1], d[2]));            // 4 d0 - 5 d2 + d4   /   4 d1 - 5 d3 + d5
+          else if constexpr (ROLE == 1)
+            t[c] = fmaf(-4.0f, d[1], d[3]) + fmaf(-4.0f, d[0], d[2]);    // (d4 - 4 d2) + (d3 - 4 d1)
+          else if constexpr (ROLE == 2)
+            t[c] = fmaf(-4.0f, d[1], d[3]) - fmaf(-4.0f, d[0], d[2]);
+          else if constexpr (ROLE == 3)
+            t[c] = fmaf(2.0f, d[2] - d[0], d[3] - d[1]);                 // (d4 - d2) + 2 (d3 - d1)
+          else
+            t[c] = fmaf(-2.0f, d[2] - d[0], d[3] - d[1]);
+        }
+        six(t, v);
+        const unsigned va = vwbase + (unsigned)(vs * T::VSZ) * 4u;
+        lds_write2st64_b32<ROLE * 6 + 0, ROLE * 6 + 1>(va, v[0], v[1]);
+        lds_write2st64_b32<ROLE * 6 + 2, ROLE * 6 + 3>(va, v[2], v[3]);
+        lds_write2st64_b32<ROLE * 6 + 4, ROLE * 6 + 5>(va, v[4], v[5]);
+      }
+    };
+    using N0 = std::integral_constant<int, 0>;
+    using NOPS_C = std::integral_constant<int, NOPS>;
+
+    // ---- prologue: U(0), U(1), R(0), R(1), R(2); V(0), V(1); U(2), R(3) in flight; operands of k-step 0 in registers
+    issue(0, 0, 0, 0);
+    issue(1, 1, 1, 1);
+    issue(nst /* nothing */, 2, 2, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      Raw w0, w1;
+      raw_reads(w0, 0);
+      raw_reads(w1, 1);
+      wait_raw(w0, std::integral_constant<int, NRAW>{});
+      transform_store(w0, 0);
+      wait_raw(w1, std::integral_constant<int, (ROLE < 6 ? 3 : 0)>{});
+      transform_store(w1, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();          // V(0), V(1) visible; every wave is done with R(0), R(1)
+    __builtin_amdgcn_sched_barrier(0);
+    // U(2) (its slot was zero-filled by the third issue above, which only had a patch to fetch) and R(3) into the slot of R(0)
+    issue(2, 2, 3, 0);
+    Ops X, Y;
+    load_ops(X, 0, 0);
+    wait_ops(X, N0{});
+
+    // ---- k-step s: MFMAs on `cur` (registers), transform of s+2, operand prefetch of s+1, LDS-DMA of U(s+3) / R(s+4)
+#ifndef FDT_W44_EXP
+#define FDT_W44_EXP 0     // timing experiments (tools/experiments/w44_variants.sh): 1 no transform, 2 no barrier, 3 no LDS-DMA,
+#endif                    // 4 no MFMA, 5 no operand reads -- results are wrong for every value but 0
+    auto step = [&](Ops& cur, Ops& nxt, int s) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::LOADS) : "memory");     // everything but the previous k-step's issue has landed
+      if (FDT_W44_EXP != 2) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (FDT_W44_EXP != 3) issue(s + 3, (s + 3) & 3, s + 4, (s + 4) % 3);
+      Raw w;
+      if (FDT_W44_EXP != 1) raw_reads(w, (s + 2) % 3);
+      if (FDT_W44_EXP != 5) load_ops(nxt, (s + 1) & 3, (s + 1) % 3);
+      if (FDT_W44_EXP != 4) {
+        mfma_q(cur, std::integral_constant<int, 0>{});
+        mfma_q(cur, std::integral_constant<int, 1>{});
+        mfma_q(cur, std::integral_constant<int, 2>{});
+      }
+      if (FDT_W44_EXP != 1) {
+        if (FDT_W44_EXP != 5) wait_raw(w, NOPS_C{});
+        else wait_raw(w, N0{});
+        transform_store(w, (s + 2) % 3);
+      }
+      if (FDT_W44_EXP != 4) {
+        mfma_q(cur, std::integral_constant<int, 3>{});
+        mfma_q(cur, std::integral_constant<int, 4>{});
+        mfma_q(cur, std::integral_constant<int, 5>{});
+        mfma_q(cur, std::integral_constant<int, 6>{});
+        mfma_q(cur, std::integral_constant<int, 7>{});
+        mfma_q(cur, std::integral_constant<int, 8>{});
+      }
+      if (FDT_W44_EXP != 5) wait_ops(nxt, N0{});                          // also: this wave's V(s+2) writes are done
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    for (int s = 0; s < nst; s += 2) {
+      step(X, Y, s);
+      step(Y, X, s + 1);
+    }
+  };
+  switch (wave) {
+    case 0: main_loop(std::integral_constant<int, 0>{}); break;
+    case 1: main_loop(std::integral_constant<int, 1>{}); break;
+    case 2: main_loop(std::integral_constant<int, 2>{}); break;
+    case 3: main_loop(std::integral_constant<int, 3>{}); break;
+    case 4: main_loop(std::integral_constant<int, 4>{}); break;
+    case 5: main_loop(std::integral_constant<int, 5>{}); break;
+    default: main_loop(std::integral_constant<int, 6>{}); break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the zero-fill DMA of the k-steps past the end must not land in the exchange buffer
+
+  // ---- output transform Y = A^T M A,  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1] -----------------
+  // This wave holds positions 9 pg .. 9 pg + 8 of M, i.e. (pg even) row 3 pg / 2 whole + columns 0..2 of the next row, or
+  // (pg odd) columns 3..5 of row (3 pg - 1) / 2 + the next row whole.  Per accumulator element it forms the two 4-vectors
+  // (M A)[row] it contributes to (vA: first row touched, vB: second), and the groups exchange them through LDS.
+  auto full_row = [](float m0, float m1, float m2, float m3, float m4, float m5, float (&r)[4]) {
+    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+    r[0] = m0 + s1 + s2;
+    r[1] = fmaf(2.0f, d2, d1);
+    r[2] = fmaf(4.0f, s2, s1);
+    r[3] = fmaf(8.0f, d2, d1) + m5;
+  };
+  auto lo_row = [](float m0, float m1, float m2, float (&r)[4]) {     // columns 0..2
+    r[0] = m0 + m1 + m2;
+    r[1] = m1 - m2;
+    r[2] = m1 + m2;
+    r[3] = m1 - m2;
+  };
+  auto hi_row = [](float m3, float m4, float m5, float (&r)[4]) {     // columns 3..5
+    const float s2 = m3 + m4, d2 = m3 - m4;
+    r[0] = s2;
+    r[1] = 2.0f * d2;
+    r[2] = 4.0f * s2;
+    r[3] = fmaf(8.0f, d2, m5);
+  };
+  const int HWo = a.Hout * a.Wout;
+  const bool raw = a.ws != nullptr;
+  float* dst_b = raw ? a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWo
+                     : a.out + ((long long)b * a.out_ctot + a.out_coff) * HWo;
+  const float* res_b = (!raw && a.res) ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWo : nullptr;
+  const int oy = oy0 + 4 * ty, ox = ox0 + 4 * tx;
+  const bool vec4 = (a.Wout % 4 == 0);
+  float* E = smem;
+  for (int round = 0; round < 2; ++round) {
+    __syncthreads();                       // ring (round 0) / previous round's exchange data is dead
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      float vA[4], vB[4];
+      // (static indexing of acc: both rounds are spelled out through the ternaries on a compile-time rr)
+      const float m0 = round ? acc[0][8 + rr] : acc[0][rr], m1 = round ? acc[1][8 + rr] : acc[1][rr];
+      const float m2 = round ? acc[2][8 + rr] : acc[2][rr], m3 = round ? acc[3][8 + rr] : acc[3][rr];
+      const float m4 = round ? acc[4][8 + rr] : acc[4][rr], m5 = round ? acc[5][8 + rr] : acc[5][rr];
+      const float m6 = round ? acc[6][8 + rr] : acc[6][rr], m7 = round ? acc[7][8 + rr] : acc[7][rr];
+      const float m8 = round ? acc[8][8 + rr] : acc[8][rr];
+      if (pg & 1) {
+        hi_row(m0, m1, m2, vA);
+        full_row(m3, m4, m5, m6, m7, m8, vB);
+      } else {
+        full_row(m0, m1, m2, m3, m4, m5, vA);
+        lo_row(m6, m7, m8, vB);
+      }
+      float* e = E + (((h * 4 + pg) * 8 + rr) * 8) * 64 + lane;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        e[v * 64] = vA[v];
+        e[(4 + v) * 64] = vB[v];
+      }
+    }
+    __syncthreads();
+    // this wave finishes registers r = 8 round + 2 pg + {0, 1} of its cout half: whole 4x4 tiles
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rr = 2 * pg + j;
+      const int r = 8 * round + rr;
+      float R[6][4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        auto at = [&](int src, int val) { return E[(((h * 4 + src) * 8 + rr) * 8 + val) * 64 + lane]; };
+        R[0][v] = at(0, v);
+        R[1][v] = at(0, 4 + v) + at(1, v);
+        R[2][v] = at(1, 4 + v);
+        R[3][v] = at(2, v);
+        R[4][v] = at(2, 4 + v) + at(3, v);
+        R[5][v] = at(3, 4 + v);
+      }
+      const int co = n_tile * T::BN + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co >= a.Cout || ox >= a.Wout) continue;
+      const float bv = (!raw && a.bias) ? a.bias[co] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (oy + u >= a.Hout) continue;
+        float y[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const float s1 = R[1][v] + R[2][v], d1 = R[1][v] - R[2][v], s2 = R[3][v] + R[4][v], d2 = R[3][v] - R[4][v];
+          y[v] = u == 0 ? R[0][v] + s1 + s2 : u == 1 ? fmaf(2.0f, d2, d1) : u == 2 ? fmaf(4.0f, s2, s1) : fmaf(8.0f, d2, d1) + R[5][v];
+        }
+        const long long off = (long long)co * HWo + (long long)(oy + u) * a.Wout + ox;
+        if (vec4) {
+          float4 o = make_float4(y[0], y[1], y[2], y[3]);
+          if (!raw) {
+            o.x += bv; o.y += bv; o.z += bv; o.w += bv;
+            if (res_b) {
+              const float4 rv = *reinterpret_cast<const float4*>(res_b + off);
+              o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+            }
+            if (a.act == ACT_RELU) {
+              o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+            } else if (a.act == ACT_RELU6) {
+              o.x = fminf(fmaxf(o.x, 0.f), 6.f); o.y = fminf(fmaxf(o.y, 0.f), 6.f);
+              o.z = fminf(fmaxf(o.z, 0.f), 6.f); o.w = fminf(fmaxf(o.w, 0.f), 6.f);
+            }
+          }
+          *reinterpret_cast<float4*>(dst_b + off) = o;
+        } else {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            if (ox + v >= a.Wout) continue;
+            float o = y[v];
+            if (!raw) {
+              o += bv;
+              if (res_b) o += res_b[off + v];
+              if (a.act == ACT_RELU) o = fmaxf(o, 0.f);
+              else if (a.act == ACT_RELU6) o = fminf(fmaxf(o, 0.f), 6.f);
+            }
+            dst_b[off + v] = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <class T>
+KernelEntry wino44_entry() {
+  return KernelEntry{conv_wino44_kernel<T>, T::LDS_BYTES, 512};
+}
+
+}  // namespace
+
+void conv_fill_wino44(void* row);
+
+}  // namespace fdt

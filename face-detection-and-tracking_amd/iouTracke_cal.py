@@ -285,6 +285,8 @@ def _track_pipelined(frames, inflight, size, batch):
         torch.cuda.synchronize()
         return tracker.finish()
     finally:
+        for k, t, _ in pending:          # an exception mid-sequence: retire what is in flight so the handles stay usable
+            L.fdt_model_wait(nets[k]._h, t, None, None, None)
         if tracker is not None:
             torch.cuda.synchronize()
             tracker.close()

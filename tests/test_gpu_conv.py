@@ -15,8 +15,11 @@ KINDS = {  # name: (k, stride, pad, dil)
     "1x1s1": (1, 1, 0, 1), "1x1s2": (1, 2, 0, 1), "3x3s1": (3, 1, 1, 1), "3x3d2": (3, 1, 2, 2),
     "3x3s2": (3, 2, 1, 1), "7x7s2": (7, 2, 3, 1), "7x7s4": (7, 4, 3, 1), "5x5s2": (5, 2, 2, 1),
     "7x7s2p1": (7, 2, 1, 1)}
-N_TILES = 32      # 14 direct + 11 Winograd F(2x2,3x3) (3x3 s1 / d2 only) + 4 ring-of-four (1x1 only) + 2 quarter-split Winograd
-                  # + 1 packed-f32 VALU tile for narrow heads (3x3 s1 only)
+N_TILES = 33      # 14 direct + 11 Winograd F(2x2,3x3) (3x3 s1 / d2 only) + 4 ring-of-four (1x1 only) + 2 quarter-split Winograd
+                  # + 1 packed-f32 VALU tile for narrow heads (3x3 s1 only) + 1 Winograd F(4x4,3x3) (3x3 s1 only)
+T_WINO44 = 32
+WINO44_TOL = 1e-4  # F(4x4,3x3): factors up to 8 in A^T / 5 in B^T amplify the f32 rounding of the transforms (2.7e-6 relative RMS
+                  # per layer on post-ReLU data, up to ~3e-5 of the output's maximum on N(0,1) inputs)
 
 
 def lib():
@@ -77,7 +80,7 @@ def test_every_tile_variant_matches_torch(kind):
                     assert b"not instantiated" in msg or b"bad split-K" in msg, msg
                     continue
                 tested += 1
-                tol = 3e-5 if tile >= 14 else 1e-5       # Winograd variants: f32 rounding of the transforms
+                tol = WINO44_TOL if tile == T_WINO44 else 3e-5 if tile >= 14 else 1e-5   # Winograd: rounding of the transforms
                 assert rel_err(got, exp) < tol, (kind, tile, split, (Cin, H, W, Cout), rel_err(got, exp))
     assert tested >= 4
 
@@ -223,3 +226,26 @@ def test_fused_expand_depthwise(stride, shape):
     y = F.relu6(F.conv2d(h, torch.from_numpy(wd).reshape(hid, 1, 3, 3), torch.from_numpy(bd), stride, 1, 1, hid)).numpy()
     assert out.shape == y.shape
     assert rel_err(out, y) < 1e-5, (shape, stride, rel_err(out, y))
+
+
+@pytest.mark.parametrize("shape", [(64, 40, 48, 96), (37, 31, 45, 70), (7, 16, 32, 64), (256, 64, 64, 128), (2, 5, 3, 3)])
+def test_winograd_f4x4(shape):
+    """Winograd F(4x4,3x3) (conv_wino44.h): 4x fewer multiplies than the direct form.  Aligned and odd sizes (W % 4 != 0 ->
+    scalar stores; tiles hanging over the image; an odd number of input channels -> a zero-padded k-step; fewer k-steps
+    than the pipeline is deep), residual + ReLU, split-K 1 / 2 / 3, and the RMS error on a deep reduction."""
+    Cin, H, W, Cout = shape
+    rng = np.random.default_rng(H * 131 + Cin)
+    x = rng.standard_normal((2, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((2, Cout, H, W)).astype(np.float32)
+    for kw in (dict(act=0), dict(res=res, act=1), dict(act=2)):
+        exp = reference(x, w, b, 3, 1, 1, 1, **kw)
+        for split in (1, 2, 3):
+            if split > max(1, (Cin + 1) // 2):
+                continue
+            rc, got = run_conv(x, w, b, 3, 1, 1, 1, tile=T_WINO44, split=split, **kw)
+            assert rc == 0, lib().lib().fdt_last_error()
+            assert rel_err(got, exp) < WINO44_TOL, (shape, split, list(kw), rel_err(got, exp))
+            rms = float(np.sqrt(((got.astype(np.float64) - exp) ** 2).mean()) / np.sqrt((exp.astype(np.float64) ** 2).mean()))
+            assert rms < 1e-5, (shape, split, rms)
