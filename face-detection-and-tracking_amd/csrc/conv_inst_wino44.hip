@@ -4,6 +4,6 @@
 namespace fdt {
 void conv_fill_wino44(void* row) {
   KernelEntry* r = (KernelEntry*)row;
-  r[TILE_WINO44_32x64] = wino44_entry<W44>();
+  r[TILE_WINO44_32x64] = wino44_entry();
 }
 }  // namespace fdt

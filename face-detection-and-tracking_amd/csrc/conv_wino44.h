@@ -32,38 +32,52 @@ namespace fdt {
 namespace {
 
 template <int OFF>
-__device__ __forceinline__ void lds_read_b128(f32x4& v, unsigned addr) {
+__device__ __forceinline__ void w44_read_b128(f32x4& v, unsigned addr) {
   static_assert(OFF >= 0 && OFF < 65536 && OFF % 16 == 0, "ds_read_b128 offset");
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
 }
 template <int OFF>
-__device__ __forceinline__ void lds_read_b64(f32x2& v, unsigned addr) {
+__device__ __forceinline__ void w44_read_b64(f32x2& v, unsigned addr) {
   static_assert(OFF >= 0 && OFF < 65536 && OFF % 8 == 0, "ds_read_b64 offset");
   asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
 }
 template <int O0, int O1>
-__device__ __forceinline__ void lds_write2st64_b32(unsigned addr, float x, float y) {   // offsets in units of 64 dwords
+__device__ __forceinline__ void w44_write2st64_b32(unsigned addr, float x, float y) {   // offsets in units of 64 dwords
   static_assert(O0 >= 0 && O0 < 256 && O1 >= 0 && O1 < 256, "ds_write2st64 offsets");
   asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(x), "v"(y), "n"(O0), "n"(O1) : "memory");
 }
 
-struct W44 {
+// VEC: Win % 4 == 0 -- the patch is staged as 16-byte pieces of the aligned superset [ox0 - 4, ox0 + 36) of its columns (ONE
+// LDS-DMA instruction per wave and k-step instead of three dword ones); the odd-width variant stages it dword by dword.
+template <bool VEC_>
+struct W44T {
+  static constexpr bool VEC = VEC_;
   static constexpr int TTH = 4, TTW = 8;                 // 4 x 8 tiles of 4x4 outputs
   static constexpr int TH = 4 * TTH, TW = 4 * TTW;       // 16 x 32 output pixels per workgroup
   static constexpr int BN = 64;                          // output channels per workgroup
-  static constexpr int PH = TH + 2, PWU = TW + 2, PW = 36;   // staged patch: 18 rows of 34 pixels, row pitch 36 (16-byte rows)
-  static constexpr int XPLANE = PH * PW;                 // 648 floats per channel
+  static constexpr int PH = TH + 2, PWU = TW + 2;        // staged patch: 18 rows of 34 pixels ...
+  static constexpr int PW = VEC ? 40 : 36;               // ... at a row pitch of 40 (ten 16-byte pieces) / 36 floats
+  // VEC: piece j of a row holds columns ox0 - 4 + 4 j ..; the ring slot starts 4 bytes into its 16-byte unit, so that the
+  // window column 0 (= image column ox0 - 1 + 4 tx) sits at float 4 + 4 tx of the row: 16-byte aligned ds_read_b128
+  static constexpr int XSHIFT = VEC ? 1 : 0, XWIN = VEC ? 4 : 0;
+  static constexpr int XPLANE = PH * PW;                 // 720 / 648 floats per channel
   static constexpr int XSZ = 2 * XPLANE;                 // two channels per k-step
-  static constexpr int XSZP = 1536;                      // 3 dword LDS-DMA instructions x 512 threads
+  static constexpr int XPIECES = XSZ / 4;                // VEC: 360 pieces of 16 bytes = lanes of waves 0..5
+  static constexpr int XSZP = VEC ? 1600 : 1536;         // slot: 6 waves x 64 pieces + shift / 3 dword instructions x 512 threads
   static constexpr int WSZ = 2 * 36 * BN;                // 4608 floats of transformed weights per k-step: 2 x (8 waves x 1 KB) + 2 KB
   static constexpr int VSZ = 36 * 64;                    // transformed input of a k-step: [position][channel][tile]
   static constexpr int U_SLOTS = 4, R_SLOTS = 3, V_SLOTS = 3;
   static constexpr int U0 = 0, R0 = U_SLOTS * WSZ, V0 = R0 + R_SLOTS * XSZP, RING = V0 + V_SLOTS * VSZ;
   static constexpr int EXCH = 2 * 4 * 8 * 8 * 64;        // epilogue exchange: [cout half][group][8 regs][8 values][lane]
   static constexpr size_t LDS_BYTES = (size_t)(RING > EXCH ? RING : EXCH) * sizeof(float);
-  static constexpr int LOADS = 6;                        // LDS-DMA instructions per wave per k-step (3 weights + 3 patch)
-  static_assert(XSZ <= XSZP && WSZ == 2 * 2048 + 512, "staging plan");
+  // LDS-DMA instructions per wave per k-step.  VEC: two 1 KB pieces of the weights + (waves 0..5) the patch piece or (waves
+  // 6, 7) the last 2 KB of the weights; else 2 + 1 dword of weights + 3 dwords of patch
+  static constexpr int LOADS = VEC ? 3 : 6;
+  static_assert(WSZ == 2 * 2048 + 512 && (!VEC || (XPIECES <= 6 * 64 && XSHIFT + 6 * 64 * 4 <= XSZP)), "staging plan");
+  static_assert((R0 % 4) == 0 && (XSZP % 4) == 0 && (V0 % 4) == 0, "16-byte aligned LDS regions");
 };
+using W44 = W44T<true>;
+using W44odd = W44T<false>;
 
 template <class T>
 __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
@@ -91,40 +105,67 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
 
   const float* zpad = g_zero_pad;
   asm volatile("" : "+s"(zpad));
+  // ---- staging plan of the raw patch (the same for every k-step) ----------------------------------------------------------
+  // VEC: lane e = 64 wave + lane < 360 owns the 16-byte piece (channel c, patch row yy, piece j); its source pointer advances by
+  // two channel planes per k-step (rstep), or stays at the zero word for padding / out-of-image / spare lanes (rstep 0)
+  const float* rp = zpad;
+  unsigned rstep = 0;
+  bool rch1 = false;
   int goff[3];
   unsigned okmask = 0;
+  if constexpr (T::VEC) {
+    const int e = tid;
+    const int c = e / (T::XPLANE / 4);
+    const int r = e - c * (T::XPLANE / 4);
+    const int yy = r / (T::PW / 4), j = r - yy * (T::PW / 4);
+    const int gy = oy0 - 1 + yy, gx = ox0 - 4 + 4 * j;
+    if (e < T::XPIECES && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) {
+      rp = in_b + (long long)(2 * s_begin + c) * HW + gy * a.Win + gx;
+      rstep = 2u * (unsigned)HW * 4u;
+      rch1 = c == 1;
+    }
+  } else {
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int e = tid + 512 * k;
-    const int c = e / T::XPLANE;
-    const int r = e - c * T::XPLANE;
-    const int yy = r / T::PW, xx = r - yy * T::PW;
-    const int gy = oy0 - 1 + yy, gx = ox0 - 1 + xx;
-    const bool ok = (e < T::XSZ) && xx < T::PWU && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-    goff[k] = ok ? (c * HW + gy * a.Win + gx) : 0;
-    if (ok) okmask |= (1u << k) | ((unsigned)c << (4 + k));   // bit k: in image; bit 4 + k: which of the two channels
+    for (int k = 0; k < 3; ++k) {
+      const int e = tid + 512 * k;
+      const int c = e / T::XPLANE;
+      const int r = e - c * T::XPLANE;
+      const int yy = r / T::PW, xx = r - yy * T::PW;
+      const int gy = oy0 - 1 + yy, gx = ox0 - 1 + xx;
+      const bool ok = (e < T::XSZ) && xx < T::PWU && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+      goff[k] = ok ? (c * HW + gy * a.Win + gx) : 0;
+      if (ok) okmask |= (1u << k) | ((unsigned)c << (4 + k));   // bit k: in image; bit 4 + k: which of the two channels
+    }
   }
+  const bool cin_odd = (a.Cin & 1) != 0;
 
   // LDS-DMA of one k-step: weights U(su) into ring slot `us`, raw patch R(sr) into ring slot `rs`.  k-steps past the end of
-  // this workgroup's share are fetched from the zero word, so that the (always even) number of loop passes can run over them.
-  auto issue = [&](int su, int us, int sr, int rs) {
-    {
-      const bool v = su < nst;
-      const float* src = w_t + (long long)(s_begin + su) * T::WSZ;
-      float* U_ = smem + T::U0 + us * T::WSZ;
-      glds16(v ? src + wave * 256 + lane * 4 : zpad, U_ + wave * 256);
-      glds16(v ? src + 2048 + wave * 256 + lane * 4 : zpad, U_ + 2048 + wave * 256);
-      glds4(v ? src + 4096 + wave * 64 + lane : zpad, U_ + 4096 + wave * 64);
-    }
-    {
-      const bool v = sr < nst;
-      const int c0 = (s_begin + sr) * 2;
+  // this workgroup's share are clamped to its last one (valid addresses, the same instruction count; what they fetch is
+  // never consumed by an MFMA).
+  auto issue_w = [&](auto tail_c, int su, int us, int sr, int rs) {
+    constexpr bool TAILW = decltype(tail_c)::value;     // waves 6, 7: the last 2 KB of the weights instead of a patch piece
+    const int suc = su < nst ? su : nst - 1, src_ = sr < nst ? sr : nst - 1;
+    const float* usrc = w_t + (long long)(s_begin + suc) * T::WSZ;
+    float* U_ = smem + T::U0 + us * T::WSZ;
+    glds16(usrc + wave * 256 + lane * 4, U_ + wave * 256);
+    glds16(usrc + 2048 + wave * 256 + lane * 4, U_ + 2048 + wave * 256);
+    if constexpr (T::VEC) {
+      if constexpr (TAILW) {
+        glds16(usrc + 4096 + (wave - 6) * 256 + lane * 4, U_ + 4096 + (wave - 6) * 256);
+      } else {
+        const float* p = (const float*)((const char*)rp + (unsigned long long)src_ * rstep);
+        if (cin_odd && rch1 && s_begin + src_ == nstages - 1) p = zpad;      // the channel past an odd Cin
+        glds16(p, smem + T::R0 + rs * T::XSZP + T::XSHIFT + wave * 256);
+      }
+    } else {
+      glds4(usrc + 4096 + wave * 64 + lane, U_ + 4096 + wave * 64);
+      const int c0 = (s_begin + src_) * 2;
       const float* src = in_b + (long long)c0 * HW;
       const int crem = a.Cin - c0;
       float* R_ = smem + T::R0 + rs * T::XSZP + wave * 64;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const bool ok = v && ((okmask >> k) & 1u) && (int)((okmask >> (4 + k)) & 1u) < crem;
+        const bool ok = ((okmask >> k) & 1u) && (int)((okmask >> (4 + k)) & 1u) < crem;
         glds4(ok ? src + goff[k] : zpad, R_ + 512 * k);
       }
     }
@@ -139,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
   // transform role: lane = (channel = half, tile = l31); the tile's 6x6 window starts at (4 ty, 4 tx) of the staged patch
   const int ty = l31 >> 3, tx = l31 & 7;
-  const unsigned xbase = lds0 + (unsigned)(T::R0 + half * T::XPLANE + 4 * ty * T::PW + 4 * tx) * 4u;
+  const unsigned xbase = lds0 + (unsigned)(T::R0 + T::XWIN + half * T::XPLANE + 4 * ty * T::PW + 4 * tx) * 4u;
   const unsigned vwbase = lds0 + (unsigned)(T::V0 + lane) * 4u;
   // MFMA role
   const unsigned abase = lds0 + (unsigned)(T::U0 + half * 36 * T::BN + pg * 9 * T::BN + h * 32 + l31) * 4u;
@@ -162,7 +203,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     lds_read_b32<8 * 256>(o.a8, aa);
     lds_read_b32<8 * 256>(o.b8, bb);
   };
-  constexpr int NOPS = 10;
   auto wait_ops = [&](Ops& o, auto newer_c) {
     constexpr int N_ = decltype(newer_c)::value;
     asm volatile("s_waitcnt lgkmcnt(%10)"
@@ -184,17 +224,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     f32x4 lo[4];      // columns 0..3 of the window rows this role needs
     f32x2 hi[4];      // columns 4, 5
   };
-  auto six = [](const float (&t)[6], float (&v)[6]) {   // v = B^T t
-    const float p = fmaf(-4.0f, t[2], t[4]), q = fmaf(-4.0f, t[1], t[3]);
-    const float c = t[4] - t[2], d = t[3] - t[1];
-    v[0] = fmaf(4.0f, t[0], fmaf(-5.0f, t[2], t[4]));
-    v[1] = p + q;
-    v[2] = p - q;
-    v[3] = fmaf(2.0f, d, c);
-    v[4] = fmaf(-2.0f, d, c);
-    v[5] = fmaf(4.0f, t[1], fmaf(-5.0f, t[3], t[5]));
-  };
-
   auto main_loop = [&](auto role_c) {
     constexpr int ROLE = decltype(role_c)::value;                  // 0..5: row of B^T d this wave produces; 6: none
     constexpr int R0_ = (ROLE == 0) ? 0 : 1;                       // first window row needed
@@ -204,15 +233,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     auto raw_reads = [&](Raw& w, int rs) {
       if constexpr (ROLE < 6) {
         const unsigned xa = xbase + (unsigned)(rs * T::XSZP) * 4u;
-        lds_read_b128<(R0_ + 0 * RSTEP) * T::PW * 4>(w.lo[0], xa);
-        lds_read_b64<((R0_ + 0 * RSTEP) * T::PW + 4) * 4>(w.hi[0], xa);
-        lds_read_b128<(R0_ + 1 * RSTEP) * T::PW * 4>(w.lo[1], xa);
-        lds_read_b64<((R0_ + 1 * RSTEP) * T::PW + 4) * 4>(w.hi[1], xa);
-        lds_read_b128<(R0_ + 2 * RSTEP) * T::PW * 4>(w.lo[2], xa);
-        lds_read_b64<((R0_ + 2 * RSTEP) * T::PW + 4) * 4>(w.hi[2], xa);
+        w44_read_b128<(R0_ + 0 * RSTEP) * T::PW * 4>(w.lo[0], xa);
+        w44_read_b64<((R0_ + 0 * RSTEP) * T::PW + 4) * 4>(w.hi[0], xa);
+        w44_read_b128<(R0_ + 1 * RSTEP) * T::PW * 4>(w.lo[1], xa);
+        w44_read_b64<((R0_ + 1 * RSTEP) * T::PW + 4) * 4>(w.hi[1], xa);
+        w44_read_b128<(R0_ + 2 * RSTEP) * T::PW * 4>(w.lo[2], xa);
+        w44_read_b64<((R0_ + 2 * RSTEP) * T::PW + 4) * 4>(w.hi[2], xa);
         if constexpr (NROW == 4) {
-          lds_read_b128<(R0_ + 3 * RSTEP) * T::PW * 4>(w.lo[3], xa);
-          lds_read_b64<((R0_ + 3 * RSTEP) * T::PW + 4) * 4>(w.hi[3], xa);
+          w44_read_b128<(R0_ + 3 * RSTEP) * T::PW * 4>(w.lo[3], xa);
+          w44_read_b64<((R0_ + 3 * RSTEP) * T::PW + 4) * 4>(w.hi[3], xa);
         }
       }
     };
@@ -230,39 +259,69 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
                        : "n"(N_));
       }
     };
-    auto transform_store = [&](const Raw& w, int vs) {
+    // the row transform in pieces, so that the k-step can spread it between its MFMAs: t[c] (one column of B^T d at a time),
+    // then v = B^T t in two halves, then the three paired LDS writes
+    auto t_col = [&](const Raw& w, float (&t)[6], auto cc) {
+      constexpr int c = decltype(cc)::value;
       if constexpr (ROLE < 6) {
-        float t[6], v[6];
+        float d[4];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          float d[4];
-#pragma unroll
-          for (int i = 0; i < NROW; ++i) d[i] = c < 4 ? w.lo[i][c] : w.hi[i][c - 4];
-          if constexpr (ROLE == 0 || ROLE == 5)
-            t[c] = fmaf(4.0f, d[0], fmaf(-5.0f, d[1], d[2]));            // 4 d0 - 5 d2 + d4   /   4 d1 - 5 d3 + d5
-          else if constexpr (ROLE == 1)
-            t[c] = fmaf(-4.0f, d[1], d[3]) + fmaf(-4.0f, d[0], d[2]);    // (d4 - 4 d2) + (d3 - 4 d1)
-          else if constexpr (ROLE == 2)
-            t[c] = fmaf(-4.0f, d[1], d[3]) - fmaf(-4.0f, d[0], d[2]);
-          else if constexpr (ROLE == 3)
-            t[c] = fmaf(2.0f, d[2] - d[0], d[3] - d[1]);                 // (d4 - d2) + 2 (d3 - d1)
-          else
-            t[c] = fmaf(-2.0f, d[2] - d[0], d[3] - d[1]);
-        }
-        six(t, v);
-        const unsigned va = vwbase + (unsigned)(vs * T::VSZ) * 4u;
-        lds_write2st64_b32<ROLE * 6 + 0, ROLE * 6 + 1>(va, v[0], v[1]);
-        lds_write2st64_b32<ROLE * 6 + 2, ROLE * 6 + 3>(va, v[2], v[3]);
-        lds_write2st64_b32<ROLE * 6 + 4, ROLE * 6 + 5>(va, v[4], v[5]);
+        for (int i = 0; i < NROW; ++i) d[i] = c < 4 ? w.lo[i][c < 4 ? c : 0] : w.hi[i][c < 4 ? 0 : c - 4];
+        if constexpr (ROLE == 0 || ROLE == 5)
+          t[c] = fmaf(4.0f, d[0], fmaf(-5.0f, d[1], d[2]));            // 4 d0 - 5 d2 + d4   /   4 d1 - 5 d3 + d5
+        else if constexpr (ROLE == 1)
+          t[c] = fmaf(-4.0f, d[1], d[3]) + fmaf(-4.0f, d[0], d[2]);    // (d4 - 4 d2) + (d3 - 4 d1)
+        else if constexpr (ROLE == 2)
+          t[c] = fmaf(-4.0f, d[1], d[3]) - fmaf(-4.0f, d[0], d[2]);
+        else if constexpr (ROLE == 3)
+          t[c] = fmaf(2.0f, d[2] - d[0], d[3] - d[1]);                 // (d4 - d2) + 2 (d3 - d1)
+        else
+          t[c] = fmaf(-2.0f, d[2] - d[0], d[3] - d[1]);
       }
     };
+    auto v_lo = [&](const float (&t)[6], float (&v)[6]) {              // v0, v1, v2 of v = B^T t
+      if constexpr (ROLE < 6) {
+        const float p = fmaf(-4.0f, t[2], t[4]), q = fmaf(-4.0f, t[1], t[3]);
+        v[0] = fmaf(4.0f, t[0], fmaf(-5.0f, t[2], t[4]));
+        v[1] = p + q;
+        v[2] = p - q;
+      }
+    };
+    auto v_hi = [&](const float (&t)[6], float (&v)[6]) {              // v3, v4, v5
+      if constexpr (ROLE < 6) {
+        const float c = t[4] - t[2], d = t[3] - t[1];
+        v[3] = fmaf(2.0f, d, c);
+        v[4] = fmaf(-2.0f, d, c);
+        v[5] = fmaf(4.0f, t[1], fmaf(-5.0f, t[3], t[5]));
+      }
+    };
+    auto v_store = [&](const float (&v)[6], int vs) {
+      if constexpr (ROLE < 6) {
+        const unsigned va = vwbase + (unsigned)(vs * T::VSZ) * 4u;
+        w44_write2st64_b32<ROLE * 6 + 0, ROLE * 6 + 1>(va, v[0], v[1]);
+        w44_write2st64_b32<ROLE * 6 + 2, ROLE * 6 + 3>(va, v[2], v[3]);
+        w44_write2st64_b32<ROLE * 6 + 4, ROLE * 6 + 5>(va, v[4], v[5]);
+      }
+    };
+    auto transform_store = [&](const Raw& w, int vs) {
+      float t[6], v[6];
+      t_col(w, t, std::integral_constant<int, 0>{});
+      t_col(w, t, std::integral_constant<int, 1>{});
+      t_col(w, t, std::integral_constant<int, 2>{});
+      t_col(w, t, std::integral_constant<int, 3>{});
+      t_col(w, t, std::integral_constant<int, 4>{});
+      t_col(w, t, std::integral_constant<int, 5>{});
+      v_lo(t, v);
+      v_hi(t, v);
+      v_store(v, vs);
+    };
+    auto issue = [&](int su, int us, int sr, int rs) { issue_w(std::bool_constant<ROLE == 6>{}, su, us, sr, rs); };
     using N0 = std::integral_constant<int, 0>;
-    using NOPS_C = std::integral_constant<int, NOPS>;
 
     // ---- prologue: U(0), U(1), R(0), R(1), R(2); V(0), V(1); U(2), R(3) in flight; operands of k-step 0 in registers
     issue(0, 0, 0, 0);
     issue(1, 1, 1, 1);
-    issue(nst /* nothing */, 2, 2, 2);
+    issue(2, 2, 2, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -278,49 +337,74 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     }
     __builtin_amdgcn_s_barrier();          // V(0), V(1) visible; every wave is done with R(0), R(1)
     __builtin_amdgcn_sched_barrier(0);
-    // U(2) (its slot was zero-filled by the third issue above, which only had a patch to fetch) and R(3) into the slot of R(0)
-    issue(2, 2, 3, 0);
+    issue(2, 2, 3, 0);                     // R(3) into the slot of R(0) (U(2) once more: one instruction count per issue)
     Ops X, Y;
     load_ops(X, 0, 0);
     wait_ops(X, N0{});
 
     // ---- k-step s: MFMAs on `cur` (registers), transform of s+2, operand prefetch of s+1, LDS-DMA of U(s+3) / R(s+4)
 #ifndef FDT_W44_EXP
-#define FDT_W44_EXP 0     // timing experiments (tools/experiments/w44_variants.sh): 1 no transform, 2 no barrier, 3 no LDS-DMA,
-#endif                    // 4 no MFMA, 5 no operand reads -- results are wrong for every value but 0
+#define FDT_W44_EXP 0     // timing experiments (tools/experiments/w44_variants.sh), a bit mask: 1 no input transform, 2 no barrier,
+#endif                    // 4 no LDS-DMA in the loop, 8 no MFMA, 16 no operand reads -- results are wrong for every value but 0
+    // A wave issues in order and stalls at an MFMA while the matrix pipe is taken (by its own previous MFMA or by the other
+    // wave of the SIMD), so whatever stands behind a block of MFMAs in program order waits for all of them: the k-step
+    // therefore spreads its non-matrix work (window-read wait, the row transform in pieces, the V writes) BETWEEN its nine
+    // MFMAs, in chunks short enough to issue while the pipe executes; sched_barrier pins the order.
+    auto mf = [&](Ops& cur, auto qc) {
+      if (!(FDT_W44_EXP & 8)) mfma_q(cur, qc);
+      __builtin_amdgcn_sched_barrier(0);
+    };
     auto step = [&](Ops& cur, Ops& nxt, int s) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::LOADS) : "memory");     // everything but the previous k-step's issue has landed
-      if (FDT_W44_EXP != 2) __builtin_amdgcn_s_barrier();
+      if (!(FDT_W44_EXP & 2)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (FDT_W44_EXP != 3) issue(s + 3, (s + 3) & 3, s + 4, (s + 4) % 3);
+      // Right behind the barrier all eight waves queue their LDS reads at once; only the window reads go there (their data is
+      // needed first), four MFMAs stand between them and the wait, and the operand prefetch of the next k-step is issued late.
       Raw w;
-      if (FDT_W44_EXP != 1) raw_reads(w, (s + 2) % 3);
-      if (FDT_W44_EXP != 5) load_ops(nxt, (s + 1) & 3, (s + 1) % 3);
-      if (FDT_W44_EXP != 4) {
-        mfma_q(cur, std::integral_constant<int, 0>{});
-        mfma_q(cur, std::integral_constant<int, 1>{});
-        mfma_q(cur, std::integral_constant<int, 2>{});
+      if (!(FDT_W44_EXP & 1)) raw_reads(w, (s + 2) % 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mf(cur, std::integral_constant<int, 0>{});
+      if (!(FDT_W44_EXP & 4)) issue(s + 3, (s + 3) & 3, s + 4, (s + 4) % 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mf(cur, std::integral_constant<int, 1>{});
+      mf(cur, std::integral_constant<int, 2>{});
+      mf(cur, std::integral_constant<int, 3>{});
+      float t[6], v[6];
+      if (!(FDT_W44_EXP & 1)) {
+        wait_raw(w, N0{});
+        t_col(w, t, std::integral_constant<int, 0>{});
+        t_col(w, t, std::integral_constant<int, 1>{});
+        t_col(w, t, std::integral_constant<int, 2>{});
       }
-      if (FDT_W44_EXP != 1) {
-        if (FDT_W44_EXP != 5) wait_raw(w, NOPS_C{});
-        else wait_raw(w, N0{});
-        transform_store(w, (s + 2) % 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mf(cur, std::integral_constant<int, 4>{});
+      if (!(FDT_W44_EXP & 1)) {
+        t_col(w, t, std::integral_constant<int, 3>{});
+        t_col(w, t, std::integral_constant<int, 4>{});
+        t_col(w, t, std::integral_constant<int, 5>{});
       }
-      if (FDT_W44_EXP != 4) {
-        mfma_q(cur, std::integral_constant<int, 3>{});
-        mfma_q(cur, std::integral_constant<int, 4>{});
-        mfma_q(cur, std::integral_constant<int, 5>{});
-        mfma_q(cur, std::integral_constant<int, 6>{});
-        mfma_q(cur, std::integral_constant<int, 7>{});
-        mfma_q(cur, std::integral_constant<int, 8>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mf(cur, std::integral_constant<int, 5>{});
+      if (!(FDT_W44_EXP & 1)) {
+        v_lo(t, v);
+        v_hi(t, v);
       }
-      if (FDT_W44_EXP != 5) wait_ops(nxt, N0{});                          // also: this wave's V(s+2) writes are done
+      __builtin_amdgcn_sched_barrier(0);
+      mf(cur, std::integral_constant<int, 6>{});
+      if (!(FDT_W44_EXP & 1)) v_store(v, (s + 2) % 3);
+      if (!(FDT_W44_EXP & 16)) load_ops(nxt, (s + 1) & 3, (s + 1) % 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mf(cur, std::integral_constant<int, 7>{});
+      mf(cur, std::integral_constant<int, 8>{});
+      if (!(FDT_W44_EXP & 16)) wait_ops(nxt, N0{});                       // also: this wave's V(s+2) writes are done
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
-    for (int s = 0; s < nst; s += 2) {
+    int s = 0;
+    for (; s + 1 < nst; s += 2) {
       step(X, Y, s);
       step(Y, X, s + 1);
     }
+    if (s < nst) step(X, Y, s);
   };
   switch (wave) {
     case 0: main_loop(std::integral_constant<int, 0>{}); break;
@@ -331,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     case 5: main_loop(std::integral_constant<int, 5>{}); break;
     default: main_loop(std::integral_constant<int, 6>{}); break;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the zero-fill DMA of the k-steps past the end must not land in the exchange buffer
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the (clamped) LDS-DMA of the k-steps past the end must not land in the exchange buffer
 
   // ---- output transform Y = A^T M A,  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1] -----------------
   // This wave holds positions 9 pg .. 9 pg + 8 of M, i.e. (pg even) row 3 pg / 2 whole + columns 0..2 of the next row, or
@@ -455,9 +539,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
   }
 }
 
-template <class T>
-KernelEntry wino44_entry() {
-  return KernelEntry{conv_wino44_kernel<T>, T::LDS_BYTES, 512};
+inline KernelEntry wino44_entry() {
+  static_assert(W44::LDS_BYTES == W44odd::LDS_BYTES, "one dynamic-LDS size for both width classes");
+  return KernelEntry{conv_wino44_kernel<W44>, W44::LDS_BYTES, 512, conv_wino44_kernel<W44odd>};
 }
 
 }  // namespace

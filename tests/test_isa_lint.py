@@ -17,6 +17,7 @@ CSRC = os.path.join(ROOT, "face-detection-and-tracking_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 SRC = """#include "conv_wino.h"
+#include "conv_wino44.h"
 #include "conv_n8.h"
 namespace fdt { namespace {
 template __global__ void conv_wino2_kernel<W_64x64W>(const ConvArgs);       // 3x3 pad 1, 8x32-pixel tile
@@ -24,6 +25,9 @@ template __global__ void conv_wino2_kernel<W_128x32R3>(const ConvArgs);     // 3
 template __global__ void conv_wino2_kernel<WD2_64x64W>(const ConvArgs);     // dilation 2
 template __global__ void conv_wino4_kernel<W_64x64W>(const ConvArgs);       // quarter-split form
 template __global__ void conv_wino4_kernel<WD2_64x64R3>(const ConvArgs);
+// Winograd F(4x4,3x3) (conv_wino44.h): window reads, operand prefetch and V writes all hand-issued, seven role instances
+template __global__ void conv_wino44_kernel<W44>(const ConvArgs);
+template __global__ void conv_wino44_kernel<W44odd>(const ConvArgs);
 // the direct kernel's pipelined main loop (conv_kernel.h): 1 + 1, 2 + 1 and 2 + 2 operand registers per step
 template __global__ void conv_kernel<G_1x1_S1_K32, T_64x64>(const ConvArgs);
 template __global__ void conv_kernel<G_1x1_S1, T_128x64W>(const ConvArgs);
@@ -52,6 +56,10 @@ def test_async_lds_reads_have_no_hazards(tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert ": 0 hazards" in r.stdout
+    # conv_wino44_kernel: 9 accumulator tiles + two operand sets + the window rows must fit two waves per SIMD without spills
+    for nm in ("conv_wino44_kernelINS0_4W44TILb1EEEEEvNS_8ConvArgsE", "conv_wino44_kernelINS0_4W44TILb0EEEEEvNS_8ConvArgsE"):
+        meta44 = text.split(".name:           _ZN3fdt12_GLOBAL__N_118" + nm, 1)[1][:1500]
+        assert ".vgpr_spill_count: 0" in meta44 and int(meta44.split(".vgpr_count:")[1].split()[0]) <= 256
     # conv_n8_kernel<true>: a spill reloaded inside its loop would carry a vmcnt(0) that serialises the LDS-DMA pipeline
     # (measured: no load/compute overlap at all) -- the fast variant must stay spill-free at four waves per SIMD
     body = text.split("conv_n8_kernelILb1EEEvNS_8ConvArgsE:", 1)[1].split("s_endpgm", 1)[0]

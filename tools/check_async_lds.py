@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Lint for the hand-issued LDS reads of the conv kernels: the 8-wave Winograd kernels (conv_wino.h: conv_wino2_kernel,
-conv_wino4_kernel), the direct implicit-GEMM kernel (conv_kernel.h: conv_kernel) and the vector-ALU head kernel (conv_n8.h).
+conv_wino4_kernel; conv_wino44.h: conv_wino44_kernel), the direct implicit-GEMM kernel (conv_kernel.h: conv_kernel) and the vector-ALU head kernel (conv_n8.h).
 
 The main loop issues ds_read* through inline asm and waits with `s_waitcnt lgkmcnt(N)`, so the compiler does not
 know those registers are written asynchronously.  This scans gfx950 assembly (hipcc -S --cuda-device-only) and
@@ -29,7 +29,8 @@ def main(path):
         m = re.match(r"^(_Z\S+):", line)
         if m:
             kernel, pending = m.group(1), []
-            in_wino2 = "conv_wino2_kernel" in kernel or "conv_wino4_kernel" in kernel or "11conv_kernelI" in kernel or "conv_n8_kernel" in kernel
+            in_wino2 = ("conv_wino2_kernel" in kernel or "conv_wino4_kernel" in kernel or "conv_wino44_kernel" in kernel or
+                        "11conv_kernelI" in kernel or "conv_n8_kernel" in kernel)
             continue
         if not in_wino2:
             continue
@@ -49,6 +50,15 @@ def main(path):
                     print("%s:%d: %s uses a register of an outstanding ds_read: %s" % (path, ln, kernel[:60], code))
                     bad += 1
             pending.append(dst)
+            continue
+        if op.startswith("ds_write"):
+            # LDS writes count in lgkmcnt too and complete in order with the reads: an entry without registers
+            for d in pending:
+                if touched & d:
+                    print("%s:%d: %s stores a register of an outstanding ds_read: %s" % (path, ln, kernel[:60], code))
+                    bad += 1
+                    break
+            pending.append(set())
             continue
         m = re.match(r"s_waitcnt.*lgkmcnt\((\d+)\)", code)
         if m:
