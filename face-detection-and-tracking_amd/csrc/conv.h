@@ -69,6 +69,7 @@ enum ConvTile {
   TILE_N8_32x64,
   // Winograd F(4x4,3x3) (only valid with CONV_3x3_S1_WINO44): 16x32 px (4 x 8 tiles of 4x4), 64 ch, eight waves
   TILE_WINO44_32x64,
+  TILE_WINO44B_32x64,  // twelve waves: a wave owns half a row of the position grid and forms its own B operands (no V buffer)
   CONV_TILE_COUNT
 };
 

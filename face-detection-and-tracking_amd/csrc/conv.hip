@@ -138,8 +138,8 @@ const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum 
     {256, 64, 16, 16}, {256, 64, 8, 32},
     // packed-f32 VALU heads
     {2048, 8, 32, 64},
-    // Winograd F(4x4,3x3)
-    {512, 64, 16, 32}};
+    // Winograd F(4x4,3x3): eight waves, twelve waves
+    {512, 64, 16, 32}, {512, 64, 16, 32}};
 
 }  // namespace
 
@@ -158,7 +158,7 @@ ConvKind conv_base_kind(ConvKind k) {
 bool tile_is_wino(ConvTile t) {
   return (t >= TILE_WINO_64x64 && t <= TILE_WINO8_64x64W) || t == TILE_WINO4_64x64R3 || t == TILE_WINO4_64x64W;
 }
-bool tile_is_wino44(ConvTile t) { return t == TILE_WINO44_32x64; }
+bool tile_is_wino44(ConvTile t) { return t == TILE_WINO44_32x64 || t == TILE_WINO44B_32x64; }
 int tile_bm(ConvTile t) { return kTileDims[t][0]; }
 int tile_bn(ConvTile t) { return kTileDims[t][1]; }
 int tile_th(ConvTile t) { return kTileDims[t][2]; }
@@ -277,7 +277,8 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
                                                             : (long long)tiles * n_ct;
   FDT_REQUIRE(gx <= 0x7fffffffll && (long long)a.B * a.ksplit <= 65535, FDT_ERR_ARG, "launch_conv: grid too large");
   dim3 grid((unsigned)gx, 1, a.B * a.ksplit);
-  hipLaunchKernelGGL((ke.fn_odd && (a.Win & 3)) ? ke.fn_odd : ke.fn, grid, dim3(ke.threads), ke.lds, st, a);
+  const bool odd = ke.fn_odd && (a.Win & 3);
+  hipLaunchKernelGGL(odd ? ke.fn_odd : ke.fn, grid, dim3(odd && ke.threads_odd ? ke.threads_odd : ke.threads), ke.lds, st, a);
   FDT_LAUNCH_CHECK();
   if (a.ws) {
     const long long total = (long long)a.B * a.Cout * a.Hout * a.Wout;

@@ -5,5 +5,6 @@ namespace fdt {
 void conv_fill_wino44(void* row) {
   KernelEntry* r = (KernelEntry*)row;
   r[TILE_WINO44_32x64] = wino44_entry();
+  r[TILE_WINO44B_32x64] = wino44b_entry();
 }
 }  // namespace fdt

@@ -406,6 +406,7 @@ struct KernelEntry {
   size_t lds;
   int threads = 256;
   void (*fn_odd)(const ConvArgs) = nullptr;   // variant for Win % 4 != 0, where the class has one (conv_n8.h)
+  int threads_odd = 0;                        // its block size where that differs (0: the same)
 };
 
 //                     TH  TW  BN  WM WN NBUF

@@ -539,9 +539,358 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Twelve-wave form (three waves per SIMD).  The eight-wave kernel above measured as the SUM of its matrix time and its
+// non-matrix time per k-step (tools/experiments/w44_variants.sh: MFMAs alone 166 us, everything else alone 152 us, together
+// 288 us on 256 -> 256 @ 256x256): a wave that has issued an MFMA does not get to its other work while the pipe is busy, and
+// with two waves per SIMD nobody else does either.  Here a wave owns HALF A ROW of the 6x6 position grid (three positions) for
+// all 64 couts of the workgroup -- six accumulator tiles, 96 registers, so three waves fit a SIMD -- and
+//  * forms its own three B operands in registers from the raw window (lane = (channel, tile) is the MFMA B layout): the V
+//    buffer, its LDS writes and the B-operand reads are gone; a B operand feeds two MFMAs (both cout halves);
+//  * every wave does the same work per k-step: 6-8 window reads, ~20 VALU of transform, 4 weight reads, 2 LDS-DMA
+//    instructions, 6 MFMAs -- no idle roles, no two-wave imbalance per SIMD;
+//  * one barrier per k-step as before: at the barrier of k-step s the weights U(s+1) and the patch R(s+1) have landed (rings
+//    of three slots, issued two k-steps ahead), A(s) and B(s) sit in registers; k-step s runs its six MFMAs while it reads
+//    the window of s+1, transforms it into B(s+1) and prefetches A(s+1).
+template <class T>
+__global__ __launch_bounds__(768, 3) void conv_wino44b_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(T::VEC, "the twelve-wave form stages the patch as 16-byte pieces (Win % 4 == 0)");
+  constexpr int U0 = 0, US = 3, R0 = US * T::WSZ, RS = 3;                   // rings of three slots
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                // 0..11
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int tiles_x = (a.Wout + T::TW - 1) / T::TW;
+  FDT_BLOCK_MAP(a, sp_tile, n_tile);
+  const int oy0 = (sp_tile / tiles_x) * T::TH;
+  const int ox0 = (sp_tile % tiles_x) * T::TW;
+  const int b = blockIdx.z / a.ksplit;
+  const int ks = blockIdx.z - b * a.ksplit;
+
+  const int HW = a.Hin * a.Win;
+  const float* in_b = a.in + (long long)b * a.Cin * HW;
+  const int nstages = (a.Cin + 1) / 2;
+  const float* w_t = a.w + (long long)n_tile * nstages * T::WSZ;
+  const int s_begin = (int)((long long)nstages * ks / a.ksplit);
+  const int s_end = (int)((long long)nstages * (ks + 1) / a.ksplit);
+  const int nst = s_end - s_begin;
+
+  const float* zpad = g_zero_pad;
+  asm volatile("" : "+s"(zpad));
+  // patch staging: waves 6..11, lane e = 64 (wave - 6) + lane < 360 owns one 16-byte piece (see the eight-wave kernel)
+  const float* rp = zpad;
+  unsigned rstep = 0;
+  bool rch1 = false;
+  if (wave >= 6) {
+    const int e = tid - 384;
+    const int c = e / (T::XPLANE / 4);
+    const int r = e - c * (T::XPLANE / 4);
+    const int yy = r / (T::PW / 4), j = r - yy * (T::PW / 4);
+    const int gy = oy0 - 1 + yy, gx = ox0 - 4 + 4 * j;
+    if (e < T::XPIECES && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) {
+      rp = in_b + (long long)(2 * s_begin + c) * HW + gy * a.Win + gx;
+      rstep = 2u * (unsigned)HW * 4u;
+      rch1 = c == 1;
+    }
+  }
+  const bool cin_odd = (a.Cin & 1) != 0;
+  // LDS-DMA of k-step st (clamped to the last one of this workgroup's share) into ring slot `slot`: 18 KB of weights as 18
+  // pieces of 1 KB (waves 0..11 one each, waves 0..5 a second one) + the patch (waves 6..11): two instructions per wave
+  auto issue = [&](auto hi_c, int st, int slot) {
+    constexpr bool HI = decltype(hi_c)::value;                              // waves 6..11
+    const int sc = st < nst ? st : nst - 1;
+    const float* usrc = w_t + (long long)(s_begin + sc) * T::WSZ;
+    float* U_ = smem + U0 + slot * T::WSZ;
+    glds16(usrc + wave * 256 + lane * 4, U_ + wave * 256);
+    if constexpr (!HI) {
+      glds16(usrc + (12 + wave) * 256 + lane * 4, U_ + (12 + wave) * 256);
+    } else {
+      const float* p = (const float*)((const char*)rp + (unsigned long long)sc * rstep);
+      if (cin_odd && rch1 && s_begin + sc == nstages - 1) p = zpad;
+      glds16(p, smem + R0 + slot * T::XSZP + T::XSHIFT + (wave - 6) * 256);
+    }
+  };
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][hh][r] = 0.0f;
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+  const int ty = l31 >> 3, tx = l31 & 7;
+  const unsigned xbase = lds0 + (unsigned)(R0 + T::XWIN + half * T::XPLANE + 4 * ty * T::PW + 4 * tx) * 4u;
+  const int prow = wave >> 1, jh = wave & 1;                                 // row of the position grid, column half
+  const unsigned abase = lds0 + (unsigned)(U0 + half * 36 * T::BN + (prow * 6 + jh * 3) * T::BN + l31) * 4u;
+
+  struct AOps {
+    f32x2 p01[2];     // positions 0, 1 of the half row, per cout half
+    float p2[2];      // position 2
+  };
+  auto load_a = [&](AOps& o, int slot) {
+    const unsigned aa = abase + (unsigned)(slot * T::WSZ) * 4u;
+    lds_read2st64_b32<0, 1>(o.p01[0], aa);
+    lds_read_b32<2 * 256>(o.p2[0], aa);
+    lds_read2st64_b32<0, 1>(o.p01[1], aa + 128u);
+    lds_read_b32<2 * 256>(o.p2[1], aa + 128u);
+  };
+  constexpr int NA = 4;
+  auto wait_a = [&](AOps& o, auto newer_c) {
+    constexpr int N_ = decltype(newer_c)::value;
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(o.p01[0]), "+v"(o.p01[1]), "+v"(o.p2[0]), "+v"(o.p2[1]) : "n"(N_));
+  };
+  struct Raw {
+    f32x4 lo[4];
+    f32x2 hi[4];
+  };
+
+  auto main_loop = [&](auto role_c) {
+    constexpr int W_ = decltype(role_c)::value;                    // wave index 0..11
+    constexpr int ROW = W_ >> 1, JH = W_ & 1;
+    constexpr bool HI = W_ >= 6;
+    constexpr int R0_ = (ROW == 0) ? 0 : 1;
+    constexpr int RSTEP = (ROW == 0 || ROW == 5) ? 2 : 1;
+    constexpr int NROW = (ROW == 0 || ROW == 5) ? 3 : 4;
+    constexpr int NRAW = 2 * NROW;
+    auto raw_reads = [&](Raw& w, int slot) {
+      const unsigned xa = xbase + (unsigned)(slot * T::XSZP) * 4u;
+      w44_read_b128<(R0_ + 0 * RSTEP) * T::PW * 4>(w.lo[0], xa);
+      w44_read_b64<((R0_ + 0 * RSTEP) * T::PW + 4) * 4>(w.hi[0], xa);
+      w44_read_b128<(R0_ + 1 * RSTEP) * T::PW * 4>(w.lo[1], xa);
+      w44_read_b64<((R0_ + 1 * RSTEP) * T::PW + 4) * 4>(w.hi[1], xa);
+      w44_read_b128<(R0_ + 2 * RSTEP) * T::PW * 4>(w.lo[2], xa);
+      w44_read_b64<((R0_ + 2 * RSTEP) * T::PW + 4) * 4>(w.hi[2], xa);
+      if constexpr (NROW == 4) {
+        w44_read_b128<(R0_ + 3 * RSTEP) * T::PW * 4>(w.lo[3], xa);
+        w44_read_b64<((R0_ + 3 * RSTEP) * T::PW + 4) * 4>(w.hi[3], xa);
+      }
+    };
+    auto wait_raw = [&](Raw& w, auto newer_c) {
+      constexpr int N_ = decltype(newer_c)::value;
+      if constexpr (NROW == 4)
+        asm volatile("s_waitcnt lgkmcnt(%8)"
+                     : "+v"(w.lo[0]), "+v"(w.lo[1]), "+v"(w.lo[2]), "+v"(w.lo[3]), "+v"(w.hi[0]), "+v"(w.hi[1]), "+v"(w.hi[2]),
+                       "+v"(w.hi[3])
+                     : "n"(N_));
+      else
+        asm volatile("s_waitcnt lgkmcnt(%6)"
+                     : "+v"(w.lo[0]), "+v"(w.lo[1]), "+v"(w.lo[2]), "+v"(w.hi[0]), "+v"(w.hi[1]), "+v"(w.hi[2])
+                     : "n"(N_));
+    };
+    // t[c] = (B^T d)[ROW][c] for the five columns the half row needs (0..4 or 1..5), then its three values of B^T t
+    auto t_col = [&](const Raw& w, float (&t)[6], auto cc) {
+      constexpr int c = decltype(cc)::value;
+      float d[4];
+#pragma unroll
+      for (int i = 0; i < NROW; ++i) d[i] = c < 4 ? w.lo[i][c < 4 ? c : 0] : w.hi[i][c < 4 ? 0 : c - 4];
+      if constexpr (ROW == 0 || ROW == 5)
+        t[c] = fmaf(4.0f, d[0], fmaf(-5.0f, d[1], d[2]));
+      else if constexpr (ROW == 1)
+        t[c] = fmaf(-4.0f, d[1], d[3]) + fmaf(-4.0f, d[0], d[2]);
+      else if constexpr (ROW == 2)
+        t[c] = fmaf(-4.0f, d[1], d[3]) - fmaf(-4.0f, d[0], d[2]);
+      else if constexpr (ROW == 3)
+        t[c] = fmaf(2.0f, d[2] - d[0], d[3] - d[1]);
+      else
+        t[c] = fmaf(-2.0f, d[2] - d[0], d[3] - d[1]);
+    };
+    auto transform = [&](const Raw& w, float (&v)[3]) {
+      float t[6];
+      if constexpr (JH == 0) {
+        t_col(w, t, std::integral_constant<int, 0>{});
+        t_col(w, t, std::integral_constant<int, 1>{});
+        t_col(w, t, std::integral_constant<int, 2>{});
+        t_col(w, t, std::integral_constant<int, 3>{});
+        t_col(w, t, std::integral_constant<int, 4>{});
+        const float p = fmaf(-4.0f, t[2], t[4]), q = fmaf(-4.0f, t[1], t[3]);
+        v[0] = fmaf(4.0f, t[0], fmaf(-5.0f, t[2], t[4]));
+        v[1] = p + q;
+        v[2] = p - q;
+      } else {
+        t_col(w, t, std::integral_constant<int, 1>{});
+        t_col(w, t, std::integral_constant<int, 2>{});
+        t_col(w, t, std::integral_constant<int, 3>{});
+        t_col(w, t, std::integral_constant<int, 4>{});
+        t_col(w, t, std::integral_constant<int, 5>{});
+        const float c = t[4] - t[2], d = t[3] - t[1];
+        v[0] = fmaf(2.0f, d, c);
+        v[1] = fmaf(-2.0f, d, c);
+        v[2] = fmaf(4.0f, t[1], fmaf(-5.0f, t[3], t[5]));
+      }
+    };
+    using N0 = std::integral_constant<int, 0>;
+    using HIc = std::bool_constant<HI>;
+    auto mf = [&](const AOps& A_, const float (&B_)[3], auto jc, auto hc) {
+      constexpr int j = decltype(jc)::value, hh = decltype(hc)::value;
+      const float av = j < 2 ? A_.p01[hh][j < 2 ? j : 0] : A_.p2[hh];
+      acc[j][hh] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B_[j], acc[j][hh], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+
+    // ---- prologue: U(0), R(0), U(1), R(1) landed; B(0), A(0) in registers; U(2), R(2) in flight
+    issue(HIc{}, 0, 0);
+    issue(HIc{}, 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    AOps A0, A1;
+    float B0[3], B1[3];
+    {
+      Raw w;
+      raw_reads(w, 0);
+      load_a(A0, 0);
+      wait_raw(w, std::integral_constant<int, NA>{});
+      transform(w, B0);
+      wait_a(A0, N0{});
+    }
+    issue(HIc{}, 2, 2);
+
+    // ---- k-step s: MFMAs on (Ac, Bc); window of s+1 -> Bn; weights of s+1 -> An; LDS-DMA of s+3
+    auto step = [&](AOps& Ac, float (&Bc)[3], AOps& An, float (&Bn)[3], int s) {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // all but the previous k-step's two instructions have landed
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      Raw w;
+      raw_reads(w, (s + 1) % 3);
+      load_a(An, (s + 1) % 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mf(Ac, Bc, I0{}, I0{});
+      issue(HIc{}, s + 3, s % 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mf(Ac, Bc, I0{}, I1{});
+      mf(Ac, Bc, I1{}, I0{});
+      wait_raw(w, std::integral_constant<int, NA>{});
+      transform(w, Bn);
+      __builtin_amdgcn_sched_barrier(0);
+      mf(Ac, Bc, I1{}, I1{});
+      mf(Ac, Bc, I2{}, I0{});
+      mf(Ac, Bc, I2{}, I1{});
+      wait_a(An, N0{});
+    };
+    int s = 0;
+    for (; s + 1 < nst; s += 2) {
+      step(A0, B0, A1, B1, s);
+      step(A1, B1, A0, B0, s + 1);
+    }
+    if (s < nst) step(A0, B0, A1, B1, s);
+  };
+  switch (wave) {
+    case 0: main_loop(std::integral_constant<int, 0>{}); break;
+    case 1: main_loop(std::integral_constant<int, 1>{}); break;
+    case 2: main_loop(std::integral_constant<int, 2>{}); break;
+    case 3: main_loop(std::integral_constant<int, 3>{}); break;
+    case 4: main_loop(std::integral_constant<int, 4>{}); break;
+    case 5: main_loop(std::integral_constant<int, 5>{}); break;
+    case 6: main_loop(std::integral_constant<int, 6>{}); break;
+    case 7: main_loop(std::integral_constant<int, 7>{}); break;
+    case 8: main_loop(std::integral_constant<int, 8>{}); break;
+    case 9: main_loop(std::integral_constant<int, 9>{}); break;
+    case 10: main_loop(std::integral_constant<int, 10>{}); break;
+    default: main_loop(std::integral_constant<int, 11>{}); break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- output transform: this wave holds M[prow][3 jh .. 3 jh + 2] for both cout halves.  Per accumulator element it folds
+  // them into the 4-vector (M A)[prow] restricted to its columns; the twelve waves exchange those through LDS (four rounds of
+  // four registers, 96 KB each) and waves 0..7 finish one (cout half, register) each per round: whole 4x4 tiles.
+  const int HWo = a.Hout * a.Wout;
+  const bool raw = a.ws != nullptr;
+  float* dst_b = raw ? a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWo
+                     : a.out + ((long long)b * a.out_ctot + a.out_coff) * HWo;
+  const float* res_b = (!raw && a.res) ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWo : nullptr;
+  const int oy = oy0 + 4 * ty, ox = ox0 + 4 * tx;
+  float* E = smem;                                            // [cout half][4 regs][12 waves][4 values][64 lanes]
+  for (int round = 0; round < 4; ++round) {
+    __syncthreads();
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        float m[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          m[j] = round == 0 ? acc[j][hh][rr] : round == 1 ? acc[j][hh][4 + rr] : round == 2 ? acc[j][hh][8 + rr] : acc[j][hh][12 + rr];
+        float v4[4];
+        if (jh == 0) {                        // columns 0..2 of A^T: [1 1 1; 0 1 -1; 0 1 1; 0 1 -1]
+          v4[0] = m[0] + m[1] + m[2];
+          v4[1] = m[1] - m[2];
+          v4[2] = m[1] + m[2];
+          v4[3] = m[1] - m[2];
+        } else {                              // columns 3..5: [1 1 0; 2 -2 0; 4 4 0; 8 -8 1]
+          const float s2 = m[0] + m[1], d2 = m[0] - m[1];
+          v4[0] = s2;
+          v4[1] = 2.0f * d2;
+          v4[2] = 4.0f * s2;
+          v4[3] = fmaf(8.0f, d2, m[2]);
+        }
+        float* e = E + (((hh * 4 + rr) * 12 + wave) * 4) * 64 + lane;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) e[v * 64] = v4[v];
+      }
+    __syncthreads();
+    if (wave < 8) {
+      const int hh = wave >> 2, rr = wave & 3;
+      const int r = 4 * round + rr;
+      float R[6][4];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          R[i][v] = E[(((hh * 4 + rr) * 12 + 2 * i) * 4 + v) * 64 + lane] + E[(((hh * 4 + rr) * 12 + 2 * i + 1) * 4 + v) * 64 + lane];
+      const int co = n_tile * T::BN + hh * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < a.Cout && ox < a.Wout) {
+        const float bv = (!raw && a.bias) ? a.bias[co] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (oy + u >= a.Hout) continue;
+          float y[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const float s1 = R[1][v] + R[2][v], d1 = R[1][v] - R[2][v], s2 = R[3][v] + R[4][v], d2 = R[3][v] - R[4][v];
+            y[v] = u == 0 ? R[0][v] + s1 + s2 : u == 1 ? fmaf(2.0f, d2, d1) : u == 2 ? fmaf(4.0f, s2, s1) : fmaf(8.0f, d2, d1) + R[5][v];
+          }
+          const long long off = (long long)co * HWo + (long long)(oy + u) * a.Wout + ox;
+          float4 o = make_float4(y[0], y[1], y[2], y[3]);       // Wout % 4 == 0 (VEC): the tile row is whole and 16-byte aligned
+          if (!raw) {
+            o.x += bv; o.y += bv; o.z += bv; o.w += bv;
+            if (res_b) {
+              const float4 rv = *reinterpret_cast<const float4*>(res_b + off);
+              o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+            }
+            if (a.act == ACT_RELU) {
+              o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+            } else if (a.act == ACT_RELU6) {
+              o.x = fminf(fmaxf(o.x, 0.f), 6.f); o.y = fminf(fmaxf(o.y, 0.f), 6.f);
+              o.z = fminf(fmaxf(o.z, 0.f), 6.f); o.w = fminf(fmaxf(o.w, 0.f), 6.f);
+            }
+          }
+          *reinterpret_cast<float4*>(dst_b + off) = o;
+        }
+      }
+    }
+  }
+}
+
 inline KernelEntry wino44_entry() {
   static_assert(W44::LDS_BYTES == W44odd::LDS_BYTES, "one dynamic-LDS size for both width classes");
   return KernelEntry{conv_wino44_kernel<W44>, W44::LDS_BYTES, 512, conv_wino44_kernel<W44odd>};
+}
+// twelve waves; odd widths (Win % 4 != 0) fall back to the eight-wave dword-staging kernel -- its own LDS size and block size
+// differ, so the entry carries the larger LDS request and launch_conv picks threads per variant (KernelEntry::threads_odd)
+inline KernelEntry wino44b_entry() {
+  constexpr size_t ring = (size_t)(3 * W44::WSZ + 3 * W44::XSZP) * sizeof(float);
+  constexpr size_t exch = (size_t)2 * 4 * 12 * 4 * 64 * sizeof(float);
+  constexpr size_t lds = ring > exch ? ring : exch;
+  KernelEntry e{conv_wino44b_kernel<W44>, lds > W44odd::LDS_BYTES ? lds : W44odd::LDS_BYTES, 768, conv_wino44_kernel<W44odd>};
+  e.threads_odd = 512;
+  return e;
 }
 
 }  // namespace

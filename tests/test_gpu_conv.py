@@ -15,9 +15,10 @@ KINDS = {  # name: (k, stride, pad, dil)
     "1x1s1": (1, 1, 0, 1), "1x1s2": (1, 2, 0, 1), "3x3s1": (3, 1, 1, 1), "3x3d2": (3, 1, 2, 2),
     "3x3s2": (3, 2, 1, 1), "7x7s2": (7, 2, 3, 1), "7x7s4": (7, 4, 3, 1), "5x5s2": (5, 2, 2, 1),
     "7x7s2p1": (7, 2, 1, 1)}
-N_TILES = 33      # 14 direct + 11 Winograd F(2x2,3x3) (3x3 s1 / d2 only) + 4 ring-of-four (1x1 only) + 2 quarter-split Winograd
+N_TILES = 34      # 14 direct + 11 Winograd F(2x2,3x3) (3x3 s1 / d2 only) + 4 ring-of-four (1x1 only) + 2 quarter-split Winograd
                   # + 1 packed-f32 VALU tile for narrow heads (3x3 s1 only) + 1 Winograd F(4x4,3x3) (3x3 s1 only)
 T_WINO44 = 32
+T_WINO44B = 33     # its twelve-wave form
 WINO44_TOL = 1e-4  # F(4x4,3x3): factors up to 8 in A^T / 5 in B^T amplify the f32 rounding of the transforms (2.7e-6 relative RMS
                   # per layer on post-ReLU data, up to ~3e-5 of the output's maximum on N(0,1) inputs)
 
@@ -80,7 +81,7 @@ def test_every_tile_variant_matches_torch(kind):
                     assert b"not instantiated" in msg or b"bad split-K" in msg, msg
                     continue
                 tested += 1
-                tol = WINO44_TOL if tile == T_WINO44 else 3e-5 if tile >= 14 else 1e-5   # Winograd: rounding of the transforms
+                tol = WINO44_TOL if tile in (T_WINO44, T_WINO44B) else 3e-5 if tile >= 14 else 1e-5   # Winograd: rounding of the transforms
                 assert rel_err(got, exp) < tol, (kind, tile, split, (Cin, H, W, Cout), rel_err(got, exp))
     assert tested >= 4
 
@@ -229,7 +230,8 @@ def test_fused_expand_depthwise(stride, shape):
 
 
 @pytest.mark.parametrize("shape", [(64, 40, 48, 96), (37, 31, 45, 70), (7, 16, 32, 64), (256, 64, 64, 128), (2, 5, 3, 3)])
-def test_winograd_f4x4(shape):
+@pytest.mark.parametrize("tile", [T_WINO44, T_WINO44B])
+def test_winograd_f4x4(shape, tile):
     """Winograd F(4x4,3x3) (conv_wino44.h): 4x fewer multiplies than the direct form.  Aligned and odd sizes (W % 4 != 0 ->
     scalar stores; tiles hanging over the image; an odd number of input channels -> a zero-padded k-step; fewer k-steps
     than the pipeline is deep), residual + ReLU, split-K 1 / 2 / 3, and the RMS error on a deep reduction."""
@@ -244,7 +246,7 @@ def test_winograd_f4x4(shape):
         for split in (1, 2, 3):
             if split > max(1, (Cin + 1) // 2):
                 continue
-            rc, got = run_conv(x, w, b, 3, 1, 1, 1, tile=T_WINO44, split=split, **kw)
+            rc, got = run_conv(x, w, b, 3, 1, 1, 1, tile=tile, split=split, **kw)
             assert rc == 0, lib().lib().fdt_last_error()
             assert rel_err(got, exp) < WINO44_TOL, (shape, split, list(kw), rel_err(got, exp))
             rms = float(np.sqrt(((got.astype(np.float64) - exp) ** 2).mean()) / np.sqrt((exp.astype(np.float64) ** 2).mean()))

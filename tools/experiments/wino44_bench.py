@@ -21,12 +21,16 @@ for cin, h, w, cout in SHAPES:
             if ms and (best2 is None or ms < best2[0]):
                 best2 = (ms, cb.TILE[t], sp)
     best4 = None
-    for sp in (1, 2, 3, 4, 6, 8, 16):
-        if sp > cin // 8:
-            break
-        ms = cb.bench(14, 32, sp, cin, h, w, cout)
-        if ms and (best4 is None or ms < best4[0]):
-            best4 = (ms, sp)
+    per_tile = {}
+    for t4 in (32, 33):
+        for sp in (1, 2, 3, 4, 6, 8, 16):
+            if sp > cin // 8:
+                break
+            ms = cb.bench(14, t4, sp, cin, h, w, cout)
+            if ms and (t4 not in per_tile or ms < per_tile[t4][0]):
+                per_tile[t4] = (ms, sp)
+    best4 = min(per_tile.values())
     print("%4d -> %4d @ %3dx%-3d %6.2f GFLOP | F(2x2) %-10s /%-2d %7.1f us %6.1f alg TF/s | F(4x4) /%-2d %7.1f us %6.1f alg TF/s "
-          "(%5.1f executed) | x%.2f" % (cin, cout, h, w, gf, best2[1], best2[2], best2[0] * 1e3, gf / best2[0], best4[1],
-                                        best4[0] * 1e3, gf / best4[0], gf / 4 / best4[0], best2[0] / best4[0]))
+          "(%5.1f executed) | x%.2f | 8 waves %6.1f us /%d, 12 waves %6.1f us /%d" % (cin, cout, h, w, gf, best2[1], best2[2], best2[0] * 1e3, gf / best2[0], best4[1],
+                                        best4[0] * 1e3, gf / best4[0], gf / 4 / best4[0], best2[0] / best4[0],
+                                        per_tile[32][0] * 1e3, per_tile[32][1], per_tile[33][0] * 1e3, per_tile[33][1]))
