@@ -3,10 +3,10 @@
 # passes (FETCH_SIZE, WRITE_SIZE) summarised per kernel, MFMA-busy PMC of the dominant Winograd kernel and of the three
 # 1x1 instantiations that take the most time, the per-layer HIP-event table and the bench lines of the other
 # configurations.  Run through gpurun from the repo root:
-#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh r02'
+#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh r03'
 # Outputs land in gpurun_out/profiles_<round>/ (copy them into profiles/<round>/ afterwards).
 set -e -o pipefail
-R=${1:-r02}
+R=${1:-r03}
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT /tmp/raw
 export TMPDIR=/tmp
@@ -18,14 +18,15 @@ K_WINO=$(plan_of conv2_SSH.conv1)
 K_A=$(plan_of layer3.1.conv1)
 K_B=$(plan_of layer1.0.conv3)
 K_C=$(plan_of layer2.1.conv3)
-case "$K_WINO" in "8 29 "*|"8 30 "*) ;; *) echo "refresh_profiles: conv2_SSH.conv1 is no longer a quarter-split Winograd kernel ($K_WINO)" >&2; exit 1;; esac
-B="python bench.py --steps 48 --warmup 8 --cpu-frames 0"
-timeout -k 10 400 python bench.py --steps 64 --warmup 8 --host-frames 64 > $OUT/bench_line_res50_1024.json
+case "$K_WINO" in "14 32 "*|"14 33 "*) ;; *) echo "refresh_profiles: conv2_SSH.conv1 is no longer a Winograd F(4x4,3x3) kernel ($K_WINO)" >&2; exit 1;; esac
+K_WD2=$(plan_of conv2_SSH.conv2)       # the dilated SSH context conv: quarter-split F(2x2,3x3)
+B="python bench.py --steps 48 --warmup 8 --cpu-frames 0 --host-frames 0"
+timeout -k 10 400 python bench.py --steps 64 --warmup 8 > $OUT/bench_line_res50_1024.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt --output-format csv -- $B > $OUT/bench_under_rocprof.log 2>&1
 cp /tmp/raw/kt_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv
 # that command runs 8 priming + 8 warm-up + 48 timed + 56 parity (sequential re-run) + 5 profiled forwards
 python tools/rocprof_conv_summary.py $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv 125 $OUT/bench_line_res50_1024.json > $OUT/rocprof_vs_bench.txt
-P="python bench.py --steps 8 --warmup 2 --cpu-frames 0 --inflight 1 --profile-frames 1 --graph 0"
+P="python bench.py --steps 8 --warmup 2 --cpu-frames 0 --host-frames 0 --inflight 1 --profile-frames 1 --graph 0"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/raw -o pmc_$C --output-format csv -- $P > /tmp/raw/pmc_$C.log 2>&1
   python tools/summarize_pmc.py /tmp/raw/pmc_${C}_counter_collection.csv $OUT/pmc_${C}_by_kernel.csv
@@ -42,11 +43,12 @@ pmc_one() {
     -d /tmp/raw -o mfma_$1 --output-format csv -- python tools/one_conv.py $2 $3 $4 $5 $6 $7 $8 $9 8 > $OUT/pmc_mfma_$1_times.txt 2>&1
   python tools/summarize_pmc.py /tmp/raw/mfma_$1_counter_collection.csv $OUT/pmc_mfma_$1.csv
 }
-pmc_one wino4_256to256_256x256   $K_WINO 256 256 256 256 0    # conv2_SSH.conv1 / smooth_c3
+pmc_one wino44_256to256_256x256  $K_WINO 256 256 256 256 0    # conv2_SSH.conv1 / smooth_c3: Winograd F(4x4,3x3)
+pmc_one wino4d2_256to128_256x256 $K_WD2 256 256 256 128 0     # conv2_SSH.conv2: dilated, quarter-split F(2x2,3x3)
 pmc_one 1x1_1024to256_64x64      $K_A 1024 64 64 256 0        # layer3.x.conv1
 pmc_one 1x1_64to256_256x256_res  $K_B 64 256 256 256 1        # layer1.x.conv3 (+ residual)
 pmc_one 1x1_128to512_128x128_res $K_C 128 128 128 512 1       # layer2.x.conv3 (+ residual)
-echo "conv2_SSH.conv1 $K_WINO | layer3.1.conv1 $K_A | layer1.0.conv3 $K_B | layer2.1.conv3 $K_C" > $OUT/pmc_mfma_kernels.txt
+echo "conv2_SSH.conv1 $K_WINO | conv2_SSH.conv2 $K_WD2 | layer3.1.conv1 $K_A | layer1.0.conv3 $K_B | layer2.1.conv3 $K_C" > $OUT/pmc_mfma_kernels.txt
 # the vector-ALU kernel of the 8-channel heads (conv_n8.h): VALU / LDS activity instead of matrix-pipe occupancy
 K_HEAD=$(plan_of face_loc.0)
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
@@ -54,14 +56,19 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VA
   python tools/summarize_pmc.py /tmp/raw/valu_head_counter_collection.csv $OUT/pmc_valu_head_512to8_256x256.csv || echo "head PMC pass failed (counters unavailable)" > $OUT/pmc_valu_head_512to8_256x256.csv
 echo "face_loc.0 $K_HEAD" >> $OUT/pmc_mfma_kernels.txt
 timeout -k 10 300 python tools/profile_layers.py > $OUT/per_layer_hip_events_res50_1024.txt
-timeout -k 10 300 python bench.py --steps 64 --warmup 8 --height 480 --width 640 --cpu-frames 2 > $OUT/bench_line_res50_640x480.json
-timeout -k 10 300 python bench.py --steps 128 --warmup 16 --source 1080x1920 --height 480 --width 640 --cpu-frames 3 --host-frames 128 > $OUT/bench_line_res50_640x480_from_1080p.json
-timeout -k 10 300 python bench.py --steps 32 --warmup 4 --height 1080 --width 1920 --cpu-frames 1 > $OUT/bench_line_res50_1920x1080.json
-timeout -k 10 300 python bench.py --steps 64 --warmup 8 --arch try3 --cpu-frames 3 > $OUT/bench_line_try3_1024.json
-timeout -k 10 300 python bench.py --steps 32 --warmup 4 --arch try3 --batch 8 --cpu-frames 3 > $OUT/bench_line_try3_1024_b8.json
+timeout -k 10 300 python bench.py --steps 64 --warmup 8 --height 480 --width 640 > $OUT/bench_line_res50_640x480.json
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt480 --output-format csv -- python bench.py --steps 64 --warmup 8 --height 480 --width 640 --cpu-frames 0 --host-frames 0 > $OUT/bench_640x480_under_rocprof.log 2>&1
+cp /tmp/raw/kt480_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_res50_640x480.csv
+timeout -k 10 200 python tools/profile_layers.py --height 480 --width 640 > $OUT/per_layer_hip_events_res50_640x480.txt
+timeout -k 10 300 python bench.py --steps 128 --warmup 16 --source 1080x1920 --height 480 --width 640 --host-frames 256 > $OUT/bench_line_res50_640x480_from_1080p.json
+timeout -k 10 300 python bench.py --steps 32 --warmup 4 --height 1080 --width 1920 --cpu-frames 4 --host-frames 32 > $OUT/bench_line_res50_1920x1080.json
+timeout -k 10 300 python bench.py --steps 64 --warmup 8 --arch try3 > $OUT/bench_line_try3_1024.json
+timeout -k 10 300 python bench.py --steps 32 --warmup 4 --arch try3 --batch 8 > $OUT/bench_line_try3_1024_b8.json
 timeout -k 10 300 python bench.py --arch facebox --batch 16 --steps 100 --warmup 8 > $OUT/bench_line_facebox_4k_b16.json
 timeout -k 10 400 python bench.py --steps 32 --warmup 6 --batch 2 --cpu-frames 0 > $OUT/bench_line_res50_1024_b2.json
-timeout -k 10 300 python bench.py --steps 48 --warmup 8 --height 480 --width 640 --batch 4 --cpu-frames 2 > $OUT/bench_line_res50_640x480_b4.json
+timeout -k 10 300 python bench.py --steps 48 --warmup 8 --height 480 --width 640 --batch 4 --cpu-frames 0 > $OUT/bench_line_res50_640x480_b4.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o ktfb --output-format csv -- python bench.py --arch facebox --batch 16 --steps 50 --warmup 5 --cpu-frames 0 > $OUT/bench_facebox_under_rocprof.log 2>&1
 cp /tmp/raw/ktfb_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_facebox_4k_b16.csv
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kttry3 --output-format csv -- python bench.py --steps 32 --warmup 4 --arch try3 --batch 8 --cpu-frames 0 --host-frames 0 > $OUT/bench_try3_b8_under_rocprof.log 2>&1
+cp /tmp/raw/kttry3_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_try3_1024_b8.csv
 tail -c 600 $OUT/bench_line_res50_1024.json
