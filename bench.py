@@ -636,7 +636,7 @@ def main():
         # HBM bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (PMC
         # cannot be read from inside the process); the committed summary of the current round is quoted here.
         traffic = traffic_src = traffic_cal = None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             tj = os.path.join(ROOT, "profiles", rnd, "conv_hbm_traffic.json")
             if args.arch == "res50" and H == 1024 and W == 1024 and os.path.exists(tj):
                 tdata = json.load(open(tj))
