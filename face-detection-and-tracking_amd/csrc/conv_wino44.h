@@ -47,6 +47,24 @@ __device__ __forceinline__ void w44_write2st64_b32(unsigned addr, float x, float
   asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(x), "v"(y), "n"(O0), "n"(O1) : "memory");
 }
 
+// Packed f32 (two columns per instruction), written as asm because the compiler scalarises these into v_fma_f32 pairs: in a kernel
+// whose matrix pipe and vector ALU do not co-execute, a VALU instruction saved is four matrix cycles gained.
+__device__ __forceinline__ f32x2 pk_fma(f32x2 x, f32x2 y, f32x2 z) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 x, f32x2 y) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 x, f32x2 y) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y));
+  return d;
+}
+
 // VEC: Win % 4 == 0 -- the patch is staged as 16-byte pieces of the aligned superset [ox0 - 4, ox0 + 36) of its columns (ONE
 // LDS-DMA instruction per wave and k-step instead of three dword ones); the odd-width variant stages it dword by dword.
 template <bool VEC_>
@@ -66,7 +84,7 @@ struct W44T {
   static constexpr int XSZP = VEC ? 1600 : 1536;         // slot: 6 waves x 64 pieces + shift / 3 dword instructions x 512 threads
   static constexpr int WSZ = 2 * 36 * BN;                // 4608 floats of transformed weights per k-step: 2 x (8 waves x 1 KB) + 2 KB
   static constexpr int VSZ = 36 * 64;                    // transformed input of a k-step: [position][channel][tile]
-  static constexpr int U_SLOTS = 4, R_SLOTS = 3, V_SLOTS = 3;
+  static constexpr int U_SLOTS = 4, R_SLOTS = 4, V_SLOTS = 4;   // four each: the loop is unrolled by four, every ring offset an immediate
   static constexpr int U0 = 0, R0 = U_SLOTS * WSZ, V0 = R0 + R_SLOTS * XSZP, RING = V0 + V_SLOTS * VSZ;
   static constexpr int EXCH = 2 * 4 * 8 * 8 * 64;        // epilogue exchange: [cout half][group][8 regs][8 values][lane]
   static constexpr size_t LDS_BYTES = (size_t)(RING > EXCH ? RING : EXCH) * sizeof(float);
@@ -105,25 +123,27 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
 
   const float* zpad = g_zero_pad;
   asm volatile("" : "+s"(zpad));
-  // ---- staging plan of the raw patch (the same for every k-step) ----------------------------------------------------------
-  // VEC: lane e = 64 wave + lane < 360 owns the 16-byte piece (channel c, patch row yy, piece j); its source pointer advances by
-  // two channel planes per k-step (rstep), or stays at the zero word for padding / out-of-image / spare lanes (rstep 0)
-  const float* rp = zpad;
-  unsigned rstep = 0;
-  bool rch1 = false;
+  // ---- staging plan (the same for every k-step) -----------------------------------------------------------------------------
+  // The matrix pipe and the vector ALU of a SIMD do not co-execute on this chip (SQ_VALU_MFMA_COEXEC_CYCLES = 0 for every conv
+  // kernel here): each VALU instruction in the main loop is four cycles taken from the MFMAs.  So the loop carries NO address
+  // arithmetic in vector registers: LDS offsets are immediates (rings of four slots, loop unrolled by four), and (VEC) both
+  // operand streams are BUFFER loads -- a per-lane byte offset that never changes plus a scalar offset advanced per k-step; lanes
+  // that stage padding / out-of-image / spare pieces carry an out-of-range offset and receive zeros from the bounds check (which
+  // also zeroes the channel past an odd Cin).
+  __amdgpu_buffer_rsrc_t wrs, xrs;
+  unsigned xvo = 0x80000000u;                              // patch piece of this lane: byte offset in the image, or out of range
+  const unsigned wvo = (unsigned)lane * 16u;
   int goff[3];
   unsigned okmask = 0;
   if constexpr (T::VEC) {
-    const int e = tid;
+    wrs = __builtin_amdgcn_make_buffer_rsrc((void*)w_t, 0, 0x7fffffff, 0x00020000);
+    xrs = __builtin_amdgcn_make_buffer_rsrc((void*)in_b, 0, a.Cin * HW * 4, 0x00020000);
+    const int e = tid;                                     // waves 0..5: lane e < 360 owns the 16-byte piece (channel c, row yy, piece j)
     const int c = e / (T::XPLANE / 4);
     const int r = e - c * (T::XPLANE / 4);
     const int yy = r / (T::PW / 4), j = r - yy * (T::PW / 4);
     const int gy = oy0 - 1 + yy, gx = ox0 - 4 + 4 * j;
-    if (e < T::XPIECES && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) {
-      rp = in_b + (long long)(2 * s_begin + c) * HW + gy * a.Win + gx;
-      rstep = 2u * (unsigned)HW * 4u;
-      rch1 = c == 1;
-    }
+    if (e < T::XPIECES && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) xvo = (unsigned)(c * HW + gy * a.Win + gx) * 4u;
   } else {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -137,32 +157,33 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
       if (ok) okmask |= (1u << k) | ((unsigned)c << (4 + k));   // bit k: in image; bit 4 + k: which of the two channels
     }
   }
-  const bool cin_odd = (a.Cin & 1) != 0;
 
-  // LDS-DMA of one k-step: weights U(su) into ring slot `us`, raw patch R(sr) into ring slot `rs`.  k-steps past the end of
-  // this workgroup's share are clamped to its last one (valid addresses, the same instruction count; what they fetch is
-  // never consumed by an MFMA).
-  auto issue_w = [&](auto tail_c, int su, int us, int sr, int rs) {
+  // LDS-DMA of one k-step into compile-time ring slots: weights U(su) -> slot US, raw patch R(sr) -> slot RS.  k-steps past the
+  // end of this workgroup's share are clamped to its last one (valid addresses, the same instruction count; never consumed).
+  auto issue_w = [&](auto tail_c, auto us_c, auto rs_c, int su, int sr) {
     constexpr bool TAILW = decltype(tail_c)::value;     // waves 6, 7: the last 2 KB of the weights instead of a patch piece
+    constexpr int US = decltype(us_c)::value, RS = decltype(rs_c)::value;
     const int suc = su < nst ? su : nst - 1, src_ = sr < nst ? sr : nst - 1;
-    const float* usrc = w_t + (long long)(s_begin + suc) * T::WSZ;
-    float* U_ = smem + T::U0 + us * T::WSZ;
-    glds16(usrc + wave * 256 + lane * 4, U_ + wave * 256);
-    glds16(usrc + 2048 + wave * 256 + lane * 4, U_ + 2048 + wave * 256);
+    float* U_ = smem + T::U0 + US * T::WSZ;
     if constexpr (T::VEC) {
-      if constexpr (TAILW) {
-        glds16(usrc + 4096 + (wave - 6) * 256 + lane * 4, U_ + 4096 + (wave - 6) * 256);
-      } else {
-        const float* p = (const float*)((const char*)rp + (unsigned long long)src_ * rstep);
-        if (cin_odd && rch1 && s_begin + src_ == nstages - 1) p = zpad;      // the channel past an odd Cin
-        glds16(p, smem + T::R0 + rs * T::XSZP + T::XSHIFT + wave * 256);
-      }
+      const unsigned ub = (unsigned)((s_begin + suc) * T::WSZ) * 4u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(U_ + wave * 256), 16, wvo, ub + (unsigned)wave * 1024u, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(U_ + 2048 + wave * 256), 16, wvo, ub + 8192u + (unsigned)wave * 1024u, 0, 0);
+      if constexpr (TAILW)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(U_ + 4096 + (wave - 6) * 256), 16, wvo,
+                                                 ub + 16384u + (unsigned)(wave - 6) * 1024u, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(smem + T::R0 + RS * T::XSZP + T::XSHIFT + wave * 256), 16, xvo,
+                                                 (unsigned)(s_begin + src_) * 2u * (unsigned)HW * 4u, 0, 0);
     } else {
+      const float* usrc = w_t + (long long)(s_begin + suc) * T::WSZ;
+      glds16(usrc + wave * 256 + lane * 4, U_ + wave * 256);
+      glds16(usrc + 2048 + wave * 256 + lane * 4, U_ + 2048 + wave * 256);
       glds4(usrc + 4096 + wave * 64 + lane, U_ + 4096 + wave * 64);
       const int c0 = (s_begin + src_) * 2;
       const float* src = in_b + (long long)c0 * HW;
       const int crem = a.Cin - c0;
-      float* R_ = smem + T::R0 + rs * T::XSZP + wave * 64;
+      float* R_ = smem + T::R0 + RS * T::XSZP + wave * 64;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const bool ok = ((okmask >> k) & 1u) && (int)((okmask >> (4 + k)) & 1u) < crem;
@@ -190,19 +211,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     f32x2 a[4], b[4];
     float a8, b8;
   };
-  auto load_ops = [&](Ops& o, int us, int vs) {
-    const unsigned aa = abase + (unsigned)(us * T::WSZ) * 4u, bb = bbase + (unsigned)(vs * T::VSZ) * 4u;
-    lds_read2st64_b32<0, 1>(o.a[0], aa);
-    lds_read2st64_b32<0, 1>(o.b[0], bb);
-    lds_read2st64_b32<2, 3>(o.a[1], aa);
-    lds_read2st64_b32<2, 3>(o.b[1], bb);
-    lds_read2st64_b32<4, 5>(o.a[2], aa);
-    lds_read2st64_b32<4, 5>(o.b[2], bb);
-    lds_read2st64_b32<6, 7>(o.a[3], aa);
-    lds_read2st64_b32<6, 7>(o.b[3], bb);
-    lds_read_b32<8 * 256>(o.a8, aa);
-    lds_read_b32<8 * 256>(o.b8, bb);
+  // operands of one k-step from compile-time ring slots: every offset is an immediate
+  auto load_ops = [&](Ops& o, auto us_c, auto vs_c) {
+    constexpr int UO = decltype(us_c)::value * (T::WSZ / 64), VO = decltype(vs_c)::value * (T::VSZ / 64);   // units of 64 dwords
+    lds_read2st64_b32<UO + 0, UO + 1>(o.a[0], abase);
+    lds_read2st64_b32<VO + 0, VO + 1>(o.b[0], bbase);
+    lds_read2st64_b32<UO + 2, UO + 3>(o.a[1], abase);
+    lds_read2st64_b32<VO + 2, VO + 3>(o.b[1], bbase);
+    lds_read2st64_b32<UO + 4, UO + 5>(o.a[2], abase);
+    lds_read2st64_b32<VO + 4, VO + 5>(o.b[2], bbase);
+    lds_read2st64_b32<UO + 6, UO + 7>(o.a[3], abase);
+    lds_read2st64_b32<VO + 6, VO + 7>(o.b[3], bbase);
+    lds_read_b32<(UO + 8) * 256>(o.a8, abase);
+    lds_read_b32<(VO + 8) * 256>(o.b8, bbase);
   };
+  static_assert(3 * (T::WSZ / 64) + 8 < 256 && (3 * (T::WSZ / 64) + 8) * 256 < 65536, "ds offset fields");
   auto wait_ops = [&](Ops& o, auto newer_c) {
     constexpr int N_ = decltype(newer_c)::value;
     asm volatile("s_waitcnt lgkmcnt(%10)"
@@ -224,24 +247,26 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     f32x4 lo[4];      // columns 0..3 of the window rows this role needs
     f32x2 hi[4];      // columns 4, 5
   };
+  const f32x2 k4 = {4.0f, 4.0f}, km5 = {-5.0f, -5.0f}, km4 = {-4.0f, -4.0f}, k2 = {2.0f, 2.0f}, km2 = {-2.0f, -2.0f};
+
   auto main_loop = [&](auto role_c) {
     constexpr int ROLE = decltype(role_c)::value;                  // 0..5: row of B^T d this wave produces; 6: none
     constexpr int R0_ = (ROLE == 0) ? 0 : 1;                       // first window row needed
     constexpr int RSTEP = (ROLE == 0 || ROLE == 5) ? 2 : 1;        // rows 0,2,4 / 1,2,3,4 / 1,3,5
     constexpr int NROW = (ROLE == 0 || ROLE == 5) ? 3 : 4;
     constexpr int NRAW = (ROLE < 6) ? 2 * NROW : 0;
-    auto raw_reads = [&](Raw& w, int rs) {
+    auto raw_reads = [&](Raw& w, auto rs_c) {
+      constexpr int SO = decltype(rs_c)::value * T::XSZP * 4;       // byte offset of the ring slot
       if constexpr (ROLE < 6) {
-        const unsigned xa = xbase + (unsigned)(rs * T::XSZP) * 4u;
-        w44_read_b128<(R0_ + 0 * RSTEP) * T::PW * 4>(w.lo[0], xa);
-        w44_read_b64<((R0_ + 0 * RSTEP) * T::PW + 4) * 4>(w.hi[0], xa);
-        w44_read_b128<(R0_ + 1 * RSTEP) * T::PW * 4>(w.lo[1], xa);
-        w44_read_b64<((R0_ + 1 * RSTEP) * T::PW + 4) * 4>(w.hi[1], xa);
-        w44_read_b128<(R0_ + 2 * RSTEP) * T::PW * 4>(w.lo[2], xa);
-        w44_read_b64<((R0_ + 2 * RSTEP) * T::PW + 4) * 4>(w.hi[2], xa);
+        w44_read_b128<SO + (R0_ + 0 * RSTEP) * T::PW * 4>(w.lo[0], xbase);
+        w44_read_b64<SO + ((R0_ + 0 * RSTEP) * T::PW + 4) * 4>(w.hi[0], xbase);
+        w44_read_b128<SO + (R0_ + 1 * RSTEP) * T::PW * 4>(w.lo[1], xbase);
+        w44_read_b64<SO + ((R0_ + 1 * RSTEP) * T::PW + 4) * 4>(w.hi[1], xbase);
+        w44_read_b128<SO + (R0_ + 2 * RSTEP) * T::PW * 4>(w.lo[2], xbase);
+        w44_read_b64<SO + ((R0_ + 2 * RSTEP) * T::PW + 4) * 4>(w.hi[2], xbase);
         if constexpr (NROW == 4) {
-          w44_read_b128<(R0_ + 3 * RSTEP) * T::PW * 4>(w.lo[3], xa);
-          w44_read_b64<((R0_ + 3 * RSTEP) * T::PW + 4) * 4>(w.hi[3], xa);
+          w44_read_b128<SO + (R0_ + 3 * RSTEP) * T::PW * 4>(w.lo[3], xbase);
+          w44_read_b64<SO + ((R0_ + 3 * RSTEP) * T::PW + 4) * 4>(w.hi[3], xbase);
         }
       }
     };
@@ -259,140 +284,134 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
                        : "n"(N_));
       }
     };
-    // the row transform in pieces, so that the k-step can spread it between its MFMAs: t[c] (one column of B^T d at a time),
-    // then v = B^T t in two halves, then the three paired LDS writes
-    auto t_col = [&](const Raw& w, float (&t)[6], auto cc) {
-      constexpr int c = decltype(cc)::value;
+    // The row transform on PACKED f32 (v_pk_fma_f32 / v_pk_add_f32: two columns per instruction).  t_pairs: T[k] = the pair of
+    // columns (2k, 2k + 1) of row ROLE of B^T d;  v_all: v = B^T t for all six columns.
+    auto t_pairs = [&](const Raw& w, f32x2 (&Tp)[3]) {
       if constexpr (ROLE < 6) {
-        float d[4];
 #pragma unroll
-        for (int i = 0; i < NROW; ++i) d[i] = c < 4 ? w.lo[i][c < 4 ? c : 0] : w.hi[i][c < 4 ? 0 : c - 4];
-        if constexpr (ROLE == 0 || ROLE == 5)
-          t[c] = fmaf(4.0f, d[0], fmaf(-5.0f, d[1], d[2]));            // 4 d0 - 5 d2 + d4   /   4 d1 - 5 d3 + d5
-        else if constexpr (ROLE == 1)
-          t[c] = fmaf(-4.0f, d[1], d[3]) + fmaf(-4.0f, d[0], d[2]);    // (d4 - 4 d2) + (d3 - 4 d1)
-        else if constexpr (ROLE == 2)
-          t[c] = fmaf(-4.0f, d[1], d[3]) - fmaf(-4.0f, d[0], d[2]);
-        else if constexpr (ROLE == 3)
-          t[c] = fmaf(2.0f, d[2] - d[0], d[3] - d[1]);                 // (d4 - d2) + 2 (d3 - d1)
-        else
-          t[c] = fmaf(-2.0f, d[2] - d[0], d[3] - d[1]);
+        for (int pr = 0; pr < 3; ++pr) {
+          f32x2 d[4];
+#pragma unroll
+          for (int i = 0; i < NROW; ++i)
+            d[i] = pr == 0 ? __builtin_shufflevector(w.lo[i], w.lo[i], 0, 1) : pr == 1 ? __builtin_shufflevector(w.lo[i], w.lo[i], 2, 3) : w.hi[i];
+          if constexpr (ROLE == 0 || ROLE == 5)
+            Tp[pr] = pk_fma(k4, d[0], pk_fma(km5, d[1], d[2]));              // 4 d0 - 5 d2 + d4   /   4 d1 - 5 d3 + d5
+          else if constexpr (ROLE == 1)
+            Tp[pr] = pk_add(pk_fma(km4, d[1], d[3]), pk_fma(km4, d[0], d[2]));   // (d4 - 4 d2) + (d3 - 4 d1)
+          else if constexpr (ROLE == 2)
+            Tp[pr] = pk_sub(pk_fma(km4, d[1], d[3]), pk_fma(km4, d[0], d[2]));
+          else if constexpr (ROLE == 3)
+            Tp[pr] = pk_fma(k2, pk_sub(d[2], d[0]), pk_sub(d[3], d[1]));     // (d4 - d2) + 2 (d3 - d1)
+          else
+            Tp[pr] = pk_fma(km2, pk_sub(d[2], d[0]), pk_sub(d[3], d[1]));
+        }
       }
     };
-    auto v_lo = [&](const float (&t)[6], float (&v)[6]) {              // v0, v1, v2 of v = B^T t
+    auto v_all = [&](const f32x2 (&Tp)[3], float (&v)[6]) {          // Tp = (t0,t1), (t2,t3), (t4,t5)
       if constexpr (ROLE < 6) {
-        const float p = fmaf(-4.0f, t[2], t[4]), q = fmaf(-4.0f, t[1], t[3]);
-        v[0] = fmaf(4.0f, t[0], fmaf(-5.0f, t[2], t[4]));
-        v[1] = p + q;
-        v[2] = p - q;
+        const f32x2 v05 = pk_fma(k4, Tp[0], pk_fma(km5, Tp[1], Tp[2]));   // (v0, v5)
+        const f32x2 pq = pk_fma(km4, Tp[1], Tp[2]);                       // .x = t4 - 4 t2
+        const float q = fmaf(-4.0f, Tp[0][1], Tp[1][1]);                  // t3 - 4 t1
+        const f32x2 cd = pk_sub(Tp[2], Tp[1]);                            // .x = t4 - t2
+        const float d = Tp[1][1] - Tp[0][1];                              // t3 - t1
+        v[0] = v05[0];
+        v[1] = pq[0] + q;
+        v[2] = pq[0] - q;
+        v[3] = fmaf(2.0f, d, cd[0]);
+        v[4] = fmaf(-2.0f, d, cd[0]);
+        v[5] = v05[1];
       }
     };
-    auto v_hi = [&](const float (&t)[6], float (&v)[6]) {              // v3, v4, v5
+    auto v_store = [&](const float (&v)[6], auto vs_c) {
+      constexpr int VO = decltype(vs_c)::value * (T::VSZ / 64) + ROLE * 6;
       if constexpr (ROLE < 6) {
-        const float c = t[4] - t[2], d = t[3] - t[1];
-        v[3] = fmaf(2.0f, d, c);
-        v[4] = fmaf(-2.0f, d, c);
-        v[5] = fmaf(4.0f, t[1], fmaf(-5.0f, t[3], t[5]));
+        w44_write2st64_b32<VO + 0, VO + 1>(vwbase, v[0], v[1]);
+        w44_write2st64_b32<VO + 2, VO + 3>(vwbase, v[2], v[3]);
+        w44_write2st64_b32<VO + 4, VO + 5>(vwbase, v[4], v[5]);
       }
     };
-    auto v_store = [&](const float (&v)[6], int vs) {
-      if constexpr (ROLE < 6) {
-        const unsigned va = vwbase + (unsigned)(vs * T::VSZ) * 4u;
-        w44_write2st64_b32<ROLE * 6 + 0, ROLE * 6 + 1>(va, v[0], v[1]);
-        w44_write2st64_b32<ROLE * 6 + 2, ROLE * 6 + 3>(va, v[2], v[3]);
-        w44_write2st64_b32<ROLE * 6 + 4, ROLE * 6 + 5>(va, v[4], v[5]);
-      }
+    auto transform_store = [&](const Raw& w, auto vs_c) {
+      f32x2 Tp[3];
+      float v[6];
+      t_pairs(w, Tp);
+      v_all(Tp, v);
+      v_store(v, vs_c);
     };
-    auto transform_store = [&](const Raw& w, int vs) {
-      float t[6], v[6];
-      t_col(w, t, std::integral_constant<int, 0>{});
-      t_col(w, t, std::integral_constant<int, 1>{});
-      t_col(w, t, std::integral_constant<int, 2>{});
-      t_col(w, t, std::integral_constant<int, 3>{});
-      t_col(w, t, std::integral_constant<int, 4>{});
-      t_col(w, t, std::integral_constant<int, 5>{});
-      v_lo(t, v);
-      v_hi(t, v);
-      v_store(v, vs);
-    };
-    auto issue = [&](int su, int us, int sr, int rs) { issue_w(std::bool_constant<ROLE == 6>{}, su, us, sr, rs); };
+    using TAILc = std::bool_constant<ROLE == 6>;
     using N0 = std::integral_constant<int, 0>;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    using S3 = std::integral_constant<int, 3>;
 
     // ---- prologue: U(0), U(1), R(0), R(1), R(2); V(0), V(1); U(2), R(3) in flight; operands of k-step 0 in registers
-    issue(0, 0, 0, 0);
-    issue(1, 1, 1, 1);
-    issue(2, 2, 2, 2);
+    issue_w(TAILc{}, S0{}, S0{}, 0, 0);
+    issue_w(TAILc{}, S1{}, S1{}, 1, 1);
+    issue_w(TAILc{}, S2{}, S2{}, 2, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     {
       Raw w0, w1;
-      raw_reads(w0, 0);
-      raw_reads(w1, 1);
+      raw_reads(w0, S0{});
+      raw_reads(w1, S1{});
       wait_raw(w0, std::integral_constant<int, NRAW>{});
-      transform_store(w0, 0);
+      transform_store(w0, S0{});
       wait_raw(w1, std::integral_constant<int, (ROLE < 6 ? 3 : 0)>{});
-      transform_store(w1, 1);
+      transform_store(w1, S1{});
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();          // V(0), V(1) visible; every wave is done with R(0), R(1)
     __builtin_amdgcn_sched_barrier(0);
-    issue(2, 2, 3, 0);                     // R(3) into the slot of R(0) (U(2) once more: one instruction count per issue)
+    issue_w(TAILc{}, S2{}, S3{}, 2, 3);    // R(3) (U(2) once more: one instruction count per issue)
     Ops X, Y;
-    load_ops(X, 0, 0);
+    load_ops(X, S0{}, S0{});
     wait_ops(X, N0{});
 
-    // ---- k-step s: MFMAs on `cur` (registers), transform of s+2, operand prefetch of s+1, LDS-DMA of U(s+3) / R(s+4)
 #ifndef FDT_W44_EXP
 #define FDT_W44_EXP 0     // timing experiments (tools/experiments/w44_variants.sh), a bit mask: 1 no input transform, 2 no barrier,
 #endif                    // 4 no LDS-DMA in the loop, 8 no MFMA, 16 no operand reads -- results are wrong for every value but 0
-    // A wave issues in order and stalls at an MFMA while the matrix pipe is taken (by its own previous MFMA or by the other
-    // wave of the SIMD), so whatever stands behind a block of MFMAs in program order waits for all of them: the k-step
-    // therefore spreads its non-matrix work (window-read wait, the row transform in pieces, the V writes) BETWEEN its nine
-    // MFMAs, in chunks short enough to issue while the pipe executes; sched_barrier pins the order.
     auto mf = [&](Ops& cur, auto qc) {
       if (!(FDT_W44_EXP & 8)) mfma_q(cur, qc);
       __builtin_amdgcn_sched_barrier(0);
     };
-    auto step = [&](Ops& cur, Ops& nxt, int s) {
+    // ---- k-step s (s mod 4 == M): MFMAs on `cur` (registers); window of s+2 -> V(s+2); operand prefetch of s+1; LDS-DMA of
+    // U(s+3) / R(s+4).  Right behind the barrier all eight waves queue their LDS reads at once: only the window reads go there
+    // (their data is needed first), four MFMAs stand between them and the wait, the operand prefetch is issued late.
+    auto step = [&](auto m_c, Ops& cur, Ops& nxt, int s) {
+      constexpr int M = decltype(m_c)::value;
+      using M1 = std::integral_constant<int, (M + 1) & 3>;
+      using M2 = std::integral_constant<int, (M + 2) & 3>;
+      using M3 = std::integral_constant<int, (M + 3) & 3>;
+      using M0 = std::integral_constant<int, M>;
+      // the first two MFMAs need nothing the barrier protects (their operands sit in registers): issued in front of it, they
+      // keep the matrix pipe fed while the workgroup synchronises
+      mf(cur, std::integral_constant<int, 0>{});
+      mf(cur, std::integral_constant<int, 1>{});
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::LOADS) : "memory");     // everything but the previous k-step's issue has landed
       if (!(FDT_W44_EXP & 2)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      // Right behind the barrier all eight waves queue their LDS reads at once; only the window reads go there (their data is
-      // needed first), four MFMAs stand between them and the wait, and the operand prefetch of the next k-step is issued late.
       Raw w;
-      if (!(FDT_W44_EXP & 1)) raw_reads(w, (s + 2) % 3);
+      if (!(FDT_W44_EXP & 1)) raw_reads(w, M2{});
       __builtin_amdgcn_sched_barrier(0);
-      mf(cur, std::integral_constant<int, 0>{});
-      if (!(FDT_W44_EXP & 4)) issue(s + 3, (s + 3) & 3, s + 4, (s + 4) % 3);
-      __builtin_amdgcn_sched_barrier(0);
-      mf(cur, std::integral_constant<int, 1>{});
       mf(cur, std::integral_constant<int, 2>{});
+      if (!(FDT_W44_EXP & 4)) issue_w(TAILc{}, M3{}, M0{}, s + 3, s + 4);
+      __builtin_amdgcn_sched_barrier(0);
       mf(cur, std::integral_constant<int, 3>{});
-      float t[6], v[6];
+      mf(cur, std::integral_constant<int, 4>{});
+      f32x2 Tp[3];
+      float v[6];
       if (!(FDT_W44_EXP & 1)) {
         wait_raw(w, N0{});
-        t_col(w, t, std::integral_constant<int, 0>{});
-        t_col(w, t, std::integral_constant<int, 1>{});
-        t_col(w, t, std::integral_constant<int, 2>{});
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mf(cur, std::integral_constant<int, 4>{});
-      if (!(FDT_W44_EXP & 1)) {
-        t_col(w, t, std::integral_constant<int, 3>{});
-        t_col(w, t, std::integral_constant<int, 4>{});
-        t_col(w, t, std::integral_constant<int, 5>{});
+        t_pairs(w, Tp);
       }
       __builtin_amdgcn_sched_barrier(0);
       mf(cur, std::integral_constant<int, 5>{});
-      if (!(FDT_W44_EXP & 1)) {
-        v_lo(t, v);
-        v_hi(t, v);
-      }
+      if (!(FDT_W44_EXP & 1)) v_all(Tp, v);
       __builtin_amdgcn_sched_barrier(0);
       mf(cur, std::integral_constant<int, 6>{});
-      if (!(FDT_W44_EXP & 1)) v_store(v, (s + 2) % 3);
-      if (!(FDT_W44_EXP & 16)) load_ops(nxt, (s + 1) & 3, (s + 1) % 3);
+      if (!(FDT_W44_EXP & 1)) v_store(v, M2{});
+      if (!(FDT_W44_EXP & 16)) load_ops(nxt, M1{}, M1{});
       __builtin_amdgcn_sched_barrier(0);
       mf(cur, std::integral_constant<int, 7>{});
       mf(cur, std::integral_constant<int, 8>{});
@@ -400,11 +419,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     int s = 0;
-    for (; s + 1 < nst; s += 2) {
-      step(X, Y, s);
-      step(Y, X, s + 1);
+    for (; s + 3 < nst; s += 4) {
+      step(S0{}, X, Y, s);
+      step(S1{}, Y, X, s + 1);
+      step(S2{}, X, Y, s + 2);
+      step(S3{}, Y, X, s + 3);
     }
-    if (s < nst) step(X, Y, s);
+    if (s < nst) step(S0{}, X, Y, s);
+    if (s + 1 < nst) step(S1{}, Y, X, s + 1);
+    if (s + 2 < nst) step(S2{}, X, Y, s + 2);
   };
   switch (wave) {
     case 0: main_loop(std::integral_constant<int, 0>{}); break;
@@ -879,7 +902,7 @@ __global__ __launch_bounds__(768, 3) void conv_wino44b_kernel(const ConvArgs a) 
 }
 
 inline KernelEntry wino44_entry() {
-  static_assert(W44::LDS_BYTES == W44odd::LDS_BYTES, "one dynamic-LDS size for both width classes");
+  static_assert(W44::LDS_BYTES >= W44odd::LDS_BYTES, "the entry carries one dynamic-LDS size for both width classes");
   return KernelEntry{conv_wino44_kernel<W44>, W44::LDS_BYTES, 512, conv_wino44_kernel<W44odd>};
 }
 // twelve waves; odd widths (Win % 4 != 0) fall back to the eight-wave dword-staging kernel -- its own LDS size and block size
@@ -888,7 +911,7 @@ inline KernelEntry wino44b_entry() {
   constexpr size_t ring = (size_t)(3 * W44::WSZ + 3 * W44::XSZP) * sizeof(float);
   constexpr size_t exch = (size_t)2 * 4 * 12 * 4 * 64 * sizeof(float);
   constexpr size_t lds = ring > exch ? ring : exch;
-  KernelEntry e{conv_wino44b_kernel<W44>, lds > W44odd::LDS_BYTES ? lds : W44odd::LDS_BYTES, 768, conv_wino44_kernel<W44odd>};
+  KernelEntry e{conv_wino44b_kernel<W44>, lds > W44::LDS_BYTES ? lds : W44::LDS_BYTES, 768, conv_wino44_kernel<W44odd>};
   e.threads_odd = 512;
   return e;
 }
