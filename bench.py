@@ -232,15 +232,15 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
 
 
 KIND_NAMES = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2", "3x3s1_wino", "3x3d2_wino", "1x1s1_k32",
-              "1x1s1_k64", "7x7s2p1", "3x3s1_n8", "3x3s1_wino44"]
-WINO_KINDS = (8, 9, 14)       # conv.h: Winograd kinds execute fewer MACs than the direct form:
-WINO_RATIO = {8: 2.25, 9: 2.25, 14: 4.0}   # F(2x2,3x3) 16/36 of them, F(4x4,3x3) (CONV_3x3_S1_WINO44) 36/144
+              "1x1s1_k64", "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44"]
+WINO_KINDS = (8, 9, 14, 15)   # conv.h: Winograd kinds execute fewer MACs than the direct form:
+WINO_RATIO = {8: 2.25, 9: 2.25, 14: 4.0, 15: 4.0}   # F(2x2,3x3) 16/36 of them, F(4x4,3x3) (CONV_3x3_{S1,D2}_WINO44) 36/144
 
 
 def kernel_label(kind, tile):
     """Kernel template a (kind, tile) pair of conv.h launches (names as rocprofv3 prints them)."""
     if kind in WINO_KINDS:
-        k = "conv_wino44_kernel" if kind == 14 else "conv_wino4_kernel" if tile in (29, 30) else (
+        k = "conv_wino44_kernel" if kind in (14, 15) else "conv_wino4_kernel" if tile in (29, 30) else (
             "conv_wino2_kernel" if 21 <= tile <= 24 else "conv_wino_kernel")
         return "%s<%s, tile %d>" % (k, KIND_NAMES[kind], tile)
     if kind == 13:            # conv.h: CONV_3x3_S1_N8, the vector-ALU kernel of the narrow heads (conv_n8.h)

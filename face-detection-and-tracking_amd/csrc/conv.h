@@ -24,6 +24,7 @@ enum ConvKind {
   CONV_7x7_S2_P1,   // pad 1 (stem of pyramid_mb2_try4.py:16: conv_bn with a 7x7 kernel, padding left at 1)
   CONV_3x3_S1_N8,   // same arithmetic class as CONV_3x3_S1, 8 output channels per workgroup on the packed-f32 VALU (conv_n8.h)
   CONV_3x3_S1_WINO44,  // same arithmetic class as CONV_3x3_S1, Winograd F(4x4,3x3): 36 taps, two input channels per stage (conv_wino44.h)
+  CONV_3x3_D2_WINO44,  // same arithmetic class as CONV_3x3_S1_D2 (dilation 2), Winograd F(4x4,3x3) on the parity sub-lattices
   CONV_KIND_COUNT
 };
 

@@ -109,6 +109,7 @@ struct Table {
     conv_fill_1x1_s1_deep(e[CONV_1x1_S1_K32], e[CONV_1x1_S1_K64]);
     conv_fill_n8(e[CONV_3x3_S1_N8]);
     conv_fill_wino44(e[CONV_3x3_S1_WINO44]);
+    conv_fill_wino44_d2(e[CONV_3x3_D2_WINO44]);
   }
 };
 
@@ -121,7 +122,7 @@ const ConvGeom kGeoms[CONV_KIND_COUNT] = {
     {1, 1, 1, 1, 0, 16, 0}, {1, 1, 2, 1, 0, 16, 0}, {3, 3, 1, 1, 1, 4, 0}, {3, 3, 1, 2, 2, 4, 0},
     {3, 3, 2, 1, 1, 4, 0},  {7, 7, 2, 1, 3, 2, 0},  {7, 7, 4, 1, 3, 2, 0}, {5, 5, 2, 1, 2, 2, 0},
     {3, 3, 1, 1, 1, 8, 1},  {3, 3, 1, 2, 2, 8, 1},  {1, 1, 1, 1, 0, 32, 0},  {1, 1, 1, 1, 0, 64, 0},
-    {7, 7, 2, 1, 1, 2, 0},  {3, 3, 1, 1, 1, 1, 0},  {3, 3, 1, 1, 1, 2, 2},
+    {7, 7, 2, 1, 1, 2, 0},  {3, 3, 1, 1, 1, 1, 0},  {3, 3, 1, 1, 1, 2, 2},  {3, 3, 1, 2, 2, 2, 2},
 };
 const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum ConvTile)
     {128, 128, 8, 16}, {128, 64, 8, 16}, {128, 32, 8, 16}, {64, 64, 8, 8},   {64, 128, 8, 8},
@@ -149,7 +150,8 @@ ConvKind conv_base_kind(ConvKind k) {
     case CONV_3x3_S1_WINO:
     case CONV_3x3_S1_WINO44:
     case CONV_3x3_S1_N8: return CONV_3x3_S1;
-    case CONV_3x3_D2_WINO: return CONV_3x3_S1_D2;
+    case CONV_3x3_D2_WINO:
+    case CONV_3x3_D2_WINO44: return CONV_3x3_S1_D2;
     case CONV_1x1_S1_K32:
     case CONV_1x1_S1_K64: return CONV_1x1_S1;
     default: return k;
@@ -250,6 +252,8 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
   if (a.res) FDT_REQUIRE(a.res_coff + a.Cout <= a.res_ctot, FDT_ERR_ARG, "launch_conv: bad residual slice");
   if (a.up) FDT_REQUIRE(a.up_h * 2 >= a.Hout && a.up_w * 2 >= a.Wout && a.up_h >= 1 && a.up_w >= 1,
                         FDT_ERR_ARG, "launch_conv: upsample source too small");
+  FDT_REQUIRE(!(kind == CONV_3x3_D2_WINO44 && (a.Win & 3)), FDT_ERR_ARG,
+              "launch_conv: the dilated Winograd F(4x4,3x3) kernel is not instantiated for Win %% 4 != 0");
   if (dev < 0) FDT_HIP(hipGetDevice(&dev));
   FDT_REQUIRE(dev < 16, FDT_ERR_ARG, "launch_conv: device index %d out of range", dev);
   if (!table().attr_set[dev][kind][tile].load(std::memory_order_acquire)) {
@@ -339,6 +343,7 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
   }
   if (kind == CONV_3x3_S1 && tile_is_wino((ConvTile)tile)) kind = CONV_3x3_S1_WINO;
   if (kind == CONV_3x3_S1 && tile_is_wino44((ConvTile)tile)) kind = CONV_3x3_S1_WINO44;
+  if (kind == CONV_3x3_S1_D2 && tile == TILE_WINO44_32x64) kind = CONV_3x3_D2_WINO44;
   if (kind == CONV_3x3_S1_D2 && tile_is_wino((ConvTile)tile)) kind = CONV_3x3_D2_WINO;
   if (kind == CONV_3x3_S1 && tile == TILE_N8_32x64) kind = CONV_3x3_S1_N8;
   FDT_REQUIRE(tile >= 0 && tile < CONV_TILE_COUNT && conv_supported((ConvKind)kind, (ConvTile)tile), FDT_ERR_ARG,

@@ -7,4 +7,8 @@ void conv_fill_wino44(void* row) {
   r[TILE_WINO44_32x64] = wino44_entry();
   r[TILE_WINO44B_32x64] = wino44b_entry();
 }
+void conv_fill_wino44_d2(void* row) {
+  KernelEntry* r = (KernelEntry*)row;
+  r[TILE_WINO44_32x64] = wino44d2_entry();
+}
 }  // namespace fdt

@@ -67,21 +67,23 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 x, f32x2 y) {
 
 // VEC: Win % 4 == 0 -- the patch is staged as 16-byte pieces of the aligned superset [ox0 - 4, ox0 + 36) of its columns (ONE
 // LDS-DMA instruction per wave and k-step instead of three dword ones); the odd-width variant stages it dword by dword.
-template <bool VEC_>
+template <bool VEC_, int D_ = 1>
 struct W44T {
   static constexpr bool VEC = VEC_;
-  static constexpr int TTH = 4, TTW = 8;                 // 4 x 8 tiles of 4x4 outputs
+  static constexpr int D = D_;                           // dilation (= padding): 1, or 2 for the SSH context convs (pyramid.py:36,38)
+  static constexpr int TTH = 4, TTW = 8;                 // 4 x 8 tiles of 4x4 outputs (D = 2: 2 x 4 cells of 8x8 pixels = 4 parity tiles each)
   static constexpr int TH = 4 * TTH, TW = 4 * TTW;       // 16 x 32 output pixels per workgroup
   static constexpr int BN = 64;                          // output channels per workgroup
-  static constexpr int PH = TH + 2, PWU = TW + 2;        // staged patch: 18 rows of 34 pixels ...
+  static constexpr int PH = TH + 2 * D, PWU = TW + 2 * D;   // staged patch: 18 rows of 34 pixels (D = 2: 20 x 36) ...
   static constexpr int PW = VEC ? 40 : 36;               // ... at a row pitch of 40 (ten 16-byte pieces) / 36 floats
-  // VEC: piece j of a row holds columns ox0 - 4 + 4 j ..; the ring slot starts 4 bytes into its 16-byte unit, so that the
-  // window column 0 (= image column ox0 - 1 + 4 tx) sits at float 4 + 4 tx of the row: 16-byte aligned ds_read_b128
-  static constexpr int XSHIFT = VEC ? 1 : 0, XWIN = VEC ? 4 : 0;
-  static constexpr int XPLANE = PH * PW;                 // 720 / 648 floats per channel
+  // VEC: piece j of a row holds columns ox0 - 4 + 4 j ..; the ring slot starts 4 bytes into its 16-byte unit, so that (D = 1)
+  // the window column 0 (= image column ox0 - 1 + 4 tx) sits at float 4 + 4 tx of the row: 16-byte aligned ds_read_b128.
+  // D = 2 windows are read as dword pairs two columns apart (no alignment to keep): column 0 = image column ox0 - 2 -> float 3
+  static constexpr int XSHIFT = VEC ? 1 : 0, XWIN = VEC ? XSHIFT + 4 - D : 0;
+  static constexpr int XPLANE = PH * PW;                 // 720 (800) / 648 floats per channel
   static constexpr int XSZ = 2 * XPLANE;                 // two channels per k-step
-  static constexpr int XPIECES = XSZ / 4;                // VEC: 360 pieces of 16 bytes = lanes of waves 0..5
-  static constexpr int XSZP = VEC ? 1600 : 1536;         // slot: 6 waves x 64 pieces + shift / 3 dword instructions x 512 threads
+  static constexpr int XPIECES = XSZ / 4;                // VEC: 360 (400) pieces of 16 bytes = lanes of waves 0..5 (+ 16 lanes of wave 6)
+  static constexpr int XSZP = VEC ? (D == 1 ? 1600 : 1616) : 1536;   // ring slot
   static constexpr int WSZ = 2 * 36 * BN;                // 4608 floats of transformed weights per k-step: 2 x (8 waves x 1 KB) + 2 KB
   static constexpr int VSZ = 36 * 64;                    // transformed input of a k-step: [position][channel][tile]
   static constexpr int U_SLOTS = 4, R_SLOTS = 4, V_SLOTS = 4;   // four each: the loop is unrolled by four, every ring offset an immediate
@@ -89,13 +91,16 @@ struct W44T {
   static constexpr int EXCH = 2 * 4 * 8 * 8 * 64;        // epilogue exchange: [cout half][group][8 regs][8 values][lane]
   static constexpr size_t LDS_BYTES = (size_t)(RING > EXCH ? RING : EXCH) * sizeof(float);
   // LDS-DMA instructions per wave per k-step.  VEC: two 1 KB pieces of the weights + (waves 0..5) the patch piece or (waves
-  // 6, 7) the last 2 KB of the weights; else 2 + 1 dword of weights + 3 dwords of patch
+  // 6, 7) the last 2 KB of the weights (+ D = 2, wave 6: the patch pieces 384..399); else 2 + 1 dword of weights + 3 dwords of patch
   static constexpr int LOADS = VEC ? 3 : 6;
-  static_assert(WSZ == 2 * 2048 + 512 && (!VEC || (XPIECES <= 6 * 64 && XSHIFT + 6 * 64 * 4 <= XSZP)), "staging plan");
+  static_assert(D == 1 || (D == 2 && VEC), "the dilated form exists for Win % 4 == 0 only");
+  static_assert(WSZ == 2 * 2048 + 512 && (!VEC || (XPIECES <= 6 * 64 + 16 && XSHIFT + XPIECES * 4 <= XSZP && XSHIFT + 6 * 64 * 4 <= XSZP)),
+                "staging plan");
   static_assert((R0 % 4) == 0 && (XSZP % 4) == 0 && (V0 % 4) == 0, "16-byte aligned LDS regions");
 };
 using W44 = W44T<true>;
 using W44odd = W44T<false>;
+using W44D2 = W44T<true, 2>;
 
 template <class T>
 __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
@@ -142,8 +147,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     const int c = e / (T::XPLANE / 4);
     const int r = e - c * (T::XPLANE / 4);
     const int yy = r / (T::PW / 4), j = r - yy * (T::PW / 4);
-    const int gy = oy0 - 1 + yy, gx = ox0 - 4 + 4 * j;
-    if (e < T::XPIECES && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) xvo = (unsigned)(c * HW + gy * a.Win + gx) * 4u;
+    const int gy = oy0 - T::D + yy, gx = ox0 - 4 + 4 * j;
+    if (e < 384 && e < T::XPIECES && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) xvo = (unsigned)(c * HW + gy * a.Win + gx) * 4u;
+    if (T::D == 2 && wave == 6) {                          // pieces 384 .. 399: sixteen lanes of wave 6, a fourth instruction
+      const int e2 = 384 + lane;
+      const int c2 = e2 / (T::XPLANE / 4);
+      const int r2 = e2 - c2 * (T::XPLANE / 4);
+      const int yy2 = r2 / (T::PW / 4), j2 = r2 - yy2 * (T::PW / 4);
+      const int gy2 = oy0 - T::D + yy2, gx2 = ox0 - 4 + 4 * j2;
+      if (e2 < T::XPIECES && gy2 >= 0 && gy2 < a.Hin && gx2 >= 0 && gx2 < a.Win) xvo = (unsigned)(c2 * HW + gy2 * a.Win + gx2) * 4u;
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
 
   // LDS-DMA of one k-step into compile-time ring slots: weights U(su) -> slot US, raw patch R(sr) -> slot RS.  k-steps past the
   // end of this workgroup's share are clamped to its last one (valid addresses, the same instruction count; never consumed).
-  auto issue_w = [&](auto tail_c, auto us_c, auto rs_c, int su, int sr) {
+  auto issue_w = [&](auto tail_c, auto extra_c, auto us_c, auto rs_c, int su, int sr) {
     constexpr bool TAILW = decltype(tail_c)::value;     // waves 6, 7: the last 2 KB of the weights instead of a patch piece
     constexpr int US = decltype(us_c)::value, RS = decltype(rs_c)::value;
     const int suc = su < nst ? su : nst - 1, src_ = sr < nst ? sr : nst - 1;
@@ -169,10 +182,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
       const unsigned ub = (unsigned)((s_begin + suc) * T::WSZ) * 4u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(U_ + wave * 256), 16, wvo, ub + (unsigned)wave * 1024u, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(U_ + 2048 + wave * 256), 16, wvo, ub + 8192u + (unsigned)wave * 1024u, 0, 0);
-      if constexpr (TAILW)
+      if constexpr (TAILW) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(U_ + 4096 + (wave - 6) * 256), 16, wvo,
                                                  ub + 16384u + (unsigned)(wave - 6) * 1024u, 0, 0);
-      else
+        if constexpr (decltype(extra_c)::value)            // D = 2, wave 6: the last sixteen patch pieces -- ONLY those lanes
+          if (lane < T::XPIECES - 384)                     // (an LDS-DMA lane writes its 16 bytes wherever it points: the rest would land in the next ring slot)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(smem + T::R0 + RS * T::XSZP + T::XSHIFT + 6 * 256), 16, xvo,
+                                                   (unsigned)(s_begin + src_) * 2u * (unsigned)HW * 4u, 0, 0);
+      } else
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(smem + T::R0 + RS * T::XSZP + T::XSHIFT + wave * 256), 16, xvo,
                                                  (unsigned)(s_begin + src_) * 2u * (unsigned)HW * 4u, 0, 0);
     } else {
@@ -200,8 +217,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
   // transform role: lane = (channel = half, tile = l31); the tile's 6x6 window starts at (4 ty, 4 tx) of the staged patch
-  const int ty = l31 >> 3, tx = l31 & 7;
-  const unsigned xbase = lds0 + (unsigned)(T::R0 + T::XWIN + half * T::XPLANE + 4 * ty * T::PW + 4 * tx) * 4u;
+  // D = 1: tile (ty, tx) of the 4 x 8 grid, outputs (4 ty + u, 4 tx + v);  D = 2: cell (cy, cx) of the 2 x 4 grid of 8x8-pixel
+  // cells, parity (py, px): outputs (8 cy + py + 2 u, 8 cx + px + 2 v), window = every second pixel from (8 cy + py, 8 cx + px)
+  const int ty = T::D == 1 ? (l31 >> 3) : (l31 >> 4), tx = T::D == 1 ? (l31 & 7) : ((l31 >> 2) & 3);
+  const int py = (l31 >> 1) & 1, px = l31 & 1;
+  const int oyl = T::D == 1 ? 4 * ty : 8 * ty + py, oxl = T::D == 1 ? 4 * tx : 8 * tx + px;     // first output pixel of the tile
+  const unsigned xbase = lds0 + (unsigned)(T::R0 + T::XWIN + half * T::XPLANE + oyl * T::PW + oxl) * 4u;
   const unsigned vwbase = lds0 + (unsigned)(T::V0 + lane) * 4u;
   // MFMA role
   const unsigned abase = lds0 + (unsigned)(T::U0 + half * 36 * T::BN + pg * 9 * T::BN + h * 32 + l31) * 4u;
@@ -244,8 +265,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
   // One row of V = B^T d B for this lane's (channel, tile):  B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0;
   //                                                                0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
   struct Raw {
-    f32x4 lo[4];      // columns 0..3 of the window rows this role needs
-    f32x2 hi[4];      // columns 4, 5
+    f32x4 lo[4];      // D = 1: columns 0..3 of the window rows this role needs
+    f32x2 hi[4];      //        columns 4, 5
+    f32x2 pr[4][3];   // D = 2: column pairs (0,1) (2,3) (4,5), read as dword pairs two image columns apart
   };
   const f32x2 k4 = {4.0f, 4.0f}, km5 = {-5.0f, -5.0f}, km4 = {-4.0f, -4.0f}, k2 = {2.0f, 2.0f}, km2 = {-2.0f, -2.0f};
 
@@ -254,10 +276,30 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     constexpr int R0_ = (ROLE == 0) ? 0 : 1;                       // first window row needed
     constexpr int RSTEP = (ROLE == 0 || ROLE == 5) ? 2 : 1;        // rows 0,2,4 / 1,2,3,4 / 1,3,5
     constexpr int NROW = (ROLE == 0 || ROLE == 5) ? 3 : 4;
-    constexpr int NRAW = (ROLE < 6) ? 2 * NROW : 0;
+    constexpr int NRAW = (ROLE < 6) ? (T::D == 2 ? 3 : 2) * NROW : 0;
     auto raw_reads = [&](Raw& w, auto rs_c) {
       constexpr int SO = decltype(rs_c)::value * T::XSZP * 4;       // byte offset of the ring slot
-      if constexpr (ROLE < 6) {
+      if constexpr (ROLE < 6 && T::D == 2) {
+        // window row i = patch row 2 i, column c = patch column 2 c: ds_read2_b32 (8-bit dword offsets, two columns = 4 dwords
+        // apart per pair) from a per-k-step base = ring slot + first row (one v_add; a second one for the rows beyond 255 dwords)
+        constexpr int ROWD = 2 * T::PW;                             // dwords between window rows
+        const unsigned xa = xbase + (unsigned)(SO + R0_ * ROWD * 4);
+        const unsigned xb2 = xa + (unsigned)(2 * RSTEP * ROWD * 4);
+        static_assert(RSTEP * ROWD + 10 < 256, "ds_read2_b32 offsets");
+#pragma unroll
+        for (int i = 0; i < NROW; ++i) {
+          const unsigned ad = i < 2 ? xa : xb2;
+          if (i == 0 || i == 2) {
+            lds_read2_b32<0, 2>(w.pr[i][0], ad);
+            lds_read2_b32<4, 6>(w.pr[i][1], ad);
+            lds_read2_b32<8, 10>(w.pr[i][2], ad);
+          } else {
+            lds_read2_b32<RSTEP * ROWD + 0, RSTEP * ROWD + 2>(w.pr[i][0], ad);
+            lds_read2_b32<RSTEP * ROWD + 4, RSTEP * ROWD + 6>(w.pr[i][1], ad);
+            lds_read2_b32<RSTEP * ROWD + 8, RSTEP * ROWD + 10>(w.pr[i][2], ad);
+          }
+        }
+      } else if constexpr (ROLE < 6) {
         w44_read_b128<SO + (R0_ + 0 * RSTEP) * T::PW * 4>(w.lo[0], xbase);
         w44_read_b64<SO + ((R0_ + 0 * RSTEP) * T::PW + 4) * 4>(w.hi[0], xbase);
         w44_read_b128<SO + (R0_ + 1 * RSTEP) * T::PW * 4>(w.lo[1], xbase);
@@ -272,7 +314,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     };
     auto wait_raw = [&](Raw& w, auto newer_c) {
       constexpr int N_ = decltype(newer_c)::value;
-      if constexpr (ROLE < 6) {
+      if constexpr (ROLE < 6 && T::D == 2) {
+        if constexpr (NROW == 4)
+          asm volatile("s_waitcnt lgkmcnt(%12)"
+                       : "+v"(w.pr[0][0]), "+v"(w.pr[0][1]), "+v"(w.pr[0][2]), "+v"(w.pr[1][0]), "+v"(w.pr[1][1]), "+v"(w.pr[1][2]),
+                         "+v"(w.pr[2][0]), "+v"(w.pr[2][1]), "+v"(w.pr[2][2]), "+v"(w.pr[3][0]), "+v"(w.pr[3][1]), "+v"(w.pr[3][2])
+                       : "n"(N_));
+        else
+          asm volatile("s_waitcnt lgkmcnt(%9)"
+                       : "+v"(w.pr[0][0]), "+v"(w.pr[0][1]), "+v"(w.pr[0][2]), "+v"(w.pr[1][0]), "+v"(w.pr[1][1]), "+v"(w.pr[1][2]),
+                         "+v"(w.pr[2][0]), "+v"(w.pr[2][1]), "+v"(w.pr[2][2])
+                       : "n"(N_));
+      } else if constexpr (ROLE < 6) {
         if constexpr (NROW == 4)
           asm volatile("s_waitcnt lgkmcnt(%8)"
                        : "+v"(w.lo[0]), "+v"(w.lo[1]), "+v"(w.lo[2]), "+v"(w.lo[3]), "+v"(w.hi[0]), "+v"(w.hi[1]), "+v"(w.hi[2]),
@@ -292,8 +345,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
         for (int pr = 0; pr < 3; ++pr) {
           f32x2 d[4];
 #pragma unroll
-          for (int i = 0; i < NROW; ++i)
-            d[i] = pr == 0 ? __builtin_shufflevector(w.lo[i], w.lo[i], 0, 1) : pr == 1 ? __builtin_shufflevector(w.lo[i], w.lo[i], 2, 3) : w.hi[i];
+          for (int i = 0; i < NROW; ++i) {
+            if constexpr (T::D == 2) d[i] = w.pr[i][pr];
+            else d[i] = pr == 0 ? __builtin_shufflevector(w.lo[i], w.lo[i], 0, 1) : pr == 1 ? __builtin_shufflevector(w.lo[i], w.lo[i], 2, 3) : w.hi[i];
+          }
           if constexpr (ROLE == 0 || ROLE == 5)
             Tp[pr] = pk_fma(k4, d[0], pk_fma(km5, d[1], d[2]));              // 4 d0 - 5 d2 + d4   /   4 d1 - 5 d3 + d5
           else if constexpr (ROLE == 1)
@@ -337,7 +392,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
       v_all(Tp, v);
       v_store(v, vs_c);
     };
-    using TAILc = std::bool_constant<ROLE == 6>;
+    using TAILc = std::bool_constant<ROLE >= 6>;          // waves 6, 7
+    using EXTRAc = std::bool_constant<ROLE == 6 && T::D == 2>;
+    constexpr int LOADS_ = T::LOADS + (EXTRAc::value ? 1 : 0);
     using N0 = std::integral_constant<int, 0>;
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -345,9 +402,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     using S3 = std::integral_constant<int, 3>;
 
     // ---- prologue: U(0), U(1), R(0), R(1), R(2); V(0), V(1); U(2), R(3) in flight; operands of k-step 0 in registers
-    issue_w(TAILc{}, S0{}, S0{}, 0, 0);
-    issue_w(TAILc{}, S1{}, S1{}, 1, 1);
-    issue_w(TAILc{}, S2{}, S2{}, 2, 2);
+    issue_w(TAILc{}, EXTRAc{}, S0{}, S0{}, 0, 0);
+    issue_w(TAILc{}, EXTRAc{}, S1{}, S1{}, 1, 1);
+    issue_w(TAILc{}, EXTRAc{}, S2{}, S2{}, 2, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -363,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     }
     __builtin_amdgcn_s_barrier();          // V(0), V(1) visible; every wave is done with R(0), R(1)
     __builtin_amdgcn_sched_barrier(0);
-    issue_w(TAILc{}, S2{}, S3{}, 2, 3);    // R(3) (U(2) once more: one instruction count per issue)
+    issue_w(TAILc{}, EXTRAc{}, S2{}, S3{}, 2, 3);    // R(3) (U(2) once more: one instruction count per issue)
     Ops X, Y;
     load_ops(X, S0{}, S0{});
     wait_ops(X, N0{});
@@ -388,14 +445,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
       // keep the matrix pipe fed while the workgroup synchronises
       mf(cur, std::integral_constant<int, 0>{});
       mf(cur, std::integral_constant<int, 1>{});
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::LOADS) : "memory");     // everything but the previous k-step's issue has landed
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_) : "memory");       // everything but the previous k-step's issue has landed
       if (!(FDT_W44_EXP & 2)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       Raw w;
       if (!(FDT_W44_EXP & 1)) raw_reads(w, M2{});
       __builtin_amdgcn_sched_barrier(0);
       mf(cur, std::integral_constant<int, 2>{});
-      if (!(FDT_W44_EXP & 4)) issue_w(TAILc{}, M3{}, M0{}, s + 3, s + 4);
+      if (!(FDT_W44_EXP & 4)) issue_w(TAILc{}, EXTRAc{}, M3{}, M0{}, s + 3, s + 4);
       __builtin_amdgcn_sched_barrier(0);
       mf(cur, std::integral_constant<int, 3>{});
       mf(cur, std::integral_constant<int, 4>{});
@@ -436,7 +493,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     case 3: main_loop(std::integral_constant<int, 3>{}); break;
     case 4: main_loop(std::integral_constant<int, 4>{}); break;
     case 5: main_loop(std::integral_constant<int, 5>{}); break;
-    default: main_loop(std::integral_constant<int, 6>{}); break;
+    case 6: main_loop(std::integral_constant<int, 6>{}); break;
+    default: main_loop(std::integral_constant<int, 7>{}); break;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the (clamped) LDS-DMA of the k-steps past the end must not land in the exchange buffer
 
@@ -469,8 +527,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
   float* dst_b = raw ? a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWo
                      : a.out + ((long long)b * a.out_ctot + a.out_coff) * HWo;
   const float* res_b = (!raw && a.res) ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWo : nullptr;
-  const int oy = oy0 + 4 * ty, ox = ox0 + 4 * tx;
-  const bool vec4 = (a.Wout % 4 == 0);
+  const int oy = oy0 + oyl, ox = ox0 + oxl;
+  const bool vec4 = (T::D == 1) && (a.Wout % 4 == 0);      // D = 2: the tile's pixels are two apart, scalar stores
   float* E = smem;
   for (int round = 0; round < 2; ++round) {
     __syncthreads();                       // ring (round 0) / previous round's exchange data is dead
@@ -519,15 +577,41 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
       const float bv = (!raw && a.bias) ? a.bias[co] : 0.0f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (oy + u >= a.Hout) continue;
+        if (oy + T::D * u >= a.Hout) continue;
         float y[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const float s1 = R[1][v] + R[2][v], d1 = R[1][v] - R[2][v], s2 = R[3][v] + R[4][v], d2 = R[3][v] - R[4][v];
           y[v] = u == 0 ? R[0][v] + s1 + s2 : u == 1 ? fmaf(2.0f, d2, d1) : u == 2 ? fmaf(4.0f, s2, s1) : fmaf(8.0f, d2, d1) + R[5][v];
         }
-        const long long off = (long long)co * HWo + (long long)(oy + u) * a.Wout + ox;
-        if (vec4) {
+        const long long off = (long long)co * HWo + (long long)(oy + T::D * u) * a.Wout + ox;
+        if constexpr (T::D == 2) {
+          // The lanes px = 0 / 1 of a cell row hold alternating pixels (8 cx + px + 2 v): one exchange between neighbouring
+          // lanes (DPP quad permutation) gives every lane four CONSECUTIVE pixels -- the even lane 8 cx .. + 3, the odd lane
+          // 8 cx + 4 .. + 7 -- and the row leaves as 16-byte stores like in the undilated form (Wout % 4 == 0 here).
+          const float s0 = px ? y[0] : y[2], s1 = px ? y[1] : y[3];
+          const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));
+          const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, true));
+          float4 o = px ? make_float4(r0, y[2], r1, y[3]) : make_float4(y[0], r0, y[1], r1);
+          const int xs = ox - px + 4 * px;                  // 8 cx (+ 4 for the odd lane)
+          const long long off4 = (long long)co * HWo + (long long)(oy + 2 * u) * a.Wout + xs;
+          if (xs < a.Wout) {
+            if (!raw) {
+              o.x += bv; o.y += bv; o.z += bv; o.w += bv;
+              if (res_b) {
+                const float4 rv = *reinterpret_cast<const float4*>(res_b + off4);
+                o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+              }
+              if (a.act == ACT_RELU) {
+                o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+              } else if (a.act == ACT_RELU6) {
+                o.x = fminf(fmaxf(o.x, 0.f), 6.f); o.y = fminf(fmaxf(o.y, 0.f), 6.f);
+                o.z = fminf(fmaxf(o.z, 0.f), 6.f); o.w = fminf(fmaxf(o.w, 0.f), 6.f);
+              }
+            }
+            *reinterpret_cast<float4*>(dst_b + off4) = o;
+          }
+        } else if (vec4) {
           float4 o = make_float4(y[0], y[1], y[2], y[3]);
           if (!raw) {
             o.x += bv; o.y += bv; o.z += bv; o.w += bv;
@@ -546,15 +630,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
         } else {
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
-            if (ox + v >= a.Wout) continue;
+            if (ox + T::D * v >= a.Wout) continue;
             float o = y[v];
             if (!raw) {
               o += bv;
-              if (res_b) o += res_b[off + v];
+              if (res_b) o += res_b[off + T::D * v];
               if (a.act == ACT_RELU) o = fmaxf(o, 0.f);
               else if (a.act == ACT_RELU6) o = fminf(fmaxf(o, 0.f), 6.f);
             }
-            dst_b[off + v] = o;
+            dst_b[off + T::D * v] = o;
           }
         }
       }
@@ -905,6 +989,10 @@ inline KernelEntry wino44_entry() {
   static_assert(W44::LDS_BYTES >= W44odd::LDS_BYTES, "the entry carries one dynamic-LDS size for both width classes");
   return KernelEntry{conv_wino44_kernel<W44>, W44::LDS_BYTES, 512, conv_wino44_kernel<W44odd>};
 }
+// dilation 2 (the SSH context convs): eight-wave form only, Win % 4 == 0 only (launch_conv refuses other widths)
+inline KernelEntry wino44d2_entry() {
+  return KernelEntry{conv_wino44_kernel<W44D2>, W44D2::LDS_BYTES, 512};
+}
 // twelve waves; odd widths (Win % 4 != 0) fall back to the eight-wave dword-staging kernel -- its own LDS size and block size
 // differ, so the entry carries the larger LDS request and launch_conv picks threads per variant (KernelEntry::threads_odd)
 inline KernelEntry wino44b_entry() {
@@ -919,5 +1007,6 @@ inline KernelEntry wino44b_entry() {
 }  // namespace
 
 void conv_fill_wino44(void* row);
+void conv_fill_wino44_d2(void* row);
 
 }  // namespace fdt

@@ -1916,6 +1916,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
     const ConvKind base = conv_base_kind(op.kind);
     for (int k = 0; k < CONV_KIND_COUNT; ++k) {
       if (conv_base_kind((ConvKind)k) != base) continue;    // e.g. direct and Winograd 3x3/s1
+      if (k == CONV_3x3_D2_WINO44 && (op.ca.Win & 3)) continue;   // instantiated for Win % 4 == 0 only
       const int nstages = ceil_div(op.ca.Cin, conv_geom((ConvKind)k).kc);
       for (int t = 0; t < CONV_TILE_COUNT; ++t) {
         if (!conv_supported((ConvKind)k, (ConvTile)t)) continue;

@@ -251,3 +251,26 @@ def test_winograd_f4x4(shape, tile):
             assert rel_err(got, exp) < WINO44_TOL, (shape, split, list(kw), rel_err(got, exp))
             rms = float(np.sqrt(((got.astype(np.float64) - exp) ** 2).mean()) / np.sqrt((exp.astype(np.float64) ** 2).mean()))
             assert rms < 1e-5, (shape, split, rms)
+
+
+@pytest.mark.parametrize("shape", [(64, 40, 48, 96), (37, 28, 44, 70), (7, 16, 32, 64), (256, 64, 64, 128)])
+def test_winograd_f4x4_dilated(shape):
+    """The dilation-2 form of the F(4x4,3x3) kernel (the SSH context convs, pyramid.py:36,38): Winograd on the four parity
+    sub-lattices of 8x8-pixel cells.  Widths are multiples of 4 (the only widths it is instantiated for; others are refused)."""
+    Cin, H, W, Cout = shape
+    rng = np.random.default_rng(H * 17 + Cin)
+    x = rng.standard_normal((2, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((2, Cout, H, W)).astype(np.float32)
+    for kw in (dict(act=0), dict(res=res, act=1)):
+        exp = reference(x, w, b, 3, 1, 2, 2, **kw)
+        for split in (1, 2, 3):
+            if split > max(1, (Cin + 1) // 2):
+                continue
+            rc, got = run_conv(x, w, b, 3, 1, 2, 2, tile=T_WINO44, split=split, **kw)
+            assert rc == 0, lib().lib().fdt_last_error()
+            assert rel_err(got, exp) < WINO44_TOL, (shape, split, list(kw), rel_err(got, exp))
+    xo = rng.standard_normal((1, 8, 12, 30)).astype(np.float32)            # Win % 4 != 0: refused, not mis-computed
+    rc, _ = run_conv(xo, w[:8, :8].copy(), b[:8].copy(), 3, 1, 2, 2, tile=T_WINO44)
+    assert rc != 0 and b"not instantiated" in lib().lib().fdt_last_error()
