@@ -28,6 +28,8 @@ template __global__ void conv_wino4_kernel<WD2_64x64R3>(const ConvArgs);
 // Winograd F(4x4,3x3) (conv_wino44.h): window reads, operand prefetch and V writes all hand-issued, seven role instances
 template __global__ void conv_wino44_kernel<W44>(const ConvArgs);
 template __global__ void conv_wino44_kernel<W44odd>(const ConvArgs);
+template __global__ void conv_wino44_kernel<W44D2>(const ConvArgs);          // dilation 2: dword-pair window reads
+template __global__ void conv_wino44b_kernel<W44>(const ConvArgs);           // twelve-wave form
 // the direct kernel's pipelined main loop (conv_kernel.h): 1 + 1, 2 + 1 and 2 + 2 operand registers per step
 template __global__ void conv_kernel<G_1x1_S1_K32, T_64x64>(const ConvArgs);
 template __global__ void conv_kernel<G_1x1_S1, T_128x64W>(const ConvArgs);
@@ -57,9 +59,14 @@ def test_async_lds_reads_have_no_hazards(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:]
     assert ": 0 hazards" in r.stdout
     # conv_wino44_kernel: 9 accumulator tiles + two operand sets + the window rows must fit two waves per SIMD without spills
-    for nm in ("conv_wino44_kernelINS0_4W44TILb1EEEEEvNS_8ConvArgsE", "conv_wino44_kernelINS0_4W44TILb0EEEEEvNS_8ConvArgsE"):
+    for nm in ("conv_wino44_kernelINS0_4W44TILb1ELi1EEEEEvNS_8ConvArgsE", "conv_wino44_kernelINS0_4W44TILb0ELi1EEEEEvNS_8ConvArgsE",
+               "conv_wino44_kernelINS0_4W44TILb1ELi2EEEEEvNS_8ConvArgsE"):
         meta44 = text.split(".name:           _ZN3fdt12_GLOBAL__N_118" + nm, 1)[1][:1500]
         assert ".vgpr_spill_count: 0" in meta44 and int(meta44.split(".vgpr_count:")[1].split()[0]) <= 256
+    # ... and its main loops carry no vector-ALU address arithmetic (the matrix pipe and the VALU do not co-execute on this chip):
+    # every LDS-DMA of the Win % 4 == 0 forms is a buffer load with a scalar offset, never a global load behind 64-bit VALU adds
+    body44 = text.split("conv_wino44_kernelINS0_4W44TILb1ELi1EEEEEvNS_8ConvArgsE:", 1)[1].split("s_endpgm", 1)[0]
+    assert body44.count("buffer_load_dwordx4") >= 21 and "global_load_lds" not in body44
     # conv_n8_kernel<true>: a spill reloaded inside its loop would carry a vmcnt(0) that serialises the LDS-DMA pipeline
     # (measured: no load/compute overlap at all) -- the fast variant must stay spill-free at four waves per SIMD
     body = text.split("conv_n8_kernelILb1EEEvNS_8ConvArgsE:", 1)[1].split("s_endpgm", 1)[0]
