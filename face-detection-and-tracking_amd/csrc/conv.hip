@@ -252,9 +252,9 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
   if (a.res) FDT_REQUIRE(a.res_coff + a.Cout <= a.res_ctot, FDT_ERR_ARG, "launch_conv: bad residual slice");
   if (a.up) FDT_REQUIRE(a.up_h * 2 >= a.Hout && a.up_w * 2 >= a.Wout && a.up_h >= 1 && a.up_w >= 1,
                         FDT_ERR_ARG, "launch_conv: upsample source too small");
-  // the F(4x4) kernels address one image through a buffer descriptor (32-bit byte offsets, bounds-checked)
-  FDT_REQUIRE(!((kind == CONV_3x3_S1_WINO44 || kind == CONV_3x3_D2_WINO44) && (long long)a.Cin * a.Hin * a.Win * 4 >= (1ll << 31)),
-              FDT_ERR_ARG, "launch_conv: input image of %d x %d x %d exceeds the 2 GB a buffer descriptor addresses", a.Cin, a.Hin, a.Win);
+  // the kernels address one image through a buffer descriptor (32-bit byte offsets, bounds-checked)
+  FDT_REQUIRE((long long)a.Cin * a.Hin * a.Win * 4 < (1ll << 31), FDT_ERR_ARG,
+              "launch_conv: input image of %d x %d x %d exceeds the 2 GB a buffer descriptor addresses", a.Cin, a.Hin, a.Win);
   FDT_REQUIRE(!(kind == CONV_3x3_D2_WINO44 && (a.Win & 3)), FDT_ERR_ARG,
               "launch_conv: the dilated Winograd F(4x4,3x3) kernel is not instantiated for Win %% 4 != 0");
   if (dev < 0) FDT_HIP(hipGetDevice(&dev));

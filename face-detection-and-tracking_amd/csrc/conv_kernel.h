@@ -55,7 +55,7 @@ struct Layout {
   static constexpr int LOADS = NX + NW;                  // LDS-DMA wave-instructions per stage
   static_assert((T::NBUF >= 4 ? 2 : 1) * LOADS < 64, "vmcnt is 6 bits");
   static_assert(G::KC % 2 == 0, "k-pairs are two input channels at one tap");
-  static_assert(NX <= 32, "okmask is 32 bits");
+  static_assert(NX <= 32, "per-lane staging offsets live in registers");
 };
 
 __device__ float g_zero_pad[4];   // source of every padded / out-of-image element (zero-initialised)
@@ -70,6 +70,23 @@ __device__ __forceinline__ void glds4(const float* g, float* l) {
 }
 __device__ __forceinline__ void glds16(const float* g, float* l) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+// LDS-DMA through a buffer descriptor: lane address = base + scalar offset + per-lane offset, bounds-checked against num_records
+// INCLUDING the scalar offset on gfx950 (tools/microbench/buffer_oob_probe.hip) -- an out-of-range lane stages zeros.  The conv
+// kernels use it so that a stage's addresses are ONE scalar add (the channel / stage offset) on per-lane offsets that never
+// change: padding and out-of-image elements carry kOob, the channels past Cin fall off the end of the descriptor.  (The matrix
+// pipe and the vector ALU of a SIMD do not co-execute here -- SQ_VALU_MFMA_COEXEC_CYCLES = 0 -- so the per-load pointer selects
+// and 64-bit adds of the global_load form were paid in MFMA time.)
+constexpr unsigned kOob = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p, long long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void bglds4(__amdgpu_buffer_rsrc_t r, float* l, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)l, 4, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void bglds16(__amdgpu_buffer_rsrc_t r, float* l, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)l, 16, voff, soff, 0, 0);
 }
 
 // Compile-time loop: f(std::integral_constant<int, I>{}) for I = I0 .. N-1 (the step index feeds "n" asm constraints).
@@ -117,12 +134,12 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
 
   // ---- per-lane staging plan (invariant over the stages) --------------------------------------------
   // Element e = 256*k + tid of the [KC][PH][PW] patch is fetched by lane (tid & 63) of wave (tid >> 6)
-  // with its k-th LDS-DMA instruction.  Padding / out-of-image elements read g_zero_pad instead, so
-  // the loads are unconditional and nothing is predicated per lane.
-  const float* zpad = g_zero_pad;          // materialised once: as a symbol it is re-fetched through the GOT
-  asm volatile("" : "+s"(zpad));            // (an SMEM load, i.e. a full lgkmcnt(0) wait) inside the main loop
-  int goff[L::NX];
-  unsigned okmask = 0;
+  // with its k-th LDS-DMA instruction: a buffer load at byte offset xoff[k] (relative to the stage's first
+  // channel) -- or kOob for padding / out-of-image elements, which the descriptor's bounds check turns into
+  // zeros, like the channels past Cin.  The loads are unconditional and carry no per-stage vector arithmetic.
+  const __amdgpu_buffer_rsrc_t xrs = buf_rsrc(in_b, (long long)a.Cin * HWin * 4);
+  const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(w_t, 0x7fffffffll);
+  unsigned xoff[L::NX];
   const bool vecx = L::VECX && (a.Win % 4 == 0);
   if (L::VECX && vecx) {
     // float4 v = 256*k + tid covers 4 consecutive pixels of one tile row of one channel
@@ -133,8 +150,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
       int p = (v - c * (T::BM / 4)) * 4;
       int gy = oy0 + p / T::TW, gx = ox0 + p % T::TW;
       bool ok = gy < a.Hin && gx < a.Win;
-      goff[k] = ok ? (c * HWin + gy * a.Win + gx) : 0;
-      if (ok) okmask |= (1u << k);
+      xoff[k] = ok ? (unsigned)(c * HWin + gy * a.Win + gx) * 4u : kOob;
     }
   } else
 #pragma unroll
@@ -146,33 +162,22 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
     int gy = oy0 * G::S - G::PAD + yy * G::PS;
     int gx = ox0 * G::S - G::PAD + xx * G::PS;
     bool ok = (e < L::XSZ) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-    goff[k] = ok ? (c * HWin + gy * a.Win + gx) : 0;
-    if (ok) okmask |= (1u << k);
+    xoff[k] = ok ? (unsigned)(c * HWin + gy * a.Win + gx) * 4u : kOob;
   }
 
 #define FDT_STAGE(s_, buf_)                                                                 \
   {                                                                                         \
-    const int c0_ = (s_) * G::KC;                                                           \
-    const float* src_ = in_b + (long long)c0_ * HWin;                                       \
-    const int crem_ = a.Cin - c0_;                                                          \
+    const unsigned xso_ = (unsigned)((s_) * G::KC) * (unsigned)HWin * 4u;                   \
     if (L::VECX && vecx) {                                                                  \
       float* X_ = smem + (buf_) * L::STAGE + wave * 256;                                    \
-      _Pragma("unroll") for (int k = 0; k < L::NXV; ++k) {                                  \
-        const int c_ = (tid + 256 * k) / (T::BM / 4);                                       \
-        const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                \
-        glds16(ok_ ? src_ + goff[k] : zpad, X_ + 1024 * k);                           \
-      }                                                                                     \
+      _Pragma("unroll") for (int k = 0; k < L::NXV; ++k) bglds16(xrs, X_ + 1024 * k, xoff[k], xso_); \
     } else {                                                                                \
       float* X_ = smem + (buf_) * L::STAGE + wave * 64;                                     \
-      _Pragma("unroll") for (int k = 0; k < L::NX; ++k) {                                   \
-        const int c_ = (tid + 256 * k) / L::XPLANE;                                         \
-        const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                \
-        glds4(ok_ ? src_ + goff[k] : zpad, X_ + 256 * k);                             \
-      }                                                                                     \
+      _Pragma("unroll") for (int k = 0; k < L::NX; ++k) bglds4(xrs, X_ + 256 * k, xoff[k], xso_);    \
     }                                                                                       \
-    const float* wsrc_ = w_t + (long long)(s_) * L::WSZP + tid * 4;                         \
+    const unsigned wso_ = (unsigned)((s_) * L::WSZP) * 4u;                                  \
     float* W_ = smem + (buf_) * L::STAGE + L::XSZP + wave * 256;                            \
-    _Pragma("unroll") for (int k = 0; k < L::NW; ++k) glds16(wsrc_ + 1024 * k, W_ + 1024 * k); \
+    _Pragma("unroll") for (int k = 0; k < L::NW; ++k) bglds16(wrs, W_ + 1024 * k, (unsigned)tid * 16u, wso_ + 4096u * k); \
   }
 
   // ---- per-lane LDS read offsets ------------------------------------------------------------------

@@ -157,6 +157,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
       const int gy2 = oy0 - T::D + yy2, gx2 = ox0 - 4 + 4 * j2;
       if (e2 < T::XPIECES && gy2 >= 0 && gy2 < a.Hin && gx2 >= 0 && gx2 < a.Win) xvo = (unsigned)(c2 * HW + gy2 * a.Win + gx2) * 4u;
     }
+    // The second channel of the last k-step does not exist when Cin is odd: its offset (scalar + per-lane) is >= num_records,
+    // and the bounds check of a raw buffer load on gfx950 includes the scalar offset (tools/microbench/buffer_oob_probe.hip,
+    // profiles/r03/buffer_oob_probe.txt; pinned by tests/test_gpu_conv.py::test_channels_past_cin_read_as_zero): zeros.
   } else {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -187,10 +190,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
                                                  ub + 16384u + (unsigned)(wave - 6) * 1024u, 0, 0);
         if constexpr (decltype(extra_c)::value)            // D = 2, wave 6: the last sixteen patch pieces -- ONLY those lanes
           if (lane < T::XPIECES - 384)                     // (an LDS-DMA lane writes its 16 bytes wherever it points: the rest would land in the next ring slot)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(smem + T::R0 + RS * T::XSZP + T::XSHIFT + 6 * 256), 16, xvo,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(smem + T::R0 + RS * T::XSZP + T::XSHIFT + 6 * 256), 16,
+                                                     xvo,
                                                    (unsigned)(s_begin + src_) * 2u * (unsigned)HW * 4u, 0, 0);
       } else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(smem + T::R0 + RS * T::XSZP + T::XSHIFT + wave * 256), 16, xvo,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(smem + T::R0 + RS * T::XSZP + T::XSHIFT + wave * 256), 16,
+                                                 xvo,
                                                  (unsigned)(s_begin + src_) * 2u * (unsigned)HW * 4u, 0, 0);
     } else {
       const float* usrc = w_t + (long long)(s_begin + suc) * T::WSZ;

@@ -274,3 +274,20 @@ def test_winograd_f4x4_dilated(shape):
     xo = rng.standard_normal((1, 8, 12, 30)).astype(np.float32)            # Win % 4 != 0: refused, not mis-computed
     rc, _ = run_conv(xo, w[:8, :8].copy(), b[:8].copy(), 3, 1, 2, 2, tile=T_WINO44)
     assert rc != 0 and b"not instantiated" in lib().lib().fdt_last_error()
+
+
+@pytest.mark.parametrize("k,p,d,tile", [(3, 1, 1, T_WINO44), (3, 2, 2, T_WINO44), (3, 1, 1, 30), (1, 0, 1, 6), (3, 1, 1, 1)])
+def test_channels_past_cin_read_as_zero(k, p, d, tile):
+    """An odd / non-multiple Cin leaves the last LDS stage with channels that do not exist.  Their weights are zero, but 0 x NaN
+    is NaN: the kernels must stage ZEROS there, not whatever follows the image in memory.  Image 1 of the batch is all NaN, so
+    anything image 0's workgroups fetch past their own Cin channels would poison image 0's output."""
+    rng = np.random.default_rng(k * 10 + d)
+    Cin, H, W, Cout = 5, 20, 36, 40
+    x = rng.standard_normal((2, Cin, H, W)).astype(np.float32)
+    x[1] = np.nan
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    exp = reference(x[:1], w, None, k, 1, p, d)
+    rc, got = run_conv(x, w, None, k, 1, p, d, tile=tile, split=1)
+    assert rc == 0, lib().lib().fdt_last_error()
+    assert np.isfinite(got[0]).all() and np.isnan(got[1]).all()
+    assert rel_err(got[:1], exp) < WINO44_TOL
