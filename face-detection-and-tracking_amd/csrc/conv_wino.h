@@ -92,10 +92,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
   const int s_begin = (int)((long long)nstages * ks / a.ksplit);
   const int s_end = (int)((long long)nstages * (ks + 1) / a.ksplit);
 
-  const float* zpad = g_zero_pad;          // materialised once: as a symbol it is re-fetched through the GOT
-  asm volatile("" : "+s"(zpad));            // (an SMEM load, i.e. a full lgkmcnt(0) wait) inside the main loop
-  int goff[T::NX];
-  unsigned okmask = 0;
+  // staging plan: element e = 256 k + tid of the patch, fetched through a buffer descriptor at byte offset xoff[k] relative to
+  // the stage's first channel (kOob for padding / out-of-image: zeros from the bounds check, like the channels past Cin)
+  const __amdgpu_buffer_rsrc_t xrs = buf_rsrc(in_b, (long long)a.Cin * HW * 4);
+  const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(w_t, 0x7fffffffll);
+  unsigned xoff[T::NX];
 #pragma unroll
   for (int k = 0; k < T::NX; ++k) {
     int e = tid + 256 * k;
@@ -104,24 +105,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
     int yy = r / T::PW, xx = r - yy * T::PW;
     int gy = oy0 - 1 + yy, gx = ox0 - 1 + xx;
     bool ok = (e < T::XSZ) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-    goff[k] = ok ? (c * HW + gy * a.Win + gx) : 0;
-    if (ok) okmask |= (1u << k);
+    xoff[k] = ok ? (unsigned)(c * HW + gy * a.Win + gx) * 4u : kOob;
   }
 
 #define FDT_WSTAGE(s_, buf_)                                                                  \
   {                                                                                           \
-    const int c0_ = (s_) * T::KC;                                                             \
-    const float* src_ = in_b + (long long)c0_ * HW;                                           \
-    const int crem_ = a.Cin - c0_;                                                            \
+    const unsigned xso_ = (unsigned)((s_) * T::KC) * (unsigned)HW * 4u;                       \
     float* X_ = smem + (buf_) * T::STAGE + wave * 64;                                         \
-    _Pragma("unroll") for (int k = 0; k < T::NX; ++k) {                                       \
-      const int c_ = (tid + 256 * k) / T::XPLANE;                                             \
-      const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                    \
-      glds4(ok_ ? src_ + goff[k] : zpad, X_ + 256 * k);                                 \
-    }                                                                                         \
-    const float* wsrc_ = w_t + (long long)(s_) * T::WSZP + tid * 4;                           \
+    _Pragma("unroll") for (int k = 0; k < T::NX; ++k) bglds4(xrs, X_ + 256 * k, xoff[k], xso_);   \
+    const unsigned wso_ = (unsigned)((s_) * T::WSZP) * 4u;                                    \
     float* W_ = smem + (buf_) * T::STAGE + T::XSZP + wave * 256;                              \
-    _Pragma("unroll") for (int k = 0; k < T::NW; ++k) glds16(wsrc_ + 1024 * k, W_ + 1024 * k); \
+    _Pragma("unroll") for (int k = 0; k < T::NW; ++k) bglds16(wrs, W_ + 1024 * k, (unsigned)tid * 16u, wso_ + 4096u * k); \
   }
 
   // this lane's 2x2 output block inside the workgroup patch
@@ -267,10 +261,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   const int s_begin = (int)((long long)nstages * ks / a.ksplit);
   const int s_end = (int)((long long)nstages * (ks + 1) / a.ksplit);
 
-  const float* zpad = g_zero_pad;          // materialised once: as a symbol it is re-fetched through the GOT
-  asm volatile("" : "+s"(zpad));            // (an SMEM load, i.e. a full lgkmcnt(0) wait) inside the main loop
-  int goff[NX2];
-  unsigned okmask = 0;
+  // staging plan: element e = 512 k + tid of the patch, fetched through a buffer descriptor at byte offset xoff[k] relative to
+  // the stage's first channel (kOob for padding / out-of-image: zeros from the bounds check, like the channels past Cin)
+  const __amdgpu_buffer_rsrc_t xrs = buf_rsrc(in_b, (long long)a.Cin * HW * 4);
+  const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(w_t, 0x7fffffffll);
+  unsigned xoff[NX2];
 #pragma unroll
   for (int k = 0; k < NX2; ++k) {
     int e = tid + 512 * k;
@@ -279,24 +274,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
     int yy = r / T::PW, xx = r - yy * T::PW;
     int gy = oy0 - T::D + yy, gx = ox0 - T::D + xx;
     bool ok = (e < T::XSZ) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-    goff[k] = ok ? (c * HW + gy * a.Win + gx) : 0;
-    if (ok) okmask |= (1u << k);
+    xoff[k] = ok ? (unsigned)(c * HW + gy * a.Win + gx) * 4u : kOob;
   }
 
 #define FDT_W2STAGE(s_, buf_)                                                                  \
-  {                                                                                            \
-    const int c0_ = (s_) * T::KC;                                                              \
-    const float* src_ = in_b + (long long)c0_ * HW;                                            \
-    const int crem_ = a.Cin - c0_;                                                             \
-    float* X_ = smem + (buf_) * T::STAGE + wave * 64;                                          \
-    _Pragma("unroll") for (int k = 0; k < NX2; ++k) {                                          \
-      const int c_ = (tid + 512 * k) / T::XPLANE;                                              \
-      const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                     \
-      glds4(ok_ ? src_ + goff[k] : zpad, X_ + 512 * k);                                  \
-    }                                                                                          \
-    const float* wsrc_ = w_t + (long long)(s_) * T::WSZP + tid * 4;                            \
-    float* W_ = smem + (buf_) * T::STAGE + T::XSZP + wave * 256;                               \
-    _Pragma("unroll") for (int k = 0; k < NW2; ++k) glds16(wsrc_ + 2048 * k, W_ + 2048 * k);   \
+  {                                                                                           \
+    const unsigned xso_ = (unsigned)((s_) * T::KC) * (unsigned)HW * 4u;                       \
+    float* X_ = smem + (buf_) * T::STAGE + wave * 64;                                         \
+    _Pragma("unroll") for (int k = 0; k < NX2; ++k) bglds4(xrs, X_ + 512 * k, xoff[k], xso_);   \
+    const unsigned wso_ = (unsigned)((s_) * T::WSZP) * 4u;                                    \
+    float* W_ = smem + (buf_) * T::STAGE + T::XSZP + wave * 256;                              \
+    _Pragma("unroll") for (int k = 0; k < NW2; ++k) bglds16(wrs, W_ + 2048 * k, (unsigned)tid * 16u, wso_ + 8192u * k); \
   }
 
   // this lane's 2x2 output block {(oyl, oxl) + D * (0|1, 0|1)} inside the workgroup patch.  D = 1: blocks
@@ -599,10 +587,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
   const int s_begin = (int)((long long)nstages * ks / a.ksplit);
   const int s_end = (int)((long long)nstages * (ks + 1) / a.ksplit);
 
-  const float* zpad = g_zero_pad;
-  asm volatile("" : "+s"(zpad));
-  int goff[NX2];
-  unsigned okmask = 0;
+  // staging plan: element e = 512 k + tid of the patch, fetched through a buffer descriptor at byte offset xoff[k] relative to
+  // the stage's first channel (kOob for padding / out-of-image: zeros from the bounds check, like the channels past Cin)
+  const __amdgpu_buffer_rsrc_t xrs = buf_rsrc(in_b, (long long)a.Cin * HW * 4);
+  const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(w_t, 0x7fffffffll);
+  unsigned xoff[NX2];
 #pragma unroll
   for (int k = 0; k < NX2; ++k) {
     int e = tid + 512 * k;
@@ -611,24 +600,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
     int yy = r / T::PW, xx = r - yy * T::PW;
     int gy = oy0 - T::D + yy, gx = ox0 - T::D + xx;
     bool ok = (e < T::XSZ) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-    goff[k] = ok ? (c * HW + gy * a.Win + gx) : 0;
-    if (ok) okmask |= (1u << k);
+    xoff[k] = ok ? (unsigned)(c * HW + gy * a.Win + gx) * 4u : kOob;
   }
 
 #define FDT_W4STAGE(s_, buf_)                                                                  \
-  {                                                                                            \
-    const int c0_ = (s_) * T::KC;                                                              \
-    const float* src_ = in_b + (long long)c0_ * HW;                                            \
-    const int crem_ = a.Cin - c0_;                                                             \
-    float* X_ = smem + (buf_) * T::STAGE + wave * 64;                                          \
-    _Pragma("unroll") for (int k = 0; k < NX2; ++k) {                                          \
-      const int c_ = (tid + 512 * k) / T::XPLANE;                                              \
-      const bool ok_ = ((okmask >> k) & 1u) && c_ < crem_;                                     \
-      glds4(ok_ ? src_ + goff[k] : zpad, X_ + 512 * k);                                        \
-    }                                                                                          \
-    const float* wsrc_ = w_t + (long long)(s_) * T::WSZP + tid * 4;                            \
-    float* W_ = smem + (buf_) * T::STAGE + T::XSZP + wave * 256;                               \
-    _Pragma("unroll") for (int k = 0; k < NW2; ++k) glds16(wsrc_ + 2048 * k, W_ + 2048 * k);   \
+  {                                                                                           \
+    const unsigned xso_ = (unsigned)((s_) * T::KC) * (unsigned)HW * 4u;                       \
+    float* X_ = smem + (buf_) * T::STAGE + wave * 64;                                         \
+    _Pragma("unroll") for (int k = 0; k < NX2; ++k) bglds4(xrs, X_ + 512 * k, xoff[k], xso_);   \
+    const unsigned wso_ = (unsigned)((s_) * T::WSZP) * 4u;                                    \
+    float* W_ = smem + (buf_) * T::STAGE + T::XSZP + wave * 256;                              \
+    _Pragma("unroll") for (int k = 0; k < NW2; ++k) bglds16(wrs, W_ + 2048 * k, (unsigned)tid * 16u, wso_ + 8192u * k); \
   }
 
   const int qb = wm * 32 + l31;
