@@ -176,32 +176,38 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
 
   // LDS-DMA of one k-step into compile-time ring slots: weights U(su) -> slot US, raw patch R(sr) -> slot RS.  k-steps past the
   // end of this workgroup's share are clamped to its last one (valid addresses, the same instruction count; never consumed).
-  auto issue_w = [&](auto tail_c, auto extra_c, auto us_c, auto rs_c, int su, int sr) {
-    constexpr bool TAILW = decltype(tail_c)::value;     // waves 6, 7: the last 2 KB of the weights instead of a patch piece
-    constexpr int US = decltype(us_c)::value, RS = decltype(rs_c)::value;
-    const int suc = su < nst ? su : nst - 1, src_ = sr < nst ? sr : nst - 1;
+  auto issue_u = [&](auto tail_c, auto us_c, int su) {
+    constexpr bool TAILW = decltype(tail_c)::value;     // waves 6, 7 also fetch the last 2 KB of the weights
+    constexpr int US = decltype(us_c)::value;
+    const int suc = su < nst ? su : nst - 1;
     float* U_ = smem + T::U0 + US * T::WSZ;
     if constexpr (T::VEC) {
       const unsigned ub = (unsigned)((s_begin + suc) * T::WSZ) * 4u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(U_ + wave * 256), 16, wvo, ub + (unsigned)wave * 1024u, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(U_ + 2048 + wave * 256), 16, wvo, ub + 8192u + (unsigned)wave * 1024u, 0, 0);
-      if constexpr (TAILW) {
+      if constexpr (TAILW)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(U_ + 4096 + (wave - 6) * 256), 16, wvo,
                                                  ub + 16384u + (unsigned)(wave - 6) * 1024u, 0, 0);
-        if constexpr (decltype(extra_c)::value)            // D = 2, wave 6: the last sixteen patch pieces -- ONLY those lanes
-          if (lane < T::XPIECES - 384)                     // (an LDS-DMA lane writes its 16 bytes wherever it points: the rest would land in the next ring slot)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(smem + T::R0 + RS * T::XSZP + T::XSHIFT + 6 * 256), 16,
-                                                     xvo,
-                                                   (unsigned)(s_begin + src_) * 2u * (unsigned)HW * 4u, 0, 0);
-      } else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(smem + T::R0 + RS * T::XSZP + T::XSHIFT + wave * 256), 16,
-                                                 xvo,
-                                                 (unsigned)(s_begin + src_) * 2u * (unsigned)HW * 4u, 0, 0);
     } else {
       const float* usrc = w_t + (long long)(s_begin + suc) * T::WSZ;
       glds16(usrc + wave * 256 + lane * 4, U_ + wave * 256);
       glds16(usrc + 2048 + wave * 256 + lane * 4, U_ + 2048 + wave * 256);
       glds4(usrc + 4096 + wave * 64 + lane, U_ + 4096 + wave * 64);
+    }
+  };
+  auto issue_r = [&](auto tail_c, auto extra_c, auto rs_c, int sr) {
+    constexpr bool TAILW = decltype(tail_c)::value;     // waves 6, 7 stage no patch pieces (but wave 6 the last sixteen at D = 2)
+    constexpr int RS = decltype(rs_c)::value;
+    const int src_ = sr < nst ? sr : nst - 1;
+    if constexpr (T::VEC) {
+      const unsigned xb = (unsigned)(s_begin + src_) * 2u * (unsigned)HW * 4u;
+      if constexpr (!TAILW) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(smem + T::R0 + RS * T::XSZP + T::XSHIFT + wave * 256), 16, xvo, xb, 0, 0);
+      } else if constexpr (decltype(extra_c)::value) {
+        if (lane < T::XPIECES - 384)   // ONLY those lanes: an LDS-DMA lane writes its 16 bytes wherever it points -- the rest would land in the next ring slot
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lptr_t)(smem + T::R0 + RS * T::XSZP + T::XSHIFT + 6 * 256), 16, xvo, xb, 0, 0);
+      }
+    } else {
       const int c0 = (s_begin + src_) * 2;
       const float* src = in_b + (long long)c0 * HW;
       const int crem = a.Cin - c0;
@@ -399,17 +405,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     };
     using TAILc = std::bool_constant<ROLE >= 6>;          // waves 6, 7
     using EXTRAc = std::bool_constant<ROLE == 6 && T::D == 2>;
-    constexpr int LOADS_ = T::LOADS + (EXTRAc::value ? 1 : 0);
     using N0 = std::integral_constant<int, 0>;
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     using S2 = std::integral_constant<int, 2>;
     using S3 = std::integral_constant<int, 3>;
 
-    // ---- prologue: U(0), U(1), R(0), R(1), R(2); V(0), V(1); U(2), R(3) in flight; operands of k-step 0 in registers
-    issue_w(TAILc{}, EXTRAc{}, S0{}, S0{}, 0, 0);
-    issue_w(TAILc{}, EXTRAc{}, S1{}, S1{}, 1, 1);
-    issue_w(TAILc{}, EXTRAc{}, S2{}, S2{}, 2, 2);
+    // ---- prologue: U(0..2), R(0..4) landed; V(0..2) written; operands of k-step 0 in registers
+    issue_u(TAILc{}, S0{}, 0);
+    issue_u(TAILc{}, S1{}, 1);
+    issue_u(TAILc{}, S2{}, 2);
+    issue_r(TAILc{}, EXTRAc{}, S0{}, 0);
+    issue_r(TAILc{}, EXTRAc{}, S1{}, 1);
+    issue_r(TAILc{}, EXTRAc{}, S2{}, 2);
+    issue_r(TAILc{}, EXTRAc{}, S3{}, 3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -421,11 +430,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
       transform_store(w0, S0{});
       wait_raw(w1, std::integral_constant<int, (ROLE < 6 ? 3 : 0)>{});
       transform_store(w1, S1{});
+      raw_reads(w0, S2{});
+      wait_raw(w0, N0{});
+      transform_store(w0, S2{});
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();          // V(0), V(1) visible; every wave is done with R(0), R(1)
+    __builtin_amdgcn_s_barrier();          // V(0..2) visible; every wave is done with R(0..2)
     __builtin_amdgcn_sched_barrier(0);
-    issue_w(TAILc{}, EXTRAc{}, S2{}, S3{}, 2, 3);    // R(3) (U(2) once more: one instruction count per issue)
+    issue_r(TAILc{}, EXTRAc{}, S0{}, 4);   // R(4) into the slot of R(0)
     Ops X, Y;
     load_ops(X, S0{}, S0{});
     wait_ops(X, N0{});
@@ -437,59 +449,103 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
       if (!(FDT_W44_EXP & 8)) mfma_q(cur, qc);
       __builtin_amdgcn_sched_barrier(0);
     };
-    // ---- k-step s (s mod 4 == M): MFMAs on `cur` (registers); window of s+2 -> V(s+2); operand prefetch of s+1; LDS-DMA of
-    // U(s+3) / R(s+4).  Right behind the barrier all eight waves queue their LDS reads at once: only the window reads go there
-    // (their data is needed first), four MFMAs stand between them and the wait, the operand prefetch is issued late.
-    auto step = [&](auto m_c, Ops& cur, Ops& nxt, int s) {
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    using I5 = std::integral_constant<int, 5>;
+    using I6 = std::integral_constant<int, 6>;
+    using I7 = std::integral_constant<int, 7>;
+    using I8 = std::integral_constant<int, 8>;
+    // ---- super-step: the k-steps s = 2 S (ring slots M) and s + 1 (slots M + 1) between TWO barriers ---------------------
+    // At its barrier: the operands of k-step s sit in `cur`; U(s+1), U(s+2), R(s+3), R(s+4) have landed (all LDS-DMA of the
+    // previous super-step: vmcnt(0), one super-step = two k-steps of flight); V(s+1), V(s+2) are written.  First half: MFMAs
+    // of s, window of s+3 -> V(s+3), operands of s+1 -> `nxt`, LDS-DMA of U(s+3) / R(s+5); second half: MFMAs of s+1, window of
+    // s+4 -> V(s+4), operands of s+2 -> `cur`, LDS-DMA of U(s+4) / R(s+6).  The first two MFMAs stand in front of the barrier
+    // (their operands are registers), four MFMAs between a window read and its wait, the operand prefetch late.
+    auto super_step = [&](auto m_c, Ops& cur, Ops& nxt, int s) {
       constexpr int M = decltype(m_c)::value;
+      using M0 = std::integral_constant<int, M>;
       using M1 = std::integral_constant<int, (M + 1) & 3>;
       using M2 = std::integral_constant<int, (M + 2) & 3>;
       using M3 = std::integral_constant<int, (M + 3) & 3>;
-      using M0 = std::integral_constant<int, M>;
-      // the first two MFMAs need nothing the barrier protects (their operands sit in registers): issued in front of it, they
-      // keep the matrix pipe fed while the workgroup synchronises
-      mf(cur, std::integral_constant<int, 0>{});
-      mf(cur, std::integral_constant<int, 1>{});
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_) : "memory");       // everything but the previous k-step's issue has landed
+      mf(cur, I0{});
+      mf(cur, I1{});
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (!(FDT_W44_EXP & 2)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       Raw w;
-      if (!(FDT_W44_EXP & 1)) raw_reads(w, M2{});
-      __builtin_amdgcn_sched_barrier(0);
-      mf(cur, std::integral_constant<int, 2>{});
-      if (!(FDT_W44_EXP & 4)) issue_w(TAILc{}, EXTRAc{}, M3{}, M0{}, s + 3, s + 4);
-      __builtin_amdgcn_sched_barrier(0);
-      mf(cur, std::integral_constant<int, 3>{});
-      mf(cur, std::integral_constant<int, 4>{});
       f32x2 Tp[3];
       float v[6];
+      if (!(FDT_W44_EXP & 1)) raw_reads(w, M3{});
+      __builtin_amdgcn_sched_barrier(0);
+      mf(cur, I2{});
+      if (!(FDT_W44_EXP & 4)) {
+        issue_u(TAILc{}, M3{}, s + 3);
+        issue_r(TAILc{}, EXTRAc{}, M1{}, s + 5);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mf(cur, I3{});
+      mf(cur, I4{});
       if (!(FDT_W44_EXP & 1)) {
         wait_raw(w, N0{});
         t_pairs(w, Tp);
       }
       __builtin_amdgcn_sched_barrier(0);
-      mf(cur, std::integral_constant<int, 5>{});
+      mf(cur, I5{});
       if (!(FDT_W44_EXP & 1)) v_all(Tp, v);
       __builtin_amdgcn_sched_barrier(0);
-      mf(cur, std::integral_constant<int, 6>{});
-      if (!(FDT_W44_EXP & 1)) v_store(v, M2{});
+      mf(cur, I6{});
+      if (!(FDT_W44_EXP & 1)) v_store(v, M3{});
       if (!(FDT_W44_EXP & 16)) load_ops(nxt, M1{}, M1{});
       __builtin_amdgcn_sched_barrier(0);
-      mf(cur, std::integral_constant<int, 7>{});
-      mf(cur, std::integral_constant<int, 8>{});
-      if (!(FDT_W44_EXP & 16)) wait_ops(nxt, N0{});                       // also: this wave's V(s+2) writes are done
+      mf(cur, I7{});
+      mf(cur, I8{});
+      if (!(FDT_W44_EXP & 16)) wait_ops(nxt, N0{});
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // ---- second half: k-step s + 1
+      if (!(FDT_W44_EXP & 1)) raw_reads(w, M0{});
+      __builtin_amdgcn_sched_barrier(0);
+      mf(nxt, I0{});
+      mf(nxt, I1{});
+      mf(nxt, I2{});
+      if (!(FDT_W44_EXP & 4)) {
+        issue_u(TAILc{}, M0{}, s + 4);
+        issue_r(TAILc{}, EXTRAc{}, M2{}, s + 6);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mf(nxt, I3{});
+      mf(nxt, I4{});
+      if (!(FDT_W44_EXP & 1)) {
+        wait_raw(w, N0{});
+        t_pairs(w, Tp);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mf(nxt, I5{});
+      if (!(FDT_W44_EXP & 1)) v_all(Tp, v);
+      __builtin_amdgcn_sched_barrier(0);
+      mf(nxt, I6{});
+      if (!(FDT_W44_EXP & 1)) v_store(v, M0{});
+      if (!(FDT_W44_EXP & 16)) load_ops(cur, M2{}, M2{});
+      __builtin_amdgcn_sched_barrier(0);
+      mf(nxt, I7{});
+      mf(nxt, I8{});
+      if (!(FDT_W44_EXP & 16)) wait_ops(cur, N0{});                       // also: this wave's V writes are done
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     int s = 0;
     for (; s + 3 < nst; s += 4) {
-      step(S0{}, X, Y, s);
-      step(S1{}, Y, X, s + 1);
-      step(S2{}, X, Y, s + 2);
-      step(S3{}, Y, X, s + 3);
+      super_step(S0{}, X, Y, s);
+      super_step(S2{}, X, Y, s + 2);
     }
-    if (s < nst) step(S0{}, X, Y, s);
-    if (s + 1 < nst) step(S1{}, Y, X, s + 1);
-    if (s + 2 < nst) step(S2{}, X, Y, s + 2);
+    if (s + 1 < nst) {
+      super_step(S0{}, X, Y, s);
+      s += 2;
+    }
+    if (s < nst) {                          // an odd last k-step: its operands are in X, nothing left to prefetch
+      mf(X, I0{}); mf(X, I1{}); mf(X, I2{}); mf(X, I3{}); mf(X, I4{}); mf(X, I5{}); mf(X, I6{}); mf(X, I7{}); mf(X, I8{});
+    }
   };
   switch (wave) {
     case 0: main_loop(std::integral_constant<int, 0>{}); break;
