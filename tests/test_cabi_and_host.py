@@ -183,7 +183,7 @@ def test_bench_host_helpers_and_committed_plans():
     for layer in ("conv2_SSH.conv1", "layer3.1.conv1", "layer1.0.conv3", "layer2.1.conv3"):
         assert layer in plan, layer
     assert plan["conv2_SSH.conv1"][0] == 14 and plan["conv2_SSH.conv1"][1] in (32, 33)    # Winograd F(4x4,3x3)
-    assert plan["conv2_SSH.conv2"][0] == 9 and plan["conv2_SSH.conv2"][1] in (29, 30)     # dilated: quarter-split F(2x2,3x3)
+    assert plan["conv2_SSH.conv2"][0] == 15 and plan["conv2_SSH.conv2"][1] == 32          # dilated F(4x4,3x3) on parity sub-lattices
     assert bench.kernel_label(14, 32).startswith("conv_wino44_kernel<3x3s1_wino44") and bench.WINO_RATIO[14] == 4.0
     assert len(plan) == 105                                                               # every conv layer of Res50
     sh = open(os.path.join(ROOT, "tools", "refresh_profiles.sh")).read()
