@@ -100,6 +100,8 @@ struct ConvArgs {
   int act;
   int ksplit;             // >= 1: split the input-channel reduction over this many workgroups
   float* ws;              // split-K workspace, B*ksplit*Cout*Hout*Wout floats (ksplit > 1, or `up` on a Winograd tile)
+  unsigned* sk_count;     // non-null: in-kernel split-K combine (splitk_combine_tile below), one zeroed counter per
+                          // (image, output tile): conv_sk_counters() of them; null: splitk_reduce_kernel finishes the layer
   // workgroup -> (spatial tile, output-channel tile) map (FDT_BLOCK_MAP below): map_mode is the caller's choice
   // (CONV_MAP_*), n_sp / n_ct are filled in by launch_conv
   int map_mode, n_sp, n_ct;
@@ -189,6 +191,115 @@ __device__ __forceinline__ void add_upsampled_x2(const float* __restrict__ u, in
     v[e] += (1.0f - ly) * top + ly * bot;
   }
 }
+
+// ---- in-kernel split-K combine ----------------------------------------------------------------------------------
+// The ksplit workgroups of an output tile write their partial slabs to the workspace and take a ticket at the tile's
+// counter; the one that arrives LAST sums the slabs in ks order -- the order and operand order of splitk_reduce_kernel,
+// so the two paths are bit-identical -- and applies bias / upsample-add / residual / activation.  No workgroup ever
+// waits for another one (no spinning: nothing to deadlock on), and the result does not depend on who arrives last.
+// Visibility across the XCDs' L2s (MI355X_MICROARCH.md, "Valid forms"): every slab byte is stored `sc1`
+// (write-through), every storing wave drains its stores (`s_waitcnt vmcnt(0)`) in front of the workgroup barrier behind
+// which ONE lane adds to the counter (agent scope), the last arriver's waves load the slabs only behind a barrier
+// that lane joins after its add has returned, and every slab load is a `buffer_load ... sc1`.
+typedef float slab_f4 __attribute__((ext_vector_type(4)));
+typedef float slab_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void slab_store4(float* p, float x, float y, float z, float w, bool wt) {
+  if (wt) {
+    const slab_f4 v = {x, y, z, w};
+    // s_nop 1: a store of more than 8 bytes reads its data registers up to two wait states after issue; the compiler's
+    // hazard recogniser covers that for the stores it emits itself, not for this one (seen: one lane's .z overwritten)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(x, y, z, w);
+  }
+}
+__device__ __forceinline__ void slab_store2(float* p, float x, float y, bool wt) {
+  if (wt) {
+    const slab_f2 v = {x, y};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  } else {
+    *reinterpret_cast<float2*>(p) = make_float2(x, y);
+  }
+}
+__device__ __forceinline__ void slab_store1(float* p, float x, bool wt) {
+  if (wt)
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+  else
+    *p = x;
+}
+
+// Called by every thread of the workgroup after its slab stores; the tile is output channels [co0, co0 + nco) x rows
+// [oy0, oy0 + th) x columns [ox0, ox0 + tw) of image b (clipped to the map here).  Needs Wout % 4 == 0 and ox0, tw
+// multiples of 4 (launch_conv checks the first, the tiles guarantee the rest).  `flag`: one LDS word the caller no
+// longer needs.  tile_id = s_tile + n_sp * n_tile.
+template <int THREADS>
+__device__ __forceinline__ void splitk_combine_tile(const ConvArgs& a, int b, int tile_id, int co0, int nco, int oy0,
+                                                    int ox0, int th, int tw, unsigned* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores have reached memory
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* c = a.sk_count + (long long)b * a.n_sp * a.n_ct + tile_id;
+    const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned last = old == (unsigned)a.ksplit - 1u ? 1u : 0u;
+    if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    *flag = last;
+  }
+  __syncthreads();
+  if (!*flag) return;
+  const int HWo = a.Hout * a.Wout;
+  const int rows = min(th, a.Hout - oy0), c4 = min(tw, a.Wout - ox0) >> 2, ncov = min(nco, a.Cout - co0);
+  const int per_c = rows * c4, total = ncov * per_c;
+  const unsigned kstride = (unsigned)a.Cout * (unsigned)HWo * 4u;   // bytes between the slabs of one image
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.ws + (long long)b * a.ksplit * a.Cout * HWo), 0, (int)(kstride * (unsigned)a.ksplit), 0x00020000);
+  const float* res_b = a.res ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWo : nullptr;
+  float* out_b = a.out + ((long long)b * a.out_ctot + a.out_coff) * HWo;
+  typedef unsigned slab_u4 __attribute__((ext_vector_type(4)));
+  for (int e = threadIdx.x; e < total; e += THREADS) {
+    const int c = e / per_c, r = e - c * per_c;
+    const int y = r / c4, x4 = r - y * c4;
+    const int co = co0 + c, oy = oy0 + y, ox = ox0 + 4 * x4;
+    const int pix = oy * a.Wout + ox;
+    const unsigned off = ((unsigned)co * (unsigned)HWo + (unsigned)pix) * 4u;
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int k = 0;
+    for (; k + 4 <= a.ksplit; k += 4) {   // four slabs in flight per lane and element
+      slab_u4 p[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + (unsigned)(k + j) * kstride, 0, 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const slab_f4 f = __builtin_bit_cast(slab_f4, p[j]);
+        v[0] += f.x; v[1] += f.y; v[2] += f.z; v[3] += f.w;
+      }
+    }
+    for (; k < a.ksplit; ++k) {
+      const slab_f4 f = __builtin_bit_cast(slab_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + (unsigned)k * kstride, 0, 16));
+      v[0] += f.x; v[1] += f.y; v[2] += f.z; v[3] += f.w;
+    }
+    const float bv = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += bv;
+    if (a.up) add_upsampled_x2<4>(a.up + ((long long)b * a.Cout + co) * a.up_h * a.up_w, a.up_h, a.up_w, oy, ox, v);
+    const long long o = (long long)co * HWo + pix;
+    if (res_b) {
+      const float4 rv = *reinterpret_cast<const float4*>(res_b + o);
+      v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (a.act == ACT_RELU) v[j] = fmaxf(v[j], 0.0f);
+      else if (a.act == ACT_RELU6) v[j] = fminf(fmaxf(v[j], 0.0f), 6.0f);
+    }
+    *reinterpret_cast<float4*>(out_b + o) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+extern thread_local bool exp_skip_reduce;   // experiment hook, see conv.hip
+
+// Counters an in-kernel split-K combine needs (ConvArgs.sk_count): one per image and output tile.
+long long conv_sk_counters(ConvKind kind, ConvTile tile, const ConvArgs& a);
+bool conv_combine_supported(ConvKind kind, ConvTile tile, const ConvArgs& a);
 
 // Workspace floats a split-K launch needs.
 long long conv_ws_floats(const ConvArgs& a);

@@ -88,6 +88,12 @@ __global__ void splitk_reduce_kernel(const ConvArgs a) {
     a.out[ooff] = v[0];
 }
 
+}  // namespace
+// Experiment hook (tools/experiments/deletion.sh, FDT_SKIP_OPS=@reduce): the split-K reduce passes are not launched -- the
+// ceiling of what an in-kernel combine could gain.  Set by model.hip around a pass; never in production.
+thread_local bool exp_skip_reduce = false;
+namespace {
+
 struct Table {
   KernelEntry e[CONV_KIND_COUNT][CONV_TILE_COUNT];
   // per device: the attribute is per (function, device).  Handles on different host threads race here only to set
@@ -230,6 +236,17 @@ long long conv_ws_floats(const ConvArgs& a) {
   return a.ksplit > 1 ? (long long)a.B * a.ksplit * a.Cout * a.Hout * a.Wout : 0;
 }
 
+long long conv_sk_counters(ConvKind kind, ConvTile tile, const ConvArgs& a) {
+  (void)kind;
+  return (long long)a.B * ceil_div(a.Hout, tile_th(tile)) * ceil_div(a.Wout, tile_tw(tile)) * ceil_div(a.Cout, tile_bn(tile));
+}
+
+bool conv_combine_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
+  // (the 8-channel VALU kernel is not in: its four waves per SIMD leave no registers for the write-through store path)
+  return conv_supported(kind, tile) && kind != CONV_3x3_S1_N8 && a.ksplit > 1 && a.ws && a.Wout % 4 == 0 &&
+         (long long)a.ksplit * a.Cout * a.Hout * a.Wout * 4 < (1ll << 31);
+}
+
 double conv_flops(const ConvArgs& a, ConvKind kind) {
   const ConvGeom g = conv_geom(kind);
   return 2.0 * a.B * (double)a.Hout * a.Wout * a.Cout * a.Cin * g.kh * g.kw;
@@ -272,6 +289,9 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
   // split-K layers finish in splitk_reduce_kernel (which then also carries the fused upsample-add)
   FDT_REQUIRE(a.ksplit == 1 || a.ws, FDT_ERR_ARG, "launch_conv: workspace required");
   FDT_REQUIRE(!a.ws || a.ksplit > 1, FDT_ERR_ARG, "launch_conv: unexpected workspace");
+  // in-kernel combine (conv.h, splitk_combine_tile): 16-byte slab rows, one image's slabs behind one buffer descriptor
+  FDT_REQUIRE(!a.sk_count || conv_combine_supported(kind, tile, a), FDT_ERR_ARG,
+              "launch_conv: in-kernel split-K combine needs ksplit > 1, Wout %% 4 == 0 and < 2 GB of slabs per image");
   FDT_REQUIRE(!a.up || conv_base_kind(kind) == CONV_1x1_S1, FDT_ERR_ARG,
               "launch_conv: the fused upsample-add exists for the 1x1 class only (ContextTexture.main_conv)");
   const int tiles = ceil_div(a.Hout, tile_th(tile)) * ceil_div(a.Wout, tile_tw(tile));
@@ -287,7 +307,7 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
   const bool odd = ke.fn_odd && (a.Win & 3);
   hipLaunchKernelGGL(odd ? ke.fn_odd : ke.fn, grid, dim3(odd && ke.threads_odd ? ke.threads_odd : ke.threads), ke.lds, st, a);
   FDT_LAUNCH_CHECK();
-  if (a.ws) {
+  if (a.ws && !a.sk_count && !exp_skip_reduce) {
     const long long total = (long long)a.B * a.Cout * a.Hout * a.Wout;
     if (a.Wout % 4 == 0)
       hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)ceil_div_ll(total / 4, 256)), dim3(256), 0, st, a);
@@ -351,6 +371,8 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
   if (kind == CONV_3x3_S1 && tile == TILE_N8_32x64) kind = CONV_3x3_S1_N8;
   FDT_REQUIRE(tile >= 0 && tile < CONV_TILE_COUNT && conv_supported((ConvKind)kind, (ConvTile)tile), FDT_ERR_ARG,
               "fdt_conv2d: kernel (kind %d, tile %d) not instantiated", kind, tile);
+  const bool combine = ksplit > 0 && (ksplit & FDT_SPLIT_COMBINE);   // in-kernel combine instead of the reduce pass
+  if (combine) ksplit &= FDT_SPLIT_COMBINE - 1;
   a.ksplit = ksplit > 0 ? ksplit : 1;
   std::vector<float> tiled;
   tile_weights(w_oihw, nullptr, Cout, Cin, (ConvKind)kind, (ConvTile)tile, tiled);
@@ -379,6 +401,15 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
     a.up = dup.as<float>(); a.up_h = up_h; a.up_w = up_w;
   }
   if (a.ksplit > 1) { FDT_TRY(dws.alloc((size_t)conv_ws_floats(a) * 4)); a.ws = dws.as<float>(); }
+  DevBuf dcnt;
+  if (combine) {
+    FDT_REQUIRE(conv_combine_supported((ConvKind)kind, (ConvTile)tile, a), FDT_ERR_ARG,
+                "fdt_conv2d: in-kernel split-K combine needs ksplit > 1 and Wout %% 4 == 0");
+    const size_t nc = (size_t)conv_sk_counters((ConvKind)kind, (ConvTile)tile, a) * sizeof(unsigned);
+    FDT_TRY(dcnt.alloc(nc));
+    FDT_HIP(hipMemsetAsync(dcnt.p, 0, nc, st));
+    a.sk_count = dcnt.as<unsigned>();
+  }
   if (const char* mm = getenv("FDT_CONV_MAP")) a.map_mode = atoi(mm);   // test hook: workgroup map (conv.h CONV_MAP_*)
   FDT_TRY(launch_conv((ConvKind)kind, (ConvTile)tile, a, st));
   FDT_HIP(copy_sync(out, dout.p, n_out * 4, hipMemcpyDeviceToHost, st));
@@ -394,6 +425,8 @@ extern "C" int fdt_debug_conv_bench(int kind, int tile, int ksplit, int B, int C
   using namespace fdt;
   FDT_REQUIRE(kind >= 0 && kind < CONV_KIND_COUNT && tile >= 0 && tile < CONV_TILE_COUNT && ms_out && iters >= 1,
               FDT_ERR_ARG, "fdt_debug_conv_bench: bad argument");
+  const bool combine = ksplit > 0 && (ksplit & FDT_SPLIT_COMBINE);   // in-kernel combine instead of the reduce pass
+  if (combine) ksplit &= FDT_SPLIT_COMBINE - 1;
   FDT_REQUIRE(conv_supported((ConvKind)kind, (ConvTile)tile), FDT_ERR_ARG, "kernel not instantiated");
   const ConvGeom g = conv_geom((ConvKind)kind);
   ConvArgs a;
@@ -425,6 +458,15 @@ extern "C" int fdt_debug_conv_bench(int kind, int tile, int ksplit, int B, int C
     a.up = dup.as<float>();
   }
   if (ksplit > 1) { FDT_TRY(dws.alloc((size_t)conv_ws_floats(a) * 4)); a.ws = dws.as<float>(); }
+  DevBuf dcnt;
+  if (combine) {
+    FDT_REQUIRE(conv_combine_supported((ConvKind)kind, (ConvTile)tile, a), FDT_ERR_ARG,
+                "fdt_debug_conv_bench: in-kernel split-K combine needs ksplit > 1 and Wout %% 4 == 0");
+    const size_t nc = (size_t)conv_sk_counters((ConvKind)kind, (ConvTile)tile, a) * sizeof(unsigned);
+    FDT_TRY(dcnt.alloc(nc));
+    FDT_HIP(hipMemsetAsync(dcnt.p, 0, nc, st));
+    a.sk_count = dcnt.as<unsigned>();
+  }
   hipEvent_t e0, e1;
   FDT_HIP(hipEventCreate(&e0)); FDT_HIP(hipEventCreate(&e1));
   for (int i = 0; i < 2; ++i) FDT_TRY(launch_conv((ConvKind)kind, (ConvTile)tile, a, st));

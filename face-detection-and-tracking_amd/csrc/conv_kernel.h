@@ -352,11 +352,13 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
                 v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
               }
             }
-            *reinterpret_cast<float4*>(dst_b + off) = v;
+            slab_store4(dst_b + off, v.x, v.y, v.z, v.w, raw && a.sk_count);
           }
         }
       }
     }
+    if (a.sk_count)
+      splitk_combine_tile<256>(a, b, tile_id + a.n_sp * n_tile, n_tile * T::BN, T::BN, oy0, ox0, T::TH, T::TW, (unsigned*)smem);
     return;
   }
   if (a.ws) {

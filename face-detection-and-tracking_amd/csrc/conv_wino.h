@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
   const int HWo = a.Hout * a.Wout;
   const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
   const bool raw = a.ws != nullptr;
+  const bool wt = raw && a.sk_count;   // slabs of an in-kernel combine are stored write-through (conv.h)
   float* dst_b = raw ? a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWo
                      : a.out + ((long long)b * a.out_ctot + a.out_coff) * HWo;
   const float* res_b = (!raw && a.res) ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWo : nullptr;
@@ -217,14 +218,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
         }
       }
       if (vec2) {
-        if (row0) *reinterpret_cast<float2*>(dst_b + base) = make_float2(y00, y01);
-        if (row1) *reinterpret_cast<float2*>(dst_b + base + a.Wout) = make_float2(y10, y11);
+        if (row0) slab_store2(dst_b + base, y00, y01, wt);
+        if (row1) slab_store2(dst_b + base + a.Wout, y10, y11, wt);
       } else {
-        if (row0) { dst_b[base] = y00; if (col1) dst_b[base + 1] = y01; }
-        if (row1) { dst_b[base + a.Wout] = y10; if (col1) dst_b[base + a.Wout + 1] = y11; }
+        if (row0) { slab_store1(dst_b + base, y00, wt); if (col1) slab_store1(dst_b + base + 1, y01, wt); }
+        if (row1) { slab_store1(dst_b + base + a.Wout, y10, wt); if (col1) slab_store1(dst_b + base + a.Wout + 1, y11, wt); }
       }
     }
   }
+  if (wt) splitk_combine_tile<256>(a, b, sp_tile + a.n_sp * n_tile, n_tile * T::BN, T::BN, oy0, ox0, TH, TW, (unsigned*)smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -491,6 +493,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   const int HWo = a.Hout * a.Wout;
   const int oy = oy0 + oyl, ox = ox0 + oxl;
   const bool raw = a.ws != nullptr;
+  const bool wt = raw && a.sk_count;   // slabs of an in-kernel combine are stored write-through (conv.h)
   float* dst_b = raw ? a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWo
                      : a.out + ((long long)b * a.out_ctot + a.out_coff) * HWo;
   const float* res_b = (!raw && a.res) ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWo : nullptr;
@@ -541,14 +544,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
         }
       }
       if (vec2) {
-        if (row0) *reinterpret_cast<float2*>(dst_b + base) = make_float2(y00, y01);
-        if (row1) *reinterpret_cast<float2*>(dst_b + base + a.Wout) = make_float2(y10, y11);
+        if (row0) slab_store2(dst_b + base, y00, y01, wt);
+        if (row1) slab_store2(dst_b + base + a.Wout, y10, y11, wt);
       } else {
-        if (row0) { dst_b[base] = y00; if (col1) dst_b[base + T::D] = y01; }
-        if (row1) { dst_b[base + T::D * a.Wout] = y10; if (col1) dst_b[base + T::D * a.Wout + T::D] = y11; }
+        if (row0) { slab_store1(dst_b + base, y00, wt); if (col1) slab_store1(dst_b + base + T::D, y01, wt); }
+        if (row1) { slab_store1(dst_b + base + T::D * a.Wout, y10, wt); if (col1) slab_store1(dst_b + base + T::D * a.Wout + T::D, y11, wt); }
       }
     }
   }
+  if (wt) splitk_combine_tile<512>(a, b, sp_tile + a.n_sp * n_tile, n_tile * T::BN, T::BN, oy0, ox0, TH, TW, (unsigned*)smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -763,6 +767,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
   const int HWo = a.Hout * a.Wout;
   const int oy = oy0 + oyl, ox = ox0 + oxl;
   const bool raw = a.ws != nullptr;
+  const bool wt = raw && a.sk_count;   // slabs of an in-kernel combine are stored write-through (conv.h)
   float* dst_b = raw ? a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWo
                      : a.out + ((long long)b * a.out_ctot + a.out_coff) * HWo;
   const float* res_b = (!raw && a.res) ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWo : nullptr;
@@ -802,14 +807,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
           }
         }
         if (vec2) {
-          if (row0) *reinterpret_cast<float2*>(dst_b + base) = make_float2(y00, y01);
-          if (row1) *reinterpret_cast<float2*>(dst_b + base + a.Wout) = make_float2(y10, y11);
+          if (row0) slab_store2(dst_b + base, y00, y01, wt);
+          if (row1) slab_store2(dst_b + base + a.Wout, y10, y11, wt);
         } else {
-          if (row0) { dst_b[base] = y00; if (col1) dst_b[base + T::D] = y01; }
-          if (row1) { dst_b[base + T::D * a.Wout] = y10; if (col1) dst_b[base + T::D * a.Wout + T::D] = y11; }
+          if (row0) { slab_store1(dst_b + base, y00, wt); if (col1) slab_store1(dst_b + base + T::D, y01, wt); }
+          if (row1) { slab_store1(dst_b + base + T::D * a.Wout, y10, wt); if (col1) slab_store1(dst_b + base + T::D * a.Wout + T::D, y11, wt); }
         }
       }
     }
+  if (wt) splitk_combine_tile<512>(a, b, sp_tile + a.n_sp * n_tile, n_tile * T::BN, T::BN, oy0, ox0, TH, TW, (unsigned*)smem);
 }
 
 //                           TTH TTW WM WN KC NBUF      patch (px)  couts

@@ -585,6 +585,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
   };
   const int HWo = a.Hout * a.Wout;
   const bool raw = a.ws != nullptr;
+  const bool wt = raw && a.sk_count;   // slabs of an in-kernel combine are stored write-through (conv.h)
   float* dst_b = raw ? a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWo
                      : a.out + ((long long)b * a.out_ctot + a.out_coff) * HWo;
   const float* res_b = (!raw && a.res) ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWo : nullptr;
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
                 o.z = fminf(fmaxf(o.z, 0.f), 6.f); o.w = fminf(fmaxf(o.w, 0.f), 6.f);
               }
             }
-            *reinterpret_cast<float4*>(dst_b + off4) = o;
+            slab_store4(dst_b + off4, o.x, o.y, o.z, o.w, wt);
           }
         } else if (vec4) {
           float4 o = make_float4(y[0], y[1], y[2], y[3]);
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
               o.z = fminf(fmaxf(o.z, 0.f), 6.f); o.w = fminf(fmaxf(o.w, 0.f), 6.f);
             }
           }
-          *reinterpret_cast<float4*>(dst_b + off) = o;
+          slab_store4(dst_b + off, o.x, o.y, o.z, o.w, wt);
         } else {
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
@@ -699,12 +700,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
               if (a.act == ACT_RELU) o = fmaxf(o, 0.f);
               else if (a.act == ACT_RELU6) o = fminf(fmaxf(o, 0.f), 6.f);
             }
-            dst_b[off + T::D * v] = o;
+            slab_store1(dst_b + off + T::D * v, o, wt);
           }
         }
       }
     }
   }
+  if (wt) splitk_combine_tile<512>(a, b, sp_tile + a.n_sp * n_tile, n_tile * T::BN, T::BN, oy0, ox0, T::TH, T::TW, (unsigned*)smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -970,6 +972,7 @@ __global__ __launch_bounds__(768, 3) void conv_wino44b_kernel(const ConvArgs a) 
   // four registers, 96 KB each) and waves 0..7 finish one (cout half, register) each per round: whole 4x4 tiles.
   const int HWo = a.Hout * a.Wout;
   const bool raw = a.ws != nullptr;
+  const bool wt = raw && a.sk_count;   // slabs of an in-kernel combine are stored write-through (conv.h)
   float* dst_b = raw ? a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWo
                      : a.out + ((long long)b * a.out_ctot + a.out_coff) * HWo;
   const float* res_b = (!raw && a.res) ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWo : nullptr;
@@ -1039,11 +1042,12 @@ __global__ __launch_bounds__(768, 3) void conv_wino44b_kernel(const ConvArgs a) 
               o.z = fminf(fmaxf(o.z, 0.f), 6.f); o.w = fminf(fmaxf(o.w, 0.f), 6.f);
             }
           }
-          *reinterpret_cast<float4*>(dst_b + off) = o;
+          slab_store4(dst_b + off, o.x, o.y, o.z, o.w, wt);
         }
       }
     }
   }
+  if (wt) splitk_combine_tile<768>(a, b, sp_tile + a.n_sp * n_tile, n_tile * T::BN, T::BN, oy0, ox0, T::TH, T::TW, (unsigned*)smem);
 }
 
 inline KernelEntry wino44_entry() {

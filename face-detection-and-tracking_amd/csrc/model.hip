@@ -57,6 +57,7 @@ struct Op {
   int hid = 0;
   int level0 = 0, p_off = 0, anchors = 1;
   bool needs_ws = false;
+  bool combine = false;   // split-K partial sums are combined inside the conv kernel (ConvArgs.sk_count)
 };
 
 struct DevW {
@@ -155,7 +156,7 @@ struct fdt_model {
   unsigned long long graph_clock = 0;
   int plan_runs = 0;          // eager forwards since the plan was (re)built; capture starts at the second
   bool use_graph = true;
-  struct Hint { int kind, tile, split, map; };
+  struct Hint { int kind, tile, split, map, combine; };   // combine: in-kernel split-K combine (conv.h) instead of the reduce pass
   std::map<std::string, Hint> hints;                        // autotuned (kernel class, tile, split) per layer
   int hB = 0, hH = 0, hW = 0;                               // shape the hints were tuned for
   std::vector<void*> plan_allocs;
@@ -172,9 +173,12 @@ struct fdt_model {
   double flops_per_frame = 0;
   long long ws_floats = 0;   // split-K / fused-upsample workspace shared by all layers
   float* d_convws = nullptr;
+  unsigned* d_skcnt = nullptr;   // tile counters of the in-kernel split-K combine: shared by all layers (every layer leaves them zero)
+  long long sk_counters = 0;
 
   // profiling
   bool profile = false;
+  long long passes = 0;   // eager or captured passes through run_ops (the FDT_SKIP_OPS hook spares the first)
   std::vector<hipEvent_t> ev;
 
   ~fdt_model() {
@@ -207,6 +211,8 @@ struct fdt_model {
     d_frames_u8 = nullptr;
     d_fb_boxes = d_fb_probs = nullptr;
     d_convws = nullptr;
+    d_skcnt = nullptr;
+    sk_counters = 0;
     ws_floats = 0;
     pB = pH = pW = 0;
   }
@@ -383,6 +389,7 @@ struct Builder {
     op.name = name;
     op.kind = kind;
     int ksplit = 1, map_mode = CONV_MAP_ROWS;
+    bool combine = false;
     auto hint = m->hints.find(name);
     if (hint != m->hints.end() && m->hB == B && m->hH == m->tensors[0].H && m->hW == m->tensors[0].W &&
         conv_base_kind((ConvKind)hint->second.kind) == kind &&
@@ -392,6 +399,7 @@ struct Builder {
       op.tile = (ConvTile)hint->second.tile;
       ksplit = std::max(1, std::min(hint->second.split, ceil_div(in.C, conv_geom(kind).kc)));
       map_mode = hint->second.map;
+      combine = hint->second.combine != 0;
     } else if (kind == CONV_3x3_S1 && Ctot <= 8 && (long long)B * Ho * Wo >= 32768) {
       // narrow loc/conf heads on the large maps: the vector-ALU kernel (conv_n8.h: 70-75 TFLOP/s against the 46 of the
       // best MFMA variant, which pads 8 output channels to 32), split along K until ~512 workgroups are in the grid
@@ -421,6 +429,12 @@ struct Builder {
     op.out_t = out_t;
     op.needs_ws = ksplit > 1;
     if (op.needs_ws) m->ws_floats = std::max(m->ws_floats, conv_ws_floats(a));
+    {
+      ConvArgs probe = a;
+      probe.ws = (float*)16;   // conv_combine_supported only asks whether there is one
+      op.combine = combine && conv_combine_supported(kind, op.tile, probe);
+      if (op.combine) m->sk_counters = std::max(m->sk_counters, conv_sk_counters(kind, op.tile, a));
+    }
     if (!m->dry) {
       if (rc != FDT_OK) return -1;
       const size_t per = (size_t)in.C * g.kh * g.kw;
@@ -1224,6 +1238,12 @@ int make_plan(fdt_model* m, int B, int H, int W) {
     for (auto& op : m->ops)
       if (op.type == OP_CONV && op.needs_ws) op.ca.ws = m->d_convws;
   }
+  if (m->sk_counters) {
+    FDT_TRY(dalloc((void**)&m->d_skcnt, (size_t)m->sk_counters * sizeof(unsigned)));
+    FDT_HIP(hipMemsetAsync(m->d_skcnt, 0, (size_t)m->sk_counters * sizeof(unsigned), m->stream));
+    for (auto& op : m->ops)
+      if (op.type == OP_CONV && op.combine) op.ca.sk_count = m->d_skcnt;
+  }
   FDT_TRY(make_priors(m, H, W));
   m->pB = B;
   m->pH = H;
@@ -1244,12 +1264,39 @@ int ensure_profile_events(fdt_model* m) {
   return FDT_OK;
 }
 
+// Experiment hook (tools/experiments/deletion.sh): FDT_SKIP_OPS="prefix,prefix" leaves the ops whose name starts with one
+// of the prefixes out of the launch sequence after the handle's first pass (so that everything downstream, Detect's
+// data-dependent NMS included, keeps reading plausible maps) -- what is a layer group worth to the multi-stream step?
+// Results are wrong by construction; never set in production.
+bool op_skipped(const std::string& name) {
+  static const std::vector<std::string> prefixes = [] {
+    std::vector<std::string> v;
+    if (const char* e = getenv("FDT_SKIP_OPS")) {
+      std::string s(e), cur;
+      for (char c : s + ",") {
+        if (c == ',') {
+          if (!cur.empty()) v.push_back(cur);
+          cur.clear();
+        } else {
+          cur += c;
+        }
+      }
+    }
+    return v;
+  }();
+  for (const auto& p : prefixes)
+    if (name.compare(0, p.size(), p) == 0) return true;
+  return false;
+}
+
 int run_ops(fdt_model* m, int B, hipStream_t st) {
   const bool prof = m->profile;
   if (prof) FDT_TRY(ensure_profile_events(m));
   for (size_t i = 0; i < m->ops.size(); ++i) {
     const Op& op = m->ops[i];
     if (prof) FDT_HIP(hipEventRecord(m->ev[i], st));
+    if (m->passes > 0 && op_skipped(op.name)) continue;   // first pass complete: later ones read its (stale) maps
+    exp_skip_reduce = m->passes > 0 && op_skipped("@reduce");
     switch (op.type) {
       case OP_CONV:
         FDT_TRY(launch_conv(op.kind, op.tile, op.ca, st, m->device));
@@ -1299,6 +1346,8 @@ int run_ops(fdt_model* m, int B, hipStream_t st) {
     }
   }
   if (prof) FDT_HIP(hipEventRecord(m->ev[m->ops.size()], st));
+  exp_skip_reduce = false;
+  ++m->passes;
   return FDT_OK;
 }
 
@@ -1907,12 +1956,13 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   // FDT_TUNE_ONLY=<substring>: re-measure only the layers whose name contains it (the others keep their plan entry)
   const char* only = getenv("FDT_TUNE_ONLY");
   const float split_penalty = getenv("FDT_TUNE_SPLIT_PENALTY") ? (float)atof(getenv("FDT_TUNE_SPLIT_PENALTY")) : 0.0f;
+  const bool no_combine = getenv("FDT_TUNE_NO_COMBINE") != nullptr;   // experiment hook: reduce passes only, as before round 3
   for (auto& op : m->ops) {
     if (op.type != OP_CONV) continue;
     if (only && *only && op.name.find(only) == std::string::npos) continue;
-    struct Cand { int kind, tile, split; float ms; };
+    struct Cand { int kind, tile, split, combine; float ms; };
     std::vector<Cand> cands;
-    long long ws_need = 0;
+    long long ws_need = 0, cnt_need = 0;
     const ConvKind base = conv_base_kind(op.kind);
     for (int k = 0; k < CONV_KIND_COUNT; ++k) {
       if (conv_base_kind((ConvKind)k) != base) continue;    // e.g. direct and Winograd 3x3/s1
@@ -1929,7 +1979,12 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
           long long wsf = conv_ws_floats(a);
           if (wsf > kMaxWsFloats) break;
           ws_need = std::max(ws_need, wsf);
-          cands.push_back({k, t, split, 0.f});
+          cands.push_back({k, t, split, 0, 0.f});
+          a.ws = (float*)16;
+          if (!no_combine && conv_combine_supported((ConvKind)k, (ConvTile)t, a)) {
+            cnt_need = std::max(cnt_need, conv_sk_counters((ConvKind)k, (ConvTile)t, a));
+            cands.push_back({k, t, split, 1, 0.f});
+          }
         }
       }
     }
@@ -1940,7 +1995,15 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
       rc = FDT_ERR_HIP;
       break;
     }
-    Cand best{(int)op.kind, (int)op.tile, op.ca.ksplit, 1e30f};
+    unsigned* tmp_cnt = nullptr;
+    if (cnt_need && (hipMalloc((void**)&tmp_cnt, (size_t)cnt_need * sizeof(unsigned)) != hipSuccess ||
+                     hipMemsetAsync(tmp_cnt, 0, (size_t)cnt_need * sizeof(unsigned), st) != hipSuccess)) {
+      set_error("fdt_model_autotune: counter allocation failed");
+      rc = FDT_ERR_HIP;
+      if (tmp_ws) (void)hipFree(tmp_ws);
+      break;
+    }
+    Cand best{(int)op.kind, (int)op.tile, op.ca.ksplit, op.combine ? 1 : 0, 1e30f};
     for (auto& c : cands) {
       DevW dw;
       rc = Builder::device_weights(m, op.name, (ConvKind)c.kind, (ConvTile)c.tile, dw);
@@ -1950,6 +2013,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
       a.bias = dw.bias;
       a.ksplit = c.split;
       a.ws = c.split > 1 ? tmp_ws : nullptr;
+      a.sk_count = c.combine ? tmp_cnt : nullptr;
       float best_ms = 1e30f;
       for (int it = 0; it < iters + 1 && rc == FDT_OK; ++it) {
         (void)hipEventRecord(e0, st);
@@ -1976,6 +2040,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
       a.bias = dwb.bias;
       a.ksplit = best.split;
       a.ws = best.split > 1 ? tmp_ws : nullptr;
+      a.sk_count = best.combine ? tmp_cnt : nullptr;
       float map_ms[3] = {1e30f, 1e30f, 1e30f};
       for (int mm = 0; mm < 3 && rc == FDT_OK; ++mm) {
         a.map_mode = mm;
@@ -1995,6 +2060,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
           best_map = mm;
     }
     if (tmp_ws) (void)hipFree(tmp_ws);
+    if (tmp_cnt) (void)hipFree(tmp_cnt);
     if (rc != FDT_OK) break;
     DevW dw;
     rc = Builder::device_weights(m, op.name, (ConvKind)best.kind, (ConvTile)best.tile, dw);
@@ -2006,7 +2072,8 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
     op.ca.w = dw.w;
     op.ca.bias = dw.bias;
     op.needs_ws = best.split > 1;
-    m->hints[op.name] = {best.kind, best.tile, best.split, best_map};
+    op.combine = best.combine != 0;
+    m->hints[op.name] = {best.kind, best.tile, best.split, best_map, best.combine};
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
@@ -2027,11 +2094,25 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   }
   for (auto& op : m->ops)
     if (op.type == OP_CONV) op.ca.ws = op.needs_ws ? m->d_convws : nullptr;
+  long long cneed = 0;
+  for (auto& op : m->ops)
+    if (op.type == OP_CONV && op.combine) cneed = std::max(cneed, conv_sk_counters(op.kind, op.tile, op.ca));
+  if (cneed > m->sk_counters || (cneed && !m->d_skcnt)) {
+    unsigned* p = nullptr;
+    FDT_HIP(hipMalloc((void**)&p, (size_t)cneed * sizeof(unsigned)));
+    FDT_HIP(hipMemset(p, 0, (size_t)cneed * sizeof(unsigned)));
+    m->plan_allocs.push_back(p);
+    m->d_skcnt = p;
+    m->sk_counters = cneed;
+  }
+  for (auto& op : m->ops)
+    if (op.type == OP_CONV) op.ca.sk_count = op.combine ? m->d_skcnt : nullptr;
   m->drop_graphs();   // captured forwards bake in the old kernel choice
   return FDT_OK;
 }
 
-// Plan hints as text: one "layer kind tile split" line per conv layer, first line "shape B H W".
+// Plan hints as text: one "layer kind tile split map [1]" line per conv layer (trailing 1: in-kernel split-K combine), first
+// line "shape B H W".
 extern "C" int fdt_model_export_plan(fdt_model* m, char* buf, int buflen, int* needed) {
   FDT_REQUIRE(m && needed, FDT_ERR_ARG, "fdt_model_export_plan: bad argument");
   FDT_REQUIRE(m->pB > 0, FDT_ERR_STATE, "fdt_model_export_plan: no plan yet");
@@ -2039,7 +2120,7 @@ extern "C" int fdt_model_export_plan(fdt_model* m, char* buf, int buflen, int* n
   for (auto& op : m->ops)
     if (op.type == OP_CONV)
       out += op.name + " " + std::to_string((int)op.kind) + " " + std::to_string((int)op.tile) + " " +
-             std::to_string(op.ca.ksplit) + " " + std::to_string(op.ca.map_mode) + "\n";
+             std::to_string(op.ca.ksplit) + " " + std::to_string(op.ca.map_mode) + (op.combine ? " 1" : "") + "\n";
   *needed = (int)out.size() + 1;
   if (buf && buflen >= *needed) memcpy(buf, out.c_str(), out.size() + 1);
   return FDT_OK;
@@ -2056,15 +2137,16 @@ extern "C" int fdt_model_import_plan(fdt_model* m, const char* text) {
     p = e ? e + 1 : p + line.size();
     if (line.empty()) continue;
     char name[256];
-    int a = 0, b = 0, c = 0, d = 0, nf = 0;
+    int a = 0, b = 0, c = 0, d = 0, cb = 0, nf = 0;
     if (sscanf(line.c_str(), "shape %d %d %d", &a, &b, &c) == 3) {
       B = a; H = b; W = c;
-    } else if ((nf = sscanf(line.c_str(), "%255s %d %d %d %d", name, &a, &b, &c, &d)) >= 4) {
+    } else if ((nf = sscanf(line.c_str(), "%255s %d %d %d %d %d", name, &a, &b, &c, &d, &cb)) >= 4) {
       if (nf == 4) d = CONV_MAP_ROWS;      // plans written before the workgroup map became a choice
+      if (nf <= 5) cb = 0;                 // ... and before the in-kernel split-K combine existed
       FDT_REQUIRE(a >= 0 && a < CONV_KIND_COUNT && b >= 0 && b < CONV_TILE_COUNT && c >= 1 && c <= 4096 &&
-                      d >= CONV_MAP_ROWS && d <= CONV_MAP_XCD_CHANNEL,
+                      d >= CONV_MAP_ROWS && d <= CONV_MAP_XCD_CHANNEL && (cb == 0 || cb == 1),
                   FDT_ERR_ARG, "fdt_model_import_plan: bad entry '%s'", line.c_str());
-      hints[name] = {a, b, c, d};
+      hints[name] = {a, b, c, d, cb};
     } else {
       set_error("fdt_model_import_plan: cannot parse '%s'", line.c_str());
       return FDT_ERR_ARG;

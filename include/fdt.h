@@ -126,7 +126,10 @@ int fdt_facebox_decode(const float* loc, const float* conf, const float* anchors
  * (pyramid.py:65-68), then act (0 none, 1 ReLU, 2 ReLU6).  (ksize,stride,pad,dil) must be one of the
  * instantiated classes: 1x1 s1|s2 p0; 3x3 s1 p1; 3x3 s1 p2 d2; 3x3 s2 p1; 7x7 s2 p3; 7x7 s4 p3; 5x5 s2 p2.
  * tile/ksplit pick a kernel variant explicitly (tile < 0, ksplit <= 0: automatic; tile >= 100 means
- * variant_class * 100 + tile for the alternative implementations of a class, e.g. deep-stage 1x1).   */
+ * variant_class * 100 + tile for the alternative implementations of a class, e.g. deep-stage 1x1;
+ * ksplit | FDT_SPLIT_COMBINE: the split-K partial sums are combined inside the conv kernel by the
+ * last workgroup to arrive at an output tile instead of by a second pass -- same sums, same order).    */
+#define FDT_SPLIT_COMBINE 0x1000
 int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const float* w_oihw, const float* bias,
                int Cout, int ksize, int stride, int pad, int dil, const float* residual, const float* up,
                int up_h, int up_w, int act, int tile, int ksplit, float* out);

@@ -199,6 +199,59 @@ def test_deep_reduction_split_k_is_deterministic():
     assert rel_err(outs[0], exp) < 1e-5
 
 
+COMBINE = 0x1000   # include/fdt.h FDT_SPLIT_COMBINE: the last workgroup to arrive at an output tile sums the split-K slabs
+
+
+@pytest.mark.parametrize("case", [
+    # (k, s, p, d, tile, split, B, Cin, H, W, Cout)                       kernel the (class, tile) selects
+    (1, 1, 0, 1, 2, 4, 2, 256, 24, 40, 136),      # direct 1x1, tiles hanging over the map and over Cout
+    (1, 1, 0, 1, 1006, 8, 1, 512, 16, 16, 64),    # deep-stage 1x1 (K32)
+    (3, 1, 1, 1, 3, 16, 1, 512, 16, 16, 64),      # direct 3x3
+    (3, 2, 1, 1, 2, 4, 1, 128, 33, 64, 96),       # strided 3x3 (Wout = 32)
+    (3, 1, 2, 2, 2, 8, 1, 256, 8, 8, 64),         # dilated direct
+    (3, 1, 1, 1, 14, 2, 2, 64, 20, 36, 40),       # Winograd F(2x2), 4 waves (8-byte slab stores)
+    (3, 1, 1, 1, 22, 4, 1, 128, 32, 32, 64),      # ... half-split 8-wave form
+    (3, 1, 1, 1, 30, 8, 1, 256, 32, 32, 128),     # ... quarter-split form
+    (3, 1, 2, 2, 29, 4, 1, 128, 24, 32, 64),      # ... dilated quarter-split form (4-byte slab stores)
+    (3, 1, 2, 2, 24, 2, 1, 64, 16, 64, 64),       # ... dilated half-split form
+    (3, 1, 1, 1, 32, 4, 1, 64, 40, 64, 72),       # Winograd F(4x4), 8 waves
+    (3, 1, 1, 1, 33, 2, 2, 32, 16, 32, 64),       # ... 12 waves
+    (3, 1, 2, 2, 32, 4, 1, 64, 24, 32, 64),       # ... dilated
+])
+def test_in_kernel_split_k_combine_equals_the_reduce_pass(case):
+    """conv.h splitk_combine_tile: same slabs, same summation order, same epilogue as splitk_reduce_kernel -> the same bits,
+    whoever arrives last (two runs), with bias + residual + ReLU on top; 1x1 also with the fused upsample-add."""
+    k, s, p, d, tile, split, B, Cin, H, W, Cout = case
+    rng = np.random.default_rng(hash(case) & 0xffff)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    Ho = (H + 2 * p - d * (k - 1) - 1) // s + 1
+    Wo = (W + 2 * p - d * (k - 1) - 1) // s + 1
+    assert Wo % 4 == 0
+    res = rng.standard_normal((B, Cout, Ho, Wo)).astype(np.float32)
+    up = rng.standard_normal((B, Cout, (Ho + 1) // 2, (Wo + 1) // 2)).astype(np.float32) if (k == 1 and tile < 100) else None
+    rc, two_pass = run_conv(x, w, b, k, s, p, d, res=res, up=up, act=1, tile=tile, split=split)
+    assert rc == 0, lib().lib().fdt_last_error()
+    for _ in range(2):
+        rc, fused = run_conv(x, w, b, k, s, p, d, res=res, up=up, act=1, tile=tile, split=split | COMBINE)
+        assert rc == 0, lib().lib().fdt_last_error()
+        assert np.array_equal(fused, two_pass)
+    tol = WINO44_TOL if tile in (T_WINO44, T_WINO44B) else 2e-5
+    assert rel_err(fused, reference(x, w, b, k, s, p, d, res=res, up=up, act=1)) < tol
+
+
+def test_in_kernel_combine_refuses_what_it_cannot_do():
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((1, 64, 9, 9)).astype(np.float32)          # Wout % 4 != 0: 4-byte rows, not offered
+    w = rng.standard_normal((32, 64, 1, 1)).astype(np.float32)
+    rc, _ = run_conv(x, w, None, 1, 1, 0, 1, tile=2, split=2 | COMBINE)
+    assert rc != 0 and b"combine" in lib().lib().fdt_last_error()
+    x = rng.standard_normal((1, 64, 8, 8)).astype(np.float32)          # nothing to combine
+    rc, _ = run_conv(x, w, None, 1, 1, 0, 1, tile=2, split=1 | COMBINE)
+    assert rc != 0
+
+
 def test_unknown_class_is_an_error():
     x = np.zeros((1, 4, 8, 8), np.float32)
     w = np.zeros((4, 4, 3, 3), np.float32)
