@@ -432,6 +432,8 @@ struct Builder {
     {
       ConvArgs probe = a;
       probe.ws = (float*)16;   // conv_combine_supported only asks whether there is one
+      static const int force = getenv("FDT_FORCE_COMBINE") ? atoi(getenv("FDT_FORCE_COMBINE")) : -1;   // experiment hook: 1 all / 0 none
+      if (force >= 0) combine = force != 0 && ksplit <= (getenv("FDT_FORCE_COMBINE_MAXS") ? atoi(getenv("FDT_FORCE_COMBINE_MAXS")) : 4096);
       op.combine = combine && conv_combine_supported(kind, op.tile, probe);
       if (op.combine) m->sk_counters = std::max(m->sk_counters, conv_sk_counters(kind, op.tile, a));
     }
@@ -1956,7 +1958,9 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   // FDT_TUNE_ONLY=<substring>: re-measure only the layers whose name contains it (the others keep their plan entry)
   const char* only = getenv("FDT_TUNE_ONLY");
   const float split_penalty = getenv("FDT_TUNE_SPLIT_PENALTY") ? (float)atof(getenv("FDT_TUNE_SPLIT_PENALTY")) : 0.0f;
-  const bool no_combine = getenv("FDT_TUNE_NO_COMBINE") != nullptr;   // experiment hook: reduce passes only, as before round 3
+  // The in-kernel split-K combine (conv.h) is a candidate only on request (FDT_TUNE_COMBINE=1): measured, it wins a tenth of
+  // the split layers in isolation and nothing in the multi-stream step (docs/EXPERIMENTS.md R3-4)
+  const bool no_combine = !(getenv("FDT_TUNE_COMBINE") && atoi(getenv("FDT_TUNE_COMBINE")) != 0);
   for (auto& op : m->ops) {
     if (op.type != OP_CONV) continue;
     if (only && *only && op.name.find(only) == std::string::npos) continue;

@@ -400,6 +400,35 @@ def test_res50_native_1080p_vs_reference_fixture(res50, synth):
     assert np.array_equal(res50(frame).numpy(), y)              # graph replay: same bits
 
 
+def test_plan_with_in_kernel_split_k_combine_gives_the_same_bits(res50, synth):
+    """The optional sixth plan column (fdt_model_export_plan / _import_plan): split-K layers combined inside the conv kernel by
+    the last workgroup to arrive (csrc/conv.h) instead of by splitk_reduce_kernel.  Same slabs, same order -> the whole
+    forward (640 x 480, every split layer the kernels support switched over) is bit-identical, eagerly and from the graph."""
+    frame = synth.make_frames(1, 480, 640, seed=77)[0]
+    res50.priorbox = M("layers").PriorBoxLayer(640, 480); res50.firstTime = True
+    res50.detect = M("layers").Detect(2, 0, 750, 0.05, 0.3)
+    plan = res50.tuned_plan_text(480, 640, 1)
+    assert plan is not None
+    res50.import_plan(plan)
+    y = res50(frame).numpy()
+    loc, conf = res50.get_tensor("loc").copy(), res50.get_tensor("conf").copy()
+    lines, n_split = [], 0
+    for ln in plan.splitlines():
+        f = ln.split()
+        if len(f) == 5 and f[0] != "shape" and int(f[3]) > 1:
+            ln += " 1"
+            n_split += 1
+        lines.append(ln)
+    assert n_split >= 20
+    res50.import_plan("\n".join(lines) + "\n")
+    for _ in range(3):                                             # eager pass, graph capture, replay
+        assert np.array_equal(res50(frame).numpy(), y)
+    assert np.array_equal(res50.get_tensor("loc"), loc) and np.array_equal(res50.get_tensor("conf"), conf)
+    combined = [ln for ln in res50.export_plan().splitlines() if len(ln.split()) == 6]
+    assert len(combined) >= 10, len(combined)                      # (the 8-channel VALU heads and Wout % 4 != 0 maps stay two-pass)
+    res50.import_plan(plan)
+
+
 def test_try3_1024_batch8_vs_reference_fixture(try3, synth):
     """Config 3 of BASELINE.json: ONE batched forward of eight 1024x1024 frames (the depthwise / batched conv plan that
     bench.py --arch try3 --batch 8 times) against the reference's own batch-8 forward, per image."""
