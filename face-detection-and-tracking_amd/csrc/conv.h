@@ -100,6 +100,7 @@ struct ConvArgs {
   int act;
   int ksplit;             // >= 1: split the input-channel reduction over this many workgroups
   float* ws;              // split-K workspace, B*ksplit*Cout*Hout*Wout floats (ksplit > 1, or `up` on a Winograd tile)
+  int defer_reduce;       // non-zero: the split-K slabs stay in ws for the consumer (the grouped head finalize, ops.h)
   unsigned* sk_count;     // non-null: in-kernel split-K combine (splitk_combine_tile below), one zeroed counter per
                           // (image, output tile): conv_sk_counters() of them; null: splitk_reduce_kernel finishes the layer
   // workgroup -> (spatial tile, output-channel tile) map (FDT_BLOCK_MAP below): map_mode is the caller's choice

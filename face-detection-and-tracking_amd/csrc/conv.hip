@@ -290,6 +290,9 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
   FDT_REQUIRE(a.ksplit == 1 || a.ws, FDT_ERR_ARG, "launch_conv: workspace required");
   FDT_REQUIRE(!a.ws || a.ksplit > 1, FDT_ERR_ARG, "launch_conv: unexpected workspace");
   // in-kernel combine (conv.h, splitk_combine_tile): 16-byte slab rows, one image's slabs behind one buffer descriptor
+  FDT_REQUIRE(!(a.sk_count && a.defer_reduce), FDT_ERR_ARG, "launch_conv: in-kernel combine and deferred reduce exclude each other");
+  FDT_REQUIRE(!a.defer_reduce || (a.ksplit > 1 && !a.res && !a.up && a.act == ACT_NONE), FDT_ERR_ARG,
+              "launch_conv: a deferred reduce carries bias only (the head convs)");
   FDT_REQUIRE(!a.sk_count || conv_combine_supported(kind, tile, a), FDT_ERR_ARG,
               "launch_conv: in-kernel split-K combine needs ksplit > 1, Wout %% 4 == 0 and < 2 GB of slabs per image");
   FDT_REQUIRE(!a.up || conv_base_kind(kind) == CONV_1x1_S1, FDT_ERR_ARG,
@@ -307,7 +310,7 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
   const bool odd = ke.fn_odd && (a.Win & 3);
   hipLaunchKernelGGL(odd ? ke.fn_odd : ke.fn, grid, dim3(odd && ke.threads_odd ? ke.threads_odd : ke.threads), ke.lds, st, a);
   FDT_LAUNCH_CHECK();
-  if (a.ws && !a.sk_count && !exp_skip_reduce) {
+  if (a.ws && !a.sk_count && !a.defer_reduce && !exp_skip_reduce) {
     const long long total = (long long)a.B * a.Cout * a.Hout * a.Wout;
     if (a.Wout % 4 == 0)
       hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)ceil_div_ll(total / 4, 256)), dim3(256), 0, st, a);

@@ -58,6 +58,8 @@ struct Op {
   int level0 = 0, p_off = 0, anchors = 1;
   bool needs_ws = false;
   bool combine = false;   // split-K partial sums are combined inside the conv kernel (ConvArgs.sk_count)
+  bool last_head = false; // OP_HEADFIN: the one that launches the grouped finalize of all levels
+  bool head = false;      // OP_CONV: a head conv (its split-K slabs go to the grouped finalize, no reduce pass)
 };
 
 struct DevW {
@@ -173,6 +175,9 @@ struct fdt_model {
   double flops_per_frame = 0;
   long long ws_floats = 0;   // split-K / fused-upsample workspace shared by all layers
   float* d_convws = nullptr;
+  float* d_headws = nullptr;     // split-K slabs of the head convs, one region per level (they live until the grouped finalize)
+  long long headws_floats = 0;
+  HeadFinArgs headfin;           // table of the grouped head finalize (ops.h); nlev == 0: no PyramidBox heads
   unsigned* d_skcnt = nullptr;   // tile counters of the in-kernel split-K combine: shared by all layers (every layer leaves them zero)
   long long sk_counters = 0;
 
@@ -213,6 +218,9 @@ struct fdt_model {
     d_convws = nullptr;
     d_skcnt = nullptr;
     sk_counters = 0;
+    d_headws = nullptr;
+    headws_floats = 0;
+    headfin.nlev = 0;
     ws_floats = 0;
     pB = pH = pW = 0;
   }
@@ -1191,6 +1199,8 @@ int make_priors(fdt_model* m, int H, int W) {
 }
 
 // (Re)build the execution plan for a batch shape.
+int setup_heads(fdt_model* m);
+
 int make_plan(fdt_model* m, int B, int H, int W) {
   if (m->pB == B && m->pH == H && m->pW == W && !m->ops.empty()) {
     if (m->priors_dirty) {
@@ -1246,6 +1256,7 @@ int make_plan(fdt_model* m, int B, int H, int W) {
     for (auto& op : m->ops)
       if (op.type == OP_CONV && op.combine) op.ca.sk_count = m->d_skcnt;
   }
+  FDT_TRY(setup_heads(m));
   FDT_TRY(make_priors(m, H, W));
   m->pB = B;
   m->pH = H;
@@ -1291,6 +1302,66 @@ bool op_skipped(const std::string& name) {
   return false;
 }
 
+// The grouped head finalize: every OP_HEADFIN follows its head conv; the LAST one launches one kernel for all levels.  A head
+// conv that is split along K leaves its slabs in a region of its own (they must survive the other heads) and skips its reduce
+// pass -- the finalize kernel sums them.  Called when the plan is made and again after an autotune (the splits may change).
+int setup_heads(fdt_model* m) {
+  HeadFinArgs& h = m->headfin;
+  memset(&h, 0, sizeof(h));
+  long long need = 0;
+  for (size_t i = 0; i < m->ops.size(); ++i) {
+    if (m->ops[i].type != OP_HEADFIN) continue;
+    FDT_REQUIRE(i > 0 && m->ops[i - 1].type == OP_CONV && m->ops[i - 1].out_t == m->ops[i].in_t && h.nlev < 8, FDT_ERR_STATE,
+                "head finalize without its head conv");
+    const Op& c = m->ops[i - 1];
+    if (c.ca.ksplit > 1) need += conv_ws_floats(c.ca);
+    ++h.nlev;
+  }
+  if (!h.nlev) return FDT_OK;
+  if (need > m->headws_floats) {
+    float* p = nullptr;
+    FDT_HIP(hipMalloc((void**)&p, (size_t)need * 4));
+    m->plan_allocs.push_back(p);
+    m->d_headws = p;
+    m->headws_floats = need;
+  }
+  long long off = 0;
+  int l = 0, blk = 0;
+  for (size_t i = 0; i < m->ops.size(); ++i) {
+    if (m->ops[i].type != OP_HEADFIN) continue;
+    Op& c = m->ops[i - 1];
+    const Tensor& t = m->tensors[m->ops[i].in_t];
+    HeadLevel& L = h.lv[l++];
+    L.HW = t.H * t.W;
+    L.level0 = m->ops[i].level0;
+    L.p_off = m->ops[i].p_off;
+    L.blk0 = blk;
+    blk += ceil_div(L.HW, 256);
+    L.ksplit = c.ca.ksplit;
+    c.combine = false;
+    c.head = true;
+    c.ca.sk_count = nullptr;
+    if (c.ca.ksplit > 1) {
+      c.ca.defer_reduce = 1;
+      c.ca.ws = m->d_headws + off;
+      off += conv_ws_floats(c.ca);
+      L.src = c.ca.ws;
+      L.bias = c.ca.bias;
+    } else {
+      c.ca.defer_reduce = 0;
+      L.src = t.d;
+      L.bias = nullptr;
+    }
+    m->ops[i].last_head = l == h.nlev;
+  }
+  h.nblocks = blk;
+  h.P = m->P;
+  h.loc = m->d_loc;
+  h.conf = m->d_conf;
+  h.logits = m->d_logits;
+  return FDT_OK;
+}
+
 int run_ops(fdt_model* m, int B, hipStream_t st) {
   const bool prof = m->profile;
   if (prof) FDT_TRY(ensure_profile_events(m));
@@ -1329,12 +1400,9 @@ int run_ops(fdt_model* m, int B, hipStream_t st) {
                                  out.W, st, m->device));
         break;
       }
-      case OP_HEADFIN: {
-        const Tensor& in = m->tensors[op.in_t];
-        FDT_TRY(launch_head_finalize(in.d, B, in.H, in.W, op.level0, m->P, op.p_off, m->d_loc, m->d_conf,
-                                     m->d_logits, st));
+      case OP_HEADFIN:
+        if (op.last_head) FDT_TRY(launch_head_finalize_all(m->headfin, B, st));   // all levels at once (setup_heads)
         break;
-      }
       case OP_MBOXFIN: {
         const Tensor& in = m->tensors[op.in_t];
         const long long hw = (long long)in.H * in.W;
@@ -1985,7 +2053,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
           ws_need = std::max(ws_need, wsf);
           cands.push_back({k, t, split, 0, 0.f});
           a.ws = (float*)16;
-          if (!no_combine && conv_combine_supported((ConvKind)k, (ConvTile)t, a)) {
+          if (!no_combine && !op.head && conv_combine_supported((ConvKind)k, (ConvTile)t, a)) {
             cnt_need = std::max(cnt_need, conv_sk_counters((ConvKind)k, (ConvTile)t, a));
             cands.push_back({k, t, split, 1, 0.f});
           }
@@ -2018,6 +2086,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
       a.ksplit = c.split;
       a.ws = c.split > 1 ? tmp_ws : nullptr;
       a.sk_count = c.combine ? tmp_cnt : nullptr;
+      a.defer_reduce = op.head && c.split > 1 ? 1 : 0;   // a head conv's reduce pass is the grouped finalize's business
       float best_ms = 1e30f;
       for (int it = 0; it < iters + 1 && rc == FDT_OK; ++it) {
         (void)hipEventRecord(e0, st);
@@ -2045,6 +2114,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
       a.ksplit = best.split;
       a.ws = best.split > 1 ? tmp_ws : nullptr;
       a.sk_count = best.combine ? tmp_cnt : nullptr;
+      a.defer_reduce = op.head && best.split > 1 ? 1 : 0;
       float map_ms[3] = {1e30f, 1e30f, 1e30f};
       for (int mm = 0; mm < 3 && rc == FDT_OK; ++mm) {
         a.map_mode = mm;
@@ -2111,6 +2181,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   }
   for (auto& op : m->ops)
     if (op.type == OP_CONV) op.ca.sk_count = op.combine ? m->d_skcnt : nullptr;
+  FDT_TRY(setup_heads(m));   // the head convs' own slab regions and the grouped finalize table follow the new splits
   m->drop_graphs();   // captured forwards bake in the old kernel choice
   return FDT_OK;
 }

@@ -34,6 +34,24 @@ int launch_pad1(const float* in, int BC, int H, int W, float* out, hipStream_t s
 int launch_head_finalize(const float* head, int B, int H, int W, int level0, int P, int p_off,
                          float* loc, float* conf, float* logits, hipStream_t st);
 
+// All detection levels of a frame in ONE launch.  A level's head map is either the finished conv output [B][8][HW]
+// (ksplit == 1) or the split-K slabs the head conv left in its own workspace [B][ksplit][8][HW] (launch_conv with
+// ConvArgs.defer_reduce): the slabs are summed here in ks order and the bias added last -- the order of
+// splitk_reduce_kernel, so the two paths agree bit for bit -- which saves the head convs' reduce passes as well.
+struct HeadLevel {
+  const float* src;
+  const float* bias;     // [8], used when ksplit > 1
+  int HW, ksplit, level0, p_off, blk0;   // blk0: first block of this level in the grid's x dimension
+};
+struct HeadFinArgs {
+  HeadLevel lv[8];
+  int nlev, nblocks, P;
+  float* loc;
+  float* conf;
+  float* logits;
+};
+int launch_head_finalize_all(const HeadFinArgs& a, int B, hipStream_t st);
+
 // FaceBox multibox level: loc map [A*4][H][W] and conf map [A*2][H][W] inside one per-image block of
 // `img_stride` floats -> rows of A anchors per cell (FACEBOX/multibox_layer.py:34-48), raw logits and
 // softmax (FACEBOX/My_test_facebox.py:25).

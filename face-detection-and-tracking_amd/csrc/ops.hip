@@ -394,6 +394,46 @@ __global__ void head_finalize_kernel(const float* __restrict__ head, int HW, int
   if (logits) reinterpret_cast<float2*>(logits)[row] = make_float2(neg, pos);
 }
 
+__global__ void head_finalize_all_kernel(const HeadFinArgs a) {
+  const int b = blockIdx.y;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (i < a.nlev && (int)blockIdx.x >= a.lv[i].blk0) l = i;
+  const HeadLevel& L = a.lv[l];
+  const int p = ((int)blockIdx.x - L.blk0) * blockDim.x + threadIdx.x;
+  if (p >= L.HW) return;
+  float v[8];
+  if (L.ksplit > 1) {
+    const float* s = L.src + (long long)b * L.ksplit * 8 * L.HW + p;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = 0.0f;
+    for (int k = 0; k < L.ksplit; ++k)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] += s[((long long)k * 8 + c) * L.HW];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] += L.bias ? L.bias[c] : 0.0f;
+  } else {
+    const float* h = L.src + (long long)b * 8 * L.HW + p;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = h[(long long)c * L.HW];
+  }
+  float neg, pos;
+  if (L.level0) {   // (a,b,c,pos): neg = max(a,b,c)          pyramid.py:292-298
+    neg = fmaxf(fmaxf(v[4], v[5]), v[6]);
+    pos = v[7];
+  } else {          // (neg,a,b,c): pos = max(a,b,c)          pyramid.py:299-305
+    neg = v[4];
+    pos = fmaxf(fmaxf(v[5], v[6]), v[7]);
+  }
+  const long long row = (long long)b * a.P + L.p_off + p;
+  reinterpret_cast<float4*>(a.loc)[row] = make_float4(v[0], v[1], v[2], v[3]);
+  float pn, pp;
+  softmax2(neg, pos, pn, pp);
+  reinterpret_cast<float2*>(a.conf)[row] = make_float2(pn, pp);
+  if (a.logits) reinterpret_cast<float2*>(a.logits)[row] = make_float2(neg, pos);
+}
+
 __global__ void multibox_finalize_kernel(const float* __restrict__ locmap, const float* __restrict__ confmap,
                                          long long img_stride, int A, int HW, int P, int p_off,
                                          float* __restrict__ loc, float* __restrict__ conf,
@@ -491,6 +531,13 @@ int launch_dwconv(const float* in, const float* wk, const float* bias, int B, in
 int launch_pad1(const float* in, int BC, int H, int W, float* out, hipStream_t st) {
   const long long total = (long long)BC * (H + 2) * (W + 2);
   hipLaunchKernelGGL(pad1_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, H, W, out, total);
+  FDT_LAUNCH_CHECK();
+  return FDT_OK;
+}
+
+int launch_head_finalize_all(const HeadFinArgs& a, int B, hipStream_t st) {
+  FDT_REQUIRE(a.nlev >= 1 && a.nlev <= 8 && a.nblocks >= 1 && B >= 1 && B <= 65535, FDT_ERR_ARG, "launch_head_finalize_all: bad table");
+  hipLaunchKernelGGL(head_finalize_all_kernel, dim3(a.nblocks, B), dim3(256), 0, st, a);
   FDT_LAUNCH_CHECK();
   return FDT_OK;
 }
