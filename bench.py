@@ -363,8 +363,7 @@ def main():
     ap.add_argument("--save-plan", type=int, default=0, help="write the autotuned plan under tuned/")
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per GPU: consecutive batch-1 steps overlap on separate HIP streams "
-                         "(detection of frame i+1 runs beside the tail / tracker step of frame i); default 4 for Res50 at batch 1, "
-                         "else 3; FaceBoxes 4")
+                         "(detection of frame i+1 runs beside the tail / tracker step of frame i); default 8; FaceBoxes 4")
     ap.add_argument("--graph", type=int, default=1, help="replay each forward as a captured HIP graph (0: eager launches)")
     ap.add_argument("--host-frames", type=int, default=128,
                     help="also report the PCIe-inclusive rate: N frames handed over as pageable host buffers through the "
@@ -410,9 +409,11 @@ def main():
     W = args.width or args.size
     sd = synth.make_state_dict(args.arch, seed=0)
     B = max(1, args.batch)
-    # frames in flight: measured optimum (A/B on the box, three repetitions): Res50 at batch 1 four (1024^2: 217.5 vs 215.2
-    # frames/s, 640x480: 506 vs 490; five is worse), batched forwards and try3 three (640x480 batch 4: 651 vs 626)
-    NF = args.inflight if args.inflight > 0 else (4 if (args.arch == "res50" and B == 1) else 3)
+    # frames in flight: eight everywhere since round 3 (tools/experiments/inflight_repeat.sh, inflight_other_configs.sh, three
+    # repetitions): Res50 1024^2 4 / 8 / 12 in flight = 258.3 / 265.3 / 268.2 frames/s over 256 steps and 255.9 / 261.2 / 259.7 over
+    # the 20 steps the driver times; 640x480 605 / 613 / 614; batch 2: 285 (3) / 292 (8); try3 batch 1: 1237 (3) / 1417 (8);
+    # 1080p 126 (4) / 131 (8).  Multiples of the four hardware queues do best; five is worse than four.
+    NF = args.inflight if args.inflight > 0 else 8
     if args.arch == "res50":
         net = importlib.import_module("face-detection-and-tracking_amd.pyramid").SFD(device=local_rank)
         net.priorbox = layers.PriorBoxLayer(W, H)
@@ -851,7 +852,7 @@ def host_frames_rate(args, lib, net, frames_h, H, W, SH, SW):
     cal.net = net
     U = frames_h.shape[0]
     n = args.host_frames
-    NF = 3                           # three handles x two tickets: measured optimum of this path (four: -7 %)
+    NF = int(os.environ.get("FDT_HOST_NF", "3"))   # three handles x two tickets: measured optimum of this path (four: -7 %)
     size = (W, H) if args.source else None
     cal.track((frames_h[i % U] for i in range(2 * NF + 2)), inflight=NF, size=size)     # plans, graphs, pinned slots
     torch.cuda.synchronize()

@@ -41,6 +41,8 @@ SIGNATURES = {
     "fdt_set_device": (C.c_int, [C.c_int]),
     "fdt_device_synchronize": (C.c_int, []),
     "fdt_thread_stream": (C.c_int, [C.POINTER(_vp)]),
+    "fdt_stream_create_partition": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
+    "fdt_stream_destroy": (C.c_int, [_vp]),
     "fdt_device_mem_info": (C.c_int, [_c_i64_p, _c_i64_p]),
     "fdt_priorbox": (C.c_int, [C.c_int] * 5 + [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     "fdt_decode": (C.c_int, [_vp, _vp, C.c_int, C.c_float, C.c_float, _vp]),

@@ -65,3 +65,25 @@ extern "C" int fdt_device_mem_info(long long* free_bytes, long long* total_bytes
   if (total_bytes) *total_bytes = (long long)t;
   return FDT_OK;
 }
+
+// A stream confined to a share of the compute units: partition `part` of `parts` (1, 2 or 4) equal slices of EVERY XCD's
+// CUs.  On this chip bit i of hipExtStreamCreateWithCUMask's mask is CU i / 8 of XCD i % 8 and every XCD must keep at
+// least one CU (tools/microbench/cu_mask_probe.hip), so a partition is a contiguous run of 256 / parts mask bits.  Kernels
+// of streams on different partitions run side by side by construction instead of by the dispatcher's leave.
+extern "C" int fdt_stream_create_partition(int part, int parts, void** stream) {
+  FDT_REQUIRE(stream && (parts == 1 || parts == 2 || parts == 4) && part >= 0 && part < parts, FDT_ERR_ARG,
+              "fdt_stream_create_partition: partition %d of %d", part, parts);
+  uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int per = 256 / parts;
+  for (int i = part * per; i < (part + 1) * per; ++i) mask[i / 32] |= 1u << (i % 32);
+  hipStream_t st = nullptr;
+  FDT_HIP(hipExtStreamCreateWithCUMask(&st, 8, mask));
+  *stream = (void*)st;
+  return FDT_OK;
+}
+
+extern "C" int fdt_stream_destroy(void* stream) {
+  FDT_REQUIRE(stream, FDT_ERR_ARG, "fdt_stream_destroy: null stream");
+  FDT_HIP(hipStreamDestroy((hipStream_t)stream));
+  return FDT_OK;
+}

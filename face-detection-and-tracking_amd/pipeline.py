@@ -11,6 +11,7 @@ The frames of a step (world x batch records in rank order == frame order) are as
 (fdt_tracker_step_dev_multi).  Nothing here synchronises with the host; `finish()` does.
 """
 import ctypes
+import os
 
 import torch
 
@@ -43,7 +44,16 @@ class DetectTrackPipeline:
                                   log_frames=max(log_frames, world * self.B))
         # non-default torch streams: their handles go through the C ABI, so torch.cuda.Event and the collective are
         # ordered with the library's launches
-        self.det_streams = [torch.cuda.Stream(device=device) for _ in range(self.NF)]
+        parts = int(os.environ.get("FDT_CU_PARTS", "1"))      # experiment: detector streams on CU partitions (fdt.h)
+        if parts > 1:
+            self._raw_streams = []
+            for k in range(self.NF):
+                sp = ctypes.c_void_p()
+                _lib.check(_lib.lib().fdt_stream_create_partition(k % parts, parts, ctypes.byref(sp)))
+                self._raw_streams.append(sp)
+            self.det_streams = [torch.cuda.ExternalStream(sp.value, device=device) for sp in self._raw_streams]
+        else:
+            self.det_streams = [torch.cuda.Stream(device=device) for _ in range(self.NF)]
         self.trk_stream = torch.cuda.Stream(device=device)
         self.sp_det = [ctypes.c_void_p(s.cuda_stream) for s in self.det_streams]
         self.sp_trk = ctypes.c_void_p(self.trk_stream.cuda_stream)

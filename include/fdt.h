@@ -66,6 +66,11 @@ int fdt_device_synchronize(void);
  * consumer_stream of fdt_model_async_record) means.  A caller that passed NULL orders later work behind the
  * library's by using / synchronising this stream.                                                            */
 int fdt_thread_stream(void** stream);
+/* A stream confined to partition `part` of `parts` (1, 2, 4) equal shares of every XCD's compute units
+ * (hipExtStreamCreateWithCUMask): forwards enqueued on streams of different partitions run side by side.
+ * Destroy with fdt_stream_destroy once nothing is in flight on it.                                      */
+int fdt_stream_create_partition(int part, int parts, void** stream);
+int fdt_stream_destroy(void* stream);
 /* free / total HBM of the current device (hipMemGetInfo) */
 int fdt_device_mem_info(long long* free_bytes, long long* total_bytes);
 
