@@ -75,15 +75,19 @@ struct W44T {
   static constexpr int TH = 4 * TTH, TW = 4 * TTW;       // 16 x 32 output pixels per workgroup
   static constexpr int BN = 64;                          // output channels per workgroup
   static constexpr int PH = TH + 2 * D, PWU = TW + 2 * D;   // staged patch: 18 rows of 34 pixels (D = 2: 20 x 36) ...
-  static constexpr int PW = VEC ? 40 : 36;               // ... at a row pitch of 40 (ten 16-byte pieces) / 36 floats
+  // ... at a row pitch of 40 (ten 16-byte pieces) / 36 floats.  D = 2: 44 -- an eleventh, never-fetched piece per row: the lanes
+  // of a window read are (px, py, cx, cy) = +1, +PW, +8, +8 PW floats apart, which at PW = 40 puts cy = 0 / 1 on the same bank
+  // (8 x 40 = 5 x 64) and (cx = 3, py = 1) on (0, 0)'s: 55 % of that kernel's LDS cycles were conflicts; at 44 all 32 differ
+  static constexpr int PW = VEC ? (D == 2 ? 44 : 40) : 36;
+  static constexpr int PIECES_ROW = 10;                  // fetched pieces per row
   // VEC: piece j of a row holds columns ox0 - 4 + 4 j ..; the ring slot starts 4 bytes into its 16-byte unit, so that (D = 1)
   // the window column 0 (= image column ox0 - 1 + 4 tx) sits at float 4 + 4 tx of the row: 16-byte aligned ds_read_b128.
   // D = 2 windows are read as dword pairs two columns apart (no alignment to keep): column 0 = image column ox0 - 2 -> float 3
   static constexpr int XSHIFT = VEC ? 1 : 0, XWIN = VEC ? XSHIFT + 4 - D : 0;
   static constexpr int XPLANE = PH * PW;                 // 720 (800) / 648 floats per channel
   static constexpr int XSZ = 2 * XPLANE;                 // two channels per k-step
-  static constexpr int XPIECES = XSZ / 4;                // VEC: 360 (400) pieces of 16 bytes = lanes of waves 0..5 (+ 16 lanes of wave 6)
-  static constexpr int XSZP = VEC ? (D == 1 ? 1600 : 1616) : 1536;   // ring slot
+  static constexpr int XPIECES = XSZ / 4;                // VEC: 360 (400) pieces of 16 bytes = lanes of waves 0..5 (D = 2: 440 with the spare eleventh piece of each row, + 56 lanes of wave 6)
+  static constexpr int XSZP = VEC ? (D == 1 ? 1600 : 1776) : 1536;   // ring slot
   static constexpr int WSZ = 2 * 36 * BN;                // 4608 floats of transformed weights per k-step: 2 x (8 waves x 1 KB) + 2 KB
   static constexpr int VSZ = 36 * 64;                    // transformed input of a k-step: [position][channel][tile]
   static constexpr int U_SLOTS = 4, R_SLOTS = 4, V_SLOTS = 4;   // four each: the loop is unrolled by four, every ring offset an immediate
@@ -94,7 +98,7 @@ struct W44T {
   // 6, 7) the last 2 KB of the weights (+ D = 2, wave 6: the patch pieces 384..399); else 2 + 1 dword of weights + 3 dwords of patch
   static constexpr int LOADS = VEC ? 3 : 6;
   static_assert(D == 1 || (D == 2 && VEC), "the dilated form exists for Win % 4 == 0 only");
-  static_assert(WSZ == 2 * 2048 + 512 && (!VEC || (XPIECES <= 6 * 64 + 16 && XSHIFT + XPIECES * 4 <= XSZP && XSHIFT + 6 * 64 * 4 <= XSZP)),
+  static_assert(WSZ == 2 * 2048 + 512 && (!VEC || (XPIECES <= 7 * 64 && XSHIFT + XPIECES * 4 <= XSZP && XSHIFT + 6 * 64 * 4 <= XSZP)),
                 "staging plan");
   static_assert((R0 % 4) == 0 && (XSZP % 4) == 0 && (V0 % 4) == 0, "16-byte aligned LDS regions");
 };
@@ -148,14 +152,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     const int r = e - c * (T::XPLANE / 4);
     const int yy = r / (T::PW / 4), j = r - yy * (T::PW / 4);
     const int gy = oy0 - T::D + yy, gx = ox0 - 4 + 4 * j;
-    if (e < 384 && e < T::XPIECES && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) xvo = (unsigned)(c * HW + gy * a.Win + gx) * 4u;
-    if (T::D == 2 && wave == 6) {                          // pieces 384 .. 399: sixteen lanes of wave 6, a fourth instruction
+    if (e < 384 && e < T::XPIECES && j < T::PIECES_ROW && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win)
+      xvo = (unsigned)(c * HW + gy * a.Win + gx) * 4u;
+    if (T::D == 2 && wave == 6) {                          // pieces 384 .. 439: 56 lanes of wave 6, a fourth instruction
       const int e2 = 384 + lane;
       const int c2 = e2 / (T::XPLANE / 4);
       const int r2 = e2 - c2 * (T::XPLANE / 4);
       const int yy2 = r2 / (T::PW / 4), j2 = r2 - yy2 * (T::PW / 4);
       const int gy2 = oy0 - T::D + yy2, gx2 = ox0 - 4 + 4 * j2;
-      if (e2 < T::XPIECES && gy2 >= 0 && gy2 < a.Hin && gx2 >= 0 && gx2 < a.Win) xvo = (unsigned)(c2 * HW + gy2 * a.Win + gx2) * 4u;
+      if (e2 < T::XPIECES && j2 < T::PIECES_ROW && gy2 >= 0 && gy2 < a.Hin && gx2 >= 0 && gx2 < a.Win)
+        xvo = (unsigned)(c2 * HW + gy2 * a.Win + gx2) * 4u;
     }
     // The second channel of the last k-step does not exist when Cin is odd: its offset (scalar + per-lane) is >= num_records,
     // and the bounds check of a raw buffer load on gfx950 includes the scalar offset (tools/microbench/buffer_oob_probe.hip,
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     }
   };
   auto issue_r = [&](auto tail_c, auto extra_c, auto rs_c, int sr) {
-    constexpr bool TAILW = decltype(tail_c)::value;     // waves 6, 7 stage no patch pieces (but wave 6 the last sixteen at D = 2)
+    constexpr bool TAILW = decltype(tail_c)::value;     // waves 6, 7 stage no patch pieces (but wave 6 the last 56 at D = 2)
     constexpr int RS = decltype(rs_c)::value;
     const int src_ = sr < nst ? sr : nst - 1;
     if constexpr (T::VEC) {
