@@ -1310,7 +1310,7 @@ int setup_heads(fdt_model* m) {
   memset(&h, 0, sizeof(h));
   long long need = 0;
   for (size_t i = 0; i < m->ops.size(); ++i) {
-    if (m->ops[i].type != OP_HEADFIN) continue;
+    if (m->ops[i].type != OP_HEADFIN && m->ops[i].type != OP_MBOXFIN) continue;
     FDT_REQUIRE(i > 0 && m->ops[i - 1].type == OP_CONV && m->ops[i - 1].out_t == m->ops[i].in_t && h.nlev < 8, FDT_ERR_STATE,
                 "head finalize without its head conv");
     const Op& c = m->ops[i - 1];
@@ -1328,7 +1328,7 @@ int setup_heads(fdt_model* m) {
   long long off = 0;
   int l = 0, blk = 0;
   for (size_t i = 0; i < m->ops.size(); ++i) {
-    if (m->ops[i].type != OP_HEADFIN) continue;
+    if (m->ops[i].type != OP_HEADFIN && m->ops[i].type != OP_MBOXFIN) continue;
     Op& c = m->ops[i - 1];
     const Tensor& t = m->tensors[m->ops[i].in_t];
     HeadLevel& L = h.lv[l++];
@@ -1336,7 +1336,8 @@ int setup_heads(fdt_model* m) {
     L.level0 = m->ops[i].level0;
     L.p_off = m->ops[i].p_off;
     L.blk0 = blk;
-    blk += ceil_div(L.HW, 256);
+    L.anchors = m->ops[i].type == OP_MBOXFIN ? m->ops[i].anchors : 0;
+    blk += ceil_div(L.HW * (L.anchors ? L.anchors : 1), 256);
     L.ksplit = c.ca.ksplit;
     c.combine = false;
     c.head = true;
@@ -1403,14 +1404,9 @@ int run_ops(fdt_model* m, int B, hipStream_t st) {
       case OP_HEADFIN:
         if (op.last_head) FDT_TRY(launch_head_finalize_all(m->headfin, B, st));   // all levels at once (setup_heads)
         break;
-      case OP_MBOXFIN: {
-        const Tensor& in = m->tensors[op.in_t];
-        const long long hw = (long long)in.H * in.W;
-        FDT_TRY(launch_multibox_finalize(in.d, in.d + (long long)op.anchors * 4 * hw, (long long)in.C * hw, B,
-                                         op.anchors, in.H, in.W, m->P, op.p_off, m->d_loc, m->d_conf,
-                                         m->d_logits, st));
+      case OP_MBOXFIN:
+        if (op.last_head) FDT_TRY(launch_head_finalize_all(m->headfin, B, st));   // all multibox levels at once (setup_heads)
         break;
-      }
       default:
         break;
     }

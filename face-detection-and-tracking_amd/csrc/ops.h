@@ -42,6 +42,7 @@ struct HeadLevel {
   const float* src;
   const float* bias;     // [8], used when ksplit > 1
   int HW, ksplit, level0, p_off, blk0;   // blk0: first block of this level in the grid's x dimension
+  int anchors;           // 0: PyramidBox head (8 channels, max-in-out); A >= 1: FaceBoxes multibox level, channels [A*4 loc | A*2 conf]
 };
 struct HeadFinArgs {
   HeadLevel lv[8];
@@ -50,7 +51,7 @@ struct HeadFinArgs {
   float* conf;
   float* logits;
 };
-int launch_head_finalize_all(const HeadFinArgs& a, int B, hipStream_t st);
+int launch_head_finalize_all(const HeadFinArgs& a, int B, hipStream_t st);   // all levels PyramidBox heads or all multibox levels
 
 // FaceBox multibox level: loc map [A*4][H][W] and conf map [A*2][H][W] inside one per-image block of
 // `img_stride` floats -> rows of A anchors per cell (FACEBOX/multibox_layer.py:34-48), raw logits and

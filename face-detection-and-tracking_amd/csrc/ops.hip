@@ -434,6 +434,42 @@ __global__ void head_finalize_all_kernel(const HeadFinArgs a) {
   if (a.logits) reinterpret_cast<float2*>(a.logits)[row] = make_float2(neg, pos);
 }
 
+// FaceBoxes: all multibox levels in one launch (FACEBOX/multibox_layer.py:34-48); thread = cell * A + anchor of its level
+__global__ void multibox_finalize_all_kernel(const HeadFinArgs a) {
+  const int b = blockIdx.y;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (i < a.nlev && (int)blockIdx.x >= a.lv[i].blk0) l = i;
+  const HeadLevel& L = a.lv[l];
+  const int A = L.anchors, C = A * 6;
+  const int t = ((int)blockIdx.x - L.blk0) * blockDim.x + threadIdx.x;
+  if (t >= L.HW * A) return;
+  const int cell = t / A, an = t - cell * A;
+  const int ch[6] = {an * 4, an * 4 + 1, an * 4 + 2, an * 4 + 3, A * 4 + an * 2, A * 4 + an * 2 + 1};
+  float v[6];
+  if (L.ksplit > 1) {
+    const float* s = L.src + (long long)b * L.ksplit * C * L.HW + cell;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[c] = 0.0f;
+    for (int k = 0; k < L.ksplit; ++k)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v[c] += s[((long long)k * C + ch[c]) * L.HW];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[c] += L.bias ? L.bias[ch[c]] : 0.0f;
+  } else {
+    const float* h = L.src + (long long)b * C * L.HW + cell;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[c] = h[(long long)ch[c] * L.HW];
+  }
+  float pn, pp;
+  softmax2(v[4], v[5], pn, pp);
+  const long long row = (long long)b * a.P + L.p_off + t;
+  reinterpret_cast<float4*>(a.loc)[row] = make_float4(v[0], v[1], v[2], v[3]);
+  reinterpret_cast<float2*>(a.conf)[row] = make_float2(pn, pp);
+  if (a.logits) reinterpret_cast<float2*>(a.logits)[row] = make_float2(v[4], v[5]);
+}
+
 __global__ void multibox_finalize_kernel(const float* __restrict__ locmap, const float* __restrict__ confmap,
                                          long long img_stride, int A, int HW, int P, int p_off,
                                          float* __restrict__ loc, float* __restrict__ conf,
@@ -537,7 +573,10 @@ int launch_pad1(const float* in, int BC, int H, int W, float* out, hipStream_t s
 
 int launch_head_finalize_all(const HeadFinArgs& a, int B, hipStream_t st) {
   FDT_REQUIRE(a.nlev >= 1 && a.nlev <= 8 && a.nblocks >= 1 && B >= 1 && B <= 65535, FDT_ERR_ARG, "launch_head_finalize_all: bad table");
-  hipLaunchKernelGGL(head_finalize_all_kernel, dim3(a.nblocks, B), dim3(256), 0, st, a);
+  if (a.lv[0].anchors > 0)
+    hipLaunchKernelGGL(multibox_finalize_all_kernel, dim3(a.nblocks, B), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(head_finalize_all_kernel, dim3(a.nblocks, B), dim3(256), 0, st, a);
   FDT_LAUNCH_CHECK();
   return FDT_OK;
 }
