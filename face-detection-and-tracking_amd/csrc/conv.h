@@ -100,7 +100,8 @@ struct ConvArgs {
   int act;
   int ksplit;             // >= 1: split the input-channel reduction over this many workgroups
   float* ws;              // split-K workspace, B*ksplit*Cout*Hout*Wout floats (ksplit > 1, or `up` on a Winograd tile)
-  int defer_reduce;       // non-zero: the split-K slabs stay in ws for the consumer (the grouped head finalize, ops.h)
+  int defer_reduce;       // the split-K slabs stay in ws: 1 for a consumer that sums them itself (the grouped head finalize,
+                          // ops.h; bias only), 2 for a later launch_reduce_group() (any epilogue)
   unsigned* sk_count;     // non-null: in-kernel split-K combine (splitk_combine_tile below), one zeroed counter per
                           // (image, output tile): conv_sk_counters() of them; null: splitk_reduce_kernel finishes the layer
   // workgroup -> (spatial tile, output-channel tile) map (FDT_BLOCK_MAP below): map_mode is the caller's choice
@@ -297,6 +298,12 @@ __device__ __forceinline__ void splitk_combine_tile(const ConvArgs& a, int b, in
 }
 
 extern thread_local bool exp_skip_reduce;   // experiment hook, see conv.hip
+
+// The reduce passes of up to kReduceGroupMax split-K layers whose slabs were left in their (distinct) workspaces
+// (defer_reduce = 2) in ONE launch: what splitk_reduce_kernel does per layer, same order, same bits.  The caller keeps every
+// layer's inputs (slabs, residual, upsample source) untouched and its output unread until this has run.
+constexpr int kReduceGroupMax = 16;
+int launch_reduce_group(const ConvArgs* const* layers, int n, hipStream_t st);
 
 // Counters an in-kernel split-K combine needs (ConvArgs.sk_count): one per image and output tile.
 long long conv_sk_counters(ConvKind kind, ConvTile tile, const ConvArgs& a);

@@ -94,6 +94,71 @@ __global__ void splitk_reduce_kernel(const ConvArgs a) {
 thread_local bool exp_skip_reduce = false;
 namespace {
 
+struct ReduceGroup {
+  ConvArgs a[kReduceGroupMax];
+  int blk0[kReduceGroupMax + 1];   // first block of each layer in the grid
+  int n;
+};
+static_assert(sizeof(ReduceGroup) <= 3584, "kernel arguments");
+
+// One thread per 4 consecutive pixels of a layer with Wout % 4 == 0, else per pixel: splitk_reduce_kernel<4 / 1>, layer by
+// table lookup.
+__global__ void splitk_reduce_group_kernel(const ReduceGroup g) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < kReduceGroupMax; ++i)
+    if (i < g.n && (int)blockIdx.x >= g.blk0[i]) l = i;
+  const ConvArgs& a = g.a[l];
+  const int HWout = a.Hout * a.Wout;
+  const bool vec = (a.Wout & 3) == 0;
+  const int HWv = vec ? HWout / 4 : HWout;
+  const long long total = (long long)a.B * a.Cout * HWv;
+  const long long t = (long long)((int)blockIdx.x - g.blk0[l]) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int pix = (int)(t % HWv) * (vec ? 4 : 1);
+  const int co = (int)((t / HWv) % a.Cout);
+  const int b = (int)(t / ((long long)HWv * a.Cout));
+  float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const float* ws = a.ws + ((long long)b * a.ksplit * a.Cout + co) * HWout + pix;
+  const long long kstride = (long long)a.Cout * HWout;
+  for (int k = 0; k < a.ksplit; ++k) {
+    if (vec) {
+      const float4 p = *reinterpret_cast<const float4*>(ws + k * kstride);
+      v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+    } else {
+      v[0] += ws[k * kstride];
+    }
+  }
+  const float bv = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] += bv;
+  if (a.up) {
+    const int oy = pix / a.Wout;
+    const float* u = a.up + ((long long)b * a.Cout + co) * a.up_h * a.up_w;
+    if (vec) add_upsampled_x2<4>(u, a.up_h, a.up_w, oy, pix - oy * a.Wout, v);
+    else add_upsampled_x2<1>(u, a.up_h, a.up_w, oy, pix - oy * a.Wout, v);
+  }
+  const long long ooff = ((long long)b * a.out_ctot + a.out_coff + co) * HWout + pix;
+  if (a.res) {
+    const float* r = a.res + ((long long)b * a.res_ctot + a.res_coff + co) * HWout + pix;
+    if (vec) {
+      const float4 p = *reinterpret_cast<const float4*>(r);
+      v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+    } else {
+      v[0] += r[0];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (a.act == ACT_RELU) v[e] = fmaxf(v[e], 0.0f);
+    else if (a.act == ACT_RELU6) v[e] = fminf(fmaxf(v[e], 0.0f), 6.0f);
+  }
+  if (vec)
+    *reinterpret_cast<float4*>(a.out + ooff) = make_float4(v[0], v[1], v[2], v[3]);
+  else
+    a.out[ooff] = v[0];
+}
+
 struct Table {
   KernelEntry e[CONV_KIND_COUNT][CONV_TILE_COUNT];
   // per device: the attribute is per (function, device).  Handles on different host threads race here only to set
@@ -236,6 +301,30 @@ long long conv_ws_floats(const ConvArgs& a) {
   return a.ksplit > 1 ? (long long)a.B * a.ksplit * a.Cout * a.Hout * a.Wout : 0;
 }
 
+int launch_reduce_group(const ConvArgs* const* layers, int n, hipStream_t st) {
+  FDT_REQUIRE(layers && n >= 1, FDT_ERR_ARG, "launch_reduce_group: nothing to reduce");
+  if (exp_skip_reduce) return FDT_OK;
+  for (int i0 = 0; i0 < n; i0 += kReduceGroupMax) {
+    ReduceGroup g;
+    memset(&g, 0, sizeof(g));
+    g.n = std::min(kReduceGroupMax, n - i0);
+    long long blk = 0;
+    for (int i = 0; i < g.n; ++i) {
+      const ConvArgs& a = *layers[i0 + i];
+      FDT_REQUIRE(a.ksplit > 1 && a.ws && a.out && a.defer_reduce == 2, FDT_ERR_ARG, "launch_reduce_group: layer %d has no deferred slabs", i0 + i);
+      g.a[i] = a;
+      g.blk0[i] = (int)blk;
+      const long long hwv = (a.Wout & 3) == 0 ? (long long)a.Hout * a.Wout / 4 : (long long)a.Hout * a.Wout;
+      blk += ceil_div_ll((long long)a.B * a.Cout * hwv, 256);
+      FDT_REQUIRE(blk <= 0x7fffffffll, FDT_ERR_ARG, "launch_reduce_group: grid too large");
+    }
+    g.blk0[g.n] = (int)blk;
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((unsigned)blk), dim3(256), 0, st, g);
+    FDT_LAUNCH_CHECK();
+  }
+  return FDT_OK;
+}
+
 long long conv_sk_counters(ConvKind kind, ConvTile tile, const ConvArgs& a) {
   (void)kind;
   return (long long)a.B * ceil_div(a.Hout, tile_th(tile)) * ceil_div(a.Wout, tile_tw(tile)) * ceil_div(a.Cout, tile_bn(tile));
@@ -291,8 +380,9 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
   FDT_REQUIRE(!a.ws || a.ksplit > 1, FDT_ERR_ARG, "launch_conv: unexpected workspace");
   // in-kernel combine (conv.h, splitk_combine_tile): 16-byte slab rows, one image's slabs behind one buffer descriptor
   FDT_REQUIRE(!(a.sk_count && a.defer_reduce), FDT_ERR_ARG, "launch_conv: in-kernel combine and deferred reduce exclude each other");
-  FDT_REQUIRE(!a.defer_reduce || (a.ksplit > 1 && !a.res && !a.up && a.act == ACT_NONE), FDT_ERR_ARG,
-              "launch_conv: a deferred reduce carries bias only (the head convs)");
+  FDT_REQUIRE(!a.defer_reduce || a.ksplit > 1, FDT_ERR_ARG, "launch_conv: nothing to defer without split-K");
+  FDT_REQUIRE(a.defer_reduce != 1 || (!a.res && !a.up && a.act == ACT_NONE), FDT_ERR_ARG,
+              "launch_conv: a consumer that sums the slabs itself adds the bias only (the head convs)");
   FDT_REQUIRE(!a.sk_count || conv_combine_supported(kind, tile, a), FDT_ERR_ARG,
               "launch_conv: in-kernel split-K combine needs ksplit > 1, Wout %% 4 == 0 and < 2 GB of slabs per image");
   FDT_REQUIRE(!a.up || conv_base_kind(kind) == CONV_1x1_S1, FDT_ERR_ARG,

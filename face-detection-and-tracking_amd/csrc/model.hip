@@ -60,6 +60,9 @@ struct Op {
   bool combine = false;   // split-K partial sums are combined inside the conv kernel (ConvArgs.sk_count)
   bool last_head = false; // OP_HEADFIN: the one that launches the grouped finalize of all levels
   bool head = false;      // OP_CONV: a head conv (its split-K slabs go to the grouped finalize, no reduce pass)
+  bool lazy = false;      // OP_CONV: the reduce pass waits, with others, for the first op that needs its result (plan_reduces)
+  bool flush_before = false;   // any op: the pending reduce passes run (as one launch) before this op
+  long long ws_off = 0;   // lazy: this layer's slabs inside the shared workspace
 };
 
 struct DevW {
@@ -175,6 +178,7 @@ struct fdt_model {
   double flops_per_frame = 0;
   long long ws_floats = 0;   // split-K / fused-upsample workspace shared by all layers
   float* d_convws = nullptr;
+  bool flush_at_end = false;     // reduce passes still pending behind the last op (plan_reduces)
   float* d_headws = nullptr;     // split-K slabs of the head convs, one region per level (they live until the grouped finalize)
   long long headws_floats = 0;
   HeadFinArgs headfin;           // table of the grouped head finalize (ops.h); nlev == 0: no PyramidBox heads
@@ -1200,6 +1204,7 @@ int make_priors(fdt_model* m, int H, int W) {
 
 // (Re)build the execution plan for a batch shape.
 int setup_heads(fdt_model* m);
+int plan_reduces(fdt_model* m, int B);
 
 int make_plan(fdt_model* m, int B, int H, int W) {
   if (m->pB == B && m->pH == H && m->pW == W && !m->ops.empty()) {
@@ -1257,6 +1262,7 @@ int make_plan(fdt_model* m, int B, int H, int W) {
       if (op.type == OP_CONV && op.combine) op.ca.sk_count = m->d_skcnt;
   }
   FDT_TRY(setup_heads(m));
+  FDT_TRY(plan_reduces(m, B));
   FDT_TRY(make_priors(m, H, W));
   m->pB = B;
   m->pH = H;
@@ -1363,17 +1369,122 @@ int setup_heads(fdt_model* m) {
   return FDT_OK;
 }
 
+// Lazy reduce passes.  A split-K conv leaves its slabs in a region of the workspace of its own and its reduce pass (bias,
+// upsample-add, residual, activation, the write into its slice of the output tensor) waits until the first later op that touches
+// what it writes or rewrites what it reads; everything pending at that point runs as ONE launch (launch_reduce_group).  A
+// dependent launch costs ~4.5 us of the multi-stream step whatever it does (docs/EXPERIMENTS.md R3-4), and the three branch
+// outputs of every SSH module are read by nobody before the heads: a Res50 frame at 1024^2 makes 48 -> 3x fewer reduce launches.
+// Byte ranges decide, not tensor names: conservative (whole tensors) except for convs writing disjoint channel slices of one
+// tensor at batch 1 (the concatenated SSH outputs).  Same kernels' arithmetic, same order: same bits.
+struct ByteRange {
+  const char* lo;
+  const char* hi;
+  bool overlaps(const ByteRange& o) const { return lo && o.lo && lo < o.hi && o.lo < hi; }
+};
+ByteRange tensor_range(const fdt_model* m, int t, int B) {
+  if (t < 0) return {nullptr, nullptr};
+  const Tensor& x = m->tensors[t];
+  return {(const char*)x.d, (const char*)x.d + (size_t)B * x.C * x.H * x.W * 4};
+}
+struct OpAccess {
+  ByteRange rd[3], wr;   // wr of a conv: its channel slice when the batch is 1 (contiguous), else the whole tensor
+};
+OpAccess op_access(const fdt_model* m, const Op& op, int B) {
+  OpAccess x{{{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}}, {nullptr, nullptr}};
+  if (op.type == OP_CONV) {
+    const ConvArgs& a = op.ca;
+    const size_t hwo = (size_t)a.Hout * a.Wout;
+    x.rd[0] = {(const char*)a.in, (const char*)a.in + (size_t)a.B * a.Cin * a.Hin * a.Win * 4};
+    if (a.res) x.rd[1] = {(const char*)a.res, (const char*)a.res + (size_t)a.B * a.res_ctot * hwo * 4};
+    if (a.up) x.rd[2] = {(const char*)a.up, (const char*)a.up + (size_t)a.B * a.Cout * a.up_h * a.up_w * 4};
+    if (a.B == 1)
+      x.wr = {(const char*)(a.out + (size_t)a.out_coff * hwo), (const char*)(a.out + (size_t)(a.out_coff + a.Cout) * hwo)};
+    else
+      x.wr = {(const char*)a.out, (const char*)a.out + (size_t)a.B * a.out_ctot * hwo * 4};
+  } else {
+    x.rd[0] = tensor_range(m, op.in_t, B);
+    x.rd[1] = tensor_range(m, op.in2_t, B);
+    x.wr = tensor_range(m, op.out_t, B);
+  }
+  return x;
+}
+
+int plan_reduces(fdt_model* m, int B) {
+  static const bool off = getenv("FDT_LAZY_REDUCE") && atoi(getenv("FDT_LAZY_REDUCE")) == 0;   // test hook: a reduce pass per layer
+  std::vector<OpAccess> pend;          // accesses of the layers whose reduce pass is pending
+  long long epoch = 0, need = 0;
+  for (auto& op : m->ops) {
+    op.flush_before = false;
+    op.lazy = false;
+    op.ws_off = 0;
+    if (op.type == OP_CONV && !op.head) op.ca.defer_reduce = 0;
+  }
+  for (auto& op : m->ops) {
+    const OpAccess x = op_access(m, op, B);
+    bool conflict = false;
+    for (const auto& p : pend) {
+      for (const auto& r : x.rd) conflict |= r.overlaps(p.wr);                    // reads what a pending pass will write
+      conflict |= x.wr.overlaps(p.wr);                                              // writes it
+      for (const auto& r : p.rd) conflict |= x.wr.overlaps(r);                      // rewrites what a pending pass will read
+    }
+    // the heads' finalize and Detect read through tables / other paths: nothing may be pending behind them
+    if (op.type == OP_HEADFIN || op.type == OP_MBOXFIN) conflict |= !pend.empty();
+    if (conflict) {
+      op.flush_before = true;
+      pend.clear();
+      epoch = 0;
+    }
+    if (op.type == OP_CONV && op.ca.ksplit > 1 && !op.head && !op.combine && !off) {
+      op.lazy = true;
+      op.ws_off = epoch;
+      op.ca.defer_reduce = 2;
+      epoch += conv_ws_floats(op.ca);
+      need = std::max(need, epoch);
+      OpAccess px = x;
+      px.rd[0] = {nullptr, nullptr};   // the pending PASS reads the slabs, the residual and the upsample source, not the conv's input
+      pend.push_back(px);
+    } else if (op.type == OP_CONV && op.ca.ksplit > 1) {
+      need = std::max(need, epoch + conv_ws_floats(op.ca));   // its slabs live behind the pending ones for the length of the op
+      op.ws_off = epoch;
+    }
+  }
+  m->flush_at_end = !pend.empty();
+  if (need > m->ws_floats || (need && !m->d_convws)) {
+    float* p = nullptr;
+    FDT_HIP(hipMalloc((void**)&p, (size_t)need * 4));
+    m->plan_allocs.push_back(p);
+    m->d_convws = p;
+    m->ws_floats = need;
+  }
+  for (auto& op : m->ops)
+    if (op.type == OP_CONV && !op.head) op.ca.ws = op.ca.ksplit > 1 ? m->d_convws + op.ws_off : nullptr;
+  return FDT_OK;
+}
+
 int run_ops(fdt_model* m, int B, hipStream_t st) {
   const bool prof = m->profile;
   if (prof) FDT_TRY(ensure_profile_events(m));
+  const ConvArgs* pending[64];
+  int npend = 0;
+  auto flush = [&]() -> int {
+    if (npend) FDT_TRY(launch_reduce_group(pending, npend, st));
+    npend = 0;
+    return FDT_OK;
+  };
   for (size_t i = 0; i < m->ops.size(); ++i) {
     const Op& op = m->ops[i];
+    if (op.flush_before) FDT_TRY(flush());
     if (prof) FDT_HIP(hipEventRecord(m->ev[i], st));
     if (m->passes > 0 && op_skipped(op.name)) continue;   // first pass complete: later ones read its (stale) maps
     exp_skip_reduce = m->passes > 0 && op_skipped("@reduce");
     switch (op.type) {
       case OP_CONV:
         FDT_TRY(launch_conv(op.kind, op.tile, op.ca, st, m->device));
+        if (op.lazy) {
+          if (npend == 64) FDT_TRY(flush());
+          pending[npend++] = &op.ca;
+          if (prof) FDT_TRY(flush());   // per-op timing: every layer with its own reduce pass, as before
+        }
         break;
       case OP_POOL: {
         const Tensor& in = m->tensors[op.in_t];
@@ -1411,6 +1522,7 @@ int run_ops(fdt_model* m, int B, hipStream_t st) {
         break;
     }
   }
+  FDT_TRY(flush());
   if (prof) FDT_HIP(hipEventRecord(m->ev[m->ops.size()], st));
   exp_skip_reduce = false;
   ++m->passes;
@@ -2178,6 +2290,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   for (auto& op : m->ops)
     if (op.type == OP_CONV) op.ca.sk_count = op.combine ? m->d_skcnt : nullptr;
   FDT_TRY(setup_heads(m));   // the head convs' own slab regions and the grouped finalize table follow the new splits
+  FDT_TRY(plan_reduces(m, m->pB));
   m->drop_graphs();   // captured forwards bake in the old kernel choice
   return FDT_OK;
 }

@@ -429,6 +429,35 @@ def test_plan_with_in_kernel_split_k_combine_gives_the_same_bits(res50, synth):
     res50.import_plan(plan)
 
 
+@pytest.mark.parametrize("arch", ["res50", "try3"])
+def test_lazy_reduce_passes_read_nothing_stale(arch, res50, try3, synth):
+    """csrc/model.hip plan_reduces: split-K layers leave their slabs in the workspace and their reduce passes run, grouped, in
+    front of the first op that needs one of them.  A missed dependency would make that op read what the PREVIOUS forward left
+    in the tensor -- invisible when the same frame is run twice.  So: frame A then frame B on one handle against frame B on a
+    clone whose activations have never been written; bit for bit, detections and both head tensors."""
+    net = res50 if arch == "res50" else try3
+    H, W = 480, 640
+    PB = M("layers").PriorBoxLayer
+    net.priorbox = PB(W, H) if arch == "res50" else PB(W, H, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256))
+    net.firstTime = True
+    net.detect = M("layers").Detect(2, 0, 750, 0.05, 0.3)
+    plan = net.tuned_plan_text(H, W, 1)
+    if plan is not None:
+        net.import_plan(plan)
+    a = synth.make_frames(1, H, W, seed=5)[0]
+    b = synth.make_frames(1, H, W, seed=6)[0]
+    net(a)
+    y1 = net(b).numpy()
+    loc1, conf1 = net.get_tensor("loc").copy(), net.get_tensor("conf").copy()
+    fresh = net.clone()
+    y2 = fresh(b).numpy()
+    assert np.array_equal(y1, y2)
+    assert np.array_equal(fresh.get_tensor("loc"), loc1) and np.array_equal(fresh.get_tensor("conf"), conf1)
+    assert not np.array_equal(net(a).numpy(), y1)                  # (the two frames do differ)
+    lazy = [ln for ln in net.export_plan().splitlines() if len(ln.split()) >= 5 and ln.split()[0] != "shape" and int(ln.split()[3]) > 1]
+    assert len(lazy) >= 10                                         # there are split layers to be lazy about
+
+
 def test_try3_1024_batch8_vs_reference_fixture(try3, synth):
     """Config 3 of BASELINE.json: ONE batched forward of eight 1024x1024 frames (the depthwise / batched conv plan that
     bench.py --arch try3 --batch 8 times) against the reference's own batch-8 forward, per image."""
