@@ -156,6 +156,15 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
             "by_op": [{"op": r[0], "ms": round(r[1], 4), "GBps": round(gbs(r[2], r[1]), 1),
                        "algorithmic_tflops": round(r[3] / (r[1] * 1e-3) / 1e12, 1) if r[1] > 0 else 0.0}
                       for r in sorted(rows, key=lambda r: -r[1])[:8]],
+            # the two layers with real matrix work, priced as what they are: f32 MFMA work.  conv1 pads K = 3 x 49 = 147 to 196
+            # (two-channel stages) and N = 24 to 32 output channels; conv2 (48 -> 64, 5x5) pads nothing
+            "mfma_side": {"bound": "mfma", "peak": 157.3, "unit": "TFLOP/s",
+                          "kernels": [{"op": r[0].split("#")[0], "ms": round(r[1], 4),
+                                       "algorithmic_tflops": round(r[3] / (r[1] * 1e-3) / 1e12, 1),
+                                       "executed_tflops": round(r[3] * pad / (r[1] * 1e-3) / 1e12, 1),
+                                       "frac": round(r[3] * pad / (r[1] * 1e-3) / 1e12 / 157.3, 4)}
+                                      for r in rows for nm0, pad in (("conv1", 196.0 / 147.0 * 32.0 / 24.0), ("conv2", 1.0))
+                                      if r[0].split("#")[0] == nm0 and r[1] > 0]},
             "note": "bytes = un-fused algorithmic lower bound (each op reads its inputs and writes its output once, f32; "
                     "weights once).  The whole net is 1.87 GFLOP and 77 MB per frame over 40 launches: launch-latency bound, "
                     "which is why several batches are kept in flight; conv1 (3 -> 24 channels, K = 147 padded to 196, N = 24 "
