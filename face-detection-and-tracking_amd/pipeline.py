@@ -128,3 +128,6 @@ class DetectTrackPipeline:
             if hasattr(fp, "close"):
                 fp.close()
         self.tracker.close()
+        for sp in getattr(self, "_raw_streams", []):   # CU-partitioned detector streams (FDT_CU_PARTS): nothing is in flight any more
+            _lib.check(_lib.lib().fdt_stream_destroy(sp))
+        self._raw_streams = []

@@ -168,6 +168,29 @@ def test_pipelined_streams_match_sequential_and_oracle(res50, synth, inflight, m
     pipe.close()
 
 
+def test_cu_partitioned_streams_give_the_same_tracks(res50, synth, monkeypatch):
+    """fdt_stream_create_partition (include/fdt.h): detector streams confined to halves of every XCD's compute units.  A speed
+    experiment (slower: docs/EXPERIMENTS.md R3-6) -- the placement must not change a single bit."""
+    H, W, N = 128, 160, 14
+    dev = torch.device("cuda", 0)
+    res50.priorbox = M("layers").PriorBoxLayer(W, H); res50.firstTime = True
+    res50.detect = M("layers").Detect(2, 0, 750, 0.05, 0.35)
+    frames_d = torch.from_numpy(moving_frames(synth, N, H, W, seed=9)).to(dev)
+    out = []
+    for parts in ("1", "2"):
+        monkeypatch.setenv("FDT_CU_PARTS", parts)
+        pipe = M("pipeline").DetectTrackPipeline(res50, H, W, dev, inflight=4, log_frames=8)
+        for i in range(N):
+            pipe.step(i, frames_d[i:i + 1])
+        out.append((tracks_key(pipe.finish()), pipe.record_of_slot((N - 1) % pipe.NF)[0].copy()))
+        pipe.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    L = M("_lib")
+    st = ctypes.c_void_p()
+    assert L.lib().fdt_stream_create_partition(4, 4, ctypes.byref(st)) != 0     # partition index out of range
+    assert L.lib().fdt_stream_create_partition(0, 3, ctypes.byref(st)) != 0     # 1, 2 or 4 partitions
+
+
 def test_step_dev_multi_equals_sequential_steps():
     """G = 8 gathered records in one launch == 8 launches == the oracle (random records incl. empty frames)."""
     TOP_K, G, STEPS = 40, 8, 9
