@@ -74,7 +74,7 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
     frames_d = torch.from_numpy(frames_h).to(dev)
     L = lib.lib()
     res = net.detect_frames(frames_h)          # plan (+ the GPU results of these frames for the parity leg)
-    net.autotune(3)
+    net.autotune(args.tune_iters)
     # `inflight` batches in flight, each on its own handle (fdt_model_clone: shared weights) and stream: the net is a
     # chain of ~40 short launches, so consecutive batches overlap almost completely
     NF = args.inflight if args.inflight > 0 else 4
@@ -370,6 +370,7 @@ def main():
                     help="1: use the committed tuned plan for this shape if there is one, else autotune (tile, split-K) "
                          "per conv layer at start-up; 2: always autotune; 0: analytic model only")
     ap.add_argument("--save-plan", type=int, default=0, help="write the autotuned plan under tuned/")
+    ap.add_argument("--tune-iters", type=int, default=3, help="timed launches per candidate of the autotuner (the minimum counts)")
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per GPU: consecutive batch-1 steps overlap on separate HIP streams "
                          "(detection of frame i+1 runs beside the tail / tracker step of frame i); default 8; FaceBoxes 4")
@@ -441,7 +442,7 @@ def main():
     elif args.autotune:
         # plan-time measurement of every (tile, split-K) variant per layer; outside the timed region
         net(synth.make_frames(B, H, W, seed=99) if B > 1 else synth.make_frames(1, H, W, seed=99)[0])
-        net.autotune(3)
+        net.autotune(args.tune_iters)
         plan_text = net.export_plan()
         plan_src = "autotuned at start-up"
         if args.save_plan and rank == 0:
