@@ -12,14 +12,20 @@
 //    grid, and cannot form its own B operands from the raw window: the input transform runs once per (tile, channel) --
 //    six waves each produce one ROW of B^T d B for all 32 tiles x 2 channels of a k-step (lane = (channel, tile), exactly the
 //    MFMA B-operand layout) and write it to a V buffer in LDS; all eight waves then read A (weights U) and B (V) from LDS.
-//  * Everything is pipelined by k-step (two input channels = one MFMA k-depth): at the barrier of k-step s the weights U(s),
-//    U(s+1) and the raw patch R(s+2) have landed (LDS-DMA rings of 4 / 3 slots, issued three / four k-steps ahead, counted
-//    vmcnt), V(s), V(s+1) are written, and the MFMA operands of k-step s already sit in registers (prefetched during k-step
-//    s-1) -- so nothing waits for LDS behind the barrier; during the nine MFMAs of k-step s a wave transforms its row for
-//    k-step s+2 and prefetches the operands of s+1.
-//  * The operand stream is 1.9x the F(2x2) kernel's per MFMA cycle (18 KB of weights + 5 KB of patch per 1152 matrix-pipe
-//    cycles of a SIMD pair): tools/microbench/ldsdma_feed.hip measured that the L2 -> LDS path sustains it (35 GB/s per CU
-//    beside 102-108 TFLOP/s of LDS-fed MFMAs).
+//  * Everything is pipelined by k-step (two input channels = one MFMA k-depth) in SUPER-STEPS of two k-steps between two
+//    barriers: at the barrier the operands of k-step s sit in registers, the weights U(s+1), U(s+2) and the raw patches
+//    R(s+3), R(s+4) have landed (LDS-DMA rings of four slots each, one vmcnt(0) per super-step = two k-steps of flight) and
+//    V(s+1), V(s+2) are written; each half runs its nine MFMAs while it reads a window, transforms it into V two k-steps
+//    ahead, prefetches the next operands and issues the LDS-DMA of two / four k-steps ahead (super_step below).
+//  * The matrix pipe and the vector ALU of a SIMD do not co-execute on this chip (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so the
+//    loop carries no vector address arithmetic: every LDS offset is an immediate (rings of four slots, loop unrolled by
+//    four k-steps), both operand streams are buffer loads (a per-lane offset that never changes + a scalar offset per
+//    k-step; padding, out-of-image pieces and the channel past an odd Cin are out-of-range lanes: zeros), the transform is
+//    packed (v_pk_fma_f32).  Dilation 2 (W44T<true, 2>): tiles = parity sub-lattices of 8x8-pixel cells, row pitch 44
+//    floats so that the dword-pair window reads hit 32 different banks.
+//  * The operand stream is 1.9x the F(2x2) kernel's per MFMA cycle (18 KB of weights + 6 KB of patch per 1152 matrix-pipe
+//    cycles of a SIMD pair) and a k-step moves ~100 KB through LDS: tools/microbench/ldsdma_feed.hip puts feed + MFMAs at
+//    0.70-0.74 us per k-step and CU, the kernel runs 0.61 above its fixed part (docs/EXPERIMENTS.md R3-1).
 //  * Output transform: a wave folds its nine positions into two 4-vectors per accumulator element (the rows of M A it
 //    touches), the four position groups meet through LDS (two rounds of 128 KB), and every wave finishes whole 4x4 tiles of
 //    a quarter of the channels: bias / residual / ReLU and 16-byte row stores.
