@@ -337,13 +337,17 @@ __global__ __launch_bounds__(64) void scan_kernel(
     unsigned long long keptbits = 0;
     const int rows = (m - c * 64) < 64 ? (m - c * 64) : 64;
     int kt = kept_total;
-    for (int r = 0; r < rows; ++r) {
-      unsigned long long d = __shfl(diag, r, 64);
-      if (!((rem >> r) & 1ull) && kt < limit) {
-        keptbits |= (1ull << r);
-        ++kt;
-        rem |= d;
-      }
+    // Only the rows still alive are visited, in order: the next kept row is the lowest alive bit, its diagonal word removes
+    // rows behind it.  Same decisions as testing the 64 rows one by one (which made dense frames -- thousands of candidates,
+    // a handful kept per chunk -- pay 64 cross-lane reads per chunk); everything here is wave-uniform.
+    unsigned long long alive = ~rem & (rows == 64 ? ~0ull : ((1ull << rows) - 1ull));
+    while (alive && kt < limit) {
+      const int r = __ffsll((long long)alive) - 1;
+      keptbits |= (1ull << r);
+      ++kt;
+      rem |= __shfl(diag, r, 64);
+      alive &= ~rem;                                   // suppressed by a kept row
+      alive &= ~((2ull << r) - 1ull);                  // rows <= r are decided (r = 63: the mask is all ones)
     }
     // emit this chunk's kept rows in rank order
     if ((keptbits >> lane) & 1ull) {
