@@ -53,8 +53,11 @@ class DetectTrackPipeline:
                 self._raw_streams.append(sp)
             self.det_streams = [torch.cuda.ExternalStream(sp.value, device=device) for sp in self._raw_streams]
         else:
-            self.det_streams = [torch.cuda.Stream(device=device) for _ in range(self.NF)]
-        self.trk_stream = torch.cuda.Stream(device=device)
+            alt = int(os.environ.get("FDT_DET_PRIO_ALT", "0"))     # every alt-th detector stream at high priority
+            self.det_streams = [torch.cuda.Stream(device=device, priority=(-1 if alt and k % alt == 0 else 0))
+                                for k in range(self.NF)]
+        # experiment hooks (docs/EXPERIMENTS.md R3-10): a priority of its own moves a stream to another pool of hardware queues
+        self.trk_stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("FDT_TRK_PRIO", "0")))
         self.sp_det = [ctypes.c_void_p(s.cuda_stream) for s in self.det_streams]
         self.sp_trk = ctypes.c_void_p(self.trk_stream.cuda_stream)
         assert all(p.value for p in self.sp_det) and self.sp_trk.value, "need real stream handles"
@@ -102,7 +105,9 @@ class DetectTrackPipeline:
             # the one exchange step of the path: fixed-size per-frame box lists, rank order == frame order
             g = fp.exchange(self.sp_trk)
             n = self.world * self.B
-            if self.multi_step:
+            if os.environ.get("FDT_EXP_NO_TRACK") == "1":       # experiment: what does the association cost the step?
+                pass
+            elif self.multi_step:
                 self.tracker.step_dev_multi(ctypes.c_void_p(g.data_ptr()), n, self.REC, 2, self.top_k, self.W, self.H,
                                             self.score_thresh, self.sp_trk)
             else:
