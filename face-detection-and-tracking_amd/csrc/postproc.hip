@@ -372,7 +372,10 @@ __global__ __launch_bounds__(64) void scan_kernel(
     if (kept_total >= limit) break;
     // fold the kept rows into the removed bitmap of the later chunks
     // (eight rows per round trip: one dependent load per kept row made this loop the whole kernel's time)
-    for (int w = c + 1 + lane; w < nw; w += 64) {
+#ifndef FDT_SCAN_EXP
+#define FDT_SCAN_EXP 0   // timing experiment: 1 = the kept rows are not folded into the later words (wrong results)
+#endif
+    for (int w = c + 1 + lane; w < (FDT_SCAN_EXP == 1 ? 0 : nw); w += 64) {
       unsigned long long acc = 0;
       unsigned long long kb = keptbits;
       while (kb) {
