@@ -321,31 +321,69 @@ def run_with_timeout(fn, seconds):
     return (not t.is_alive()), box.get("r")
 
 
-def self_launch(args):
+def self_launch(args, script=None, argv=None):
     """`python bench.py --gpus N` outside a launcher: start the N ranks as children (before anything touches the GPU),
-    relay rank 0's JSON line and exit with the launcher's code."""
+    relay rank 0's JSON line and exit with the launcher's code.
+
+    A rank that had to abandon a thread inside the C-ABI RCCL communicator leaves through os._exit(3) (end of main()), but
+    the launcher does not hand that code on: `python -m torch.distributed.run` raises ChildFailedError and exits 1 whatever
+    the rank's code was.  The wedge is therefore signalled OUT OF BAND: such a rank creates the file named by
+    FDT_BENCH_WEDGE_MARKER before it exits, and the ranks are started once more -- fresh processes, the torch.distributed
+    form of the exchange -- when the launcher failed AND the marker exists.  Only the second run's line is printed.
+    `script` / `argv` exist for tests/test_bench_launch.py (a stand-in rank program under the real launcher)."""
     import socket
     import subprocess
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # rank 0's line is captured, not inherited: should the C-ABI RCCL communicator wedge (exit code 3, see the end of
-    # main()), the ranks are started once more with the torch.distributed form of the exchange and only THAT line is printed
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
-    if r.returncode == 3 and env.get("FDT_BENCH_EXCHANGE", "rccl-cabi") == "rccl-cabi":
-        print("bench.py: the RCCL communicator wedged; re-running the ranks with FDT_BENCH_EXCHANGE=torch", file=sys.stderr)
-        env["FDT_BENCH_EXCHANGE"] = "torch"
+    import tempfile
+
+    def free_port():
         with socket.socket() as so:
             so.bind(("127.0.0.1", 0))
-            cmd[cmd.index("--master-port") + 1] = str(so.getsockname()[1])
+            return so.getsockname()[1]
+
+    script = script or os.path.abspath(__file__)
+    argv = list(sys.argv[1:] if argv is None else argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    mdir = tempfile.mkdtemp(prefix="fdt_bench_")
+    marker = os.path.join(mdir, "rccl_wedged")
+    env["FDT_BENCH_WEDGE_MARKER"] = marker
+    try:
+        # rank 0's line is captured, not inherited: after a wedge only the line of the second run may reach stdout
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+        if r.returncode != 0 and os.path.exists(marker) and env.get("FDT_BENCH_EXCHANGE", "rccl-cabi") == "rccl-cabi":
+            print("bench.py: the RCCL communicator wedged (launcher exit code %d, marker present); re-running the ranks "
+                  "with FDT_BENCH_EXCHANGE=torch" % r.returncode, file=sys.stderr)
+            os.unlink(marker)
+            env["FDT_BENCH_EXCHANGE"] = "torch"
+            cmd[cmd.index("--master-port") + 1] = str(free_port())
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    finally:
+        try:
+            if os.path.exists(marker):
+                os.unlink(marker)
+            os.rmdir(mdir)
+        except OSError:
+            pass
     sys.stdout.write(r.stdout.decode(errors="replace"))
     sys.stdout.flush()
     return r.returncode
+
+
+def leave_wedged(code=3):
+    """Exit of a rank that has a thread stuck inside the C-ABI collective: no destructors behind it, and the wedge is
+    signalled through the marker file self_launch() watches (the launcher turns every failing rank code into 1)."""
+    m = os.environ.get("FDT_BENCH_WEDGE_MARKER")
+    if m:
+        try:
+            with open(m, "w") as f:
+                f.write("rank %s\n" % os.environ.get("RANK", "?"))
+        except OSError:
+            pass
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(code)
 
 
 def main():
@@ -494,8 +532,7 @@ def main():
         done, agreed = run_with_timeout(agree, limit)
         if not done or isinstance(agreed, Exception):
             print("bench.py: ranks could not agree on the exchange transport (%r): giving up" % (agreed,), file=sys.stderr)
-            sys.stderr.flush()
-            os._exit(4)
+            leave_wedged(4)      # marker + exit: `bench.py --gpus N` starts the ranks again on the torch exchange
         if agreed == 0:
             if comm is not None:
                 lib.lib().fdt_comm_destroy(comm)
@@ -847,9 +884,7 @@ def main():
             # A thread is still inside the C-ABI collective: do not run destructors behind it.  The JSON line above is a
             # valid measurement of the torch.distributed form of the exchange (config.exchange_note says so), but the run
             # is NOT a clean RCCL-capable run and must not look like one by its exit code.
-            sys.stdout.flush()
-            sys.stderr.flush()
-            os._exit(3)
+            leave_wedged(3)
         dist.destroy_process_group()
 
 
