@@ -80,7 +80,8 @@ __device__ long long g_trk_time[8];
 #define TT(i)
 #endif
 constexpr int TRK_THREADS = 1024;             // one workgroup of 16 waves per frame
-constexpr int TRK_LDS_PER_SLOT = 88;          // bytes of LDS per detection/track slot (see the carve-up below)
+constexpr int TRK_CAND = 6;                   // candidate detections (IoU > sigma_iou) kept per track; more -> exact fallback
+constexpr int TRK_LDS_PER_SLOT = 88 + 2 * TRK_CAND;   // bytes of LDS per detection/track slot (see the carve-up below)
 
 // G consecutive frames in one launch <<<1, TRK_THREADS, M * TRK_LDS_PER_SLOT>>> (G = 1 for the single-frame entry
 // points; G = world size after the all-gather of a frame-parallel step: one launch instead of G).  `dets_in`
@@ -89,11 +90,19 @@ constexpr int TRK_LDS_PER_SLOT = 88;          // bytes of LDS per detection/trac
 // frame; a frame's writes are ordered before the next frame's reads by the workgroup barrier (one workgroup == one
 // CU, whose L1 all its waves share), so the result is bit-identical to G single-frame launches.
 //
-// The greedy loop of iouTracke_cal.py:129-148 is sequential over the tracks, but its expensive part is not:
-//   phase 1 (16 waves, one track per wave at a time): arg-max of the track's IoU row over ALL detections;
-//   phase 2 (wave 0, in track order): if that detection is still free it is also the arg-max over the
-//     remaining list (deleting other rows cannot change the first maximum), so the track takes it with a
-//     few LDS reads; only when an earlier track has taken it is the row re-evaluated over the free ones.
+// The greedy loop of iouTracke_cal.py:129-148 is sequential over the tracks, but its expensive part is not.
+// CANDIDATE FORM (round 4, the default; sigma_iou >= 0): a track can only ever take a detection whose IoU with it
+// exceeds sigma_iou (:134), whatever has been deleted before its turn, so
+//   phase 1 (16 waves, one lane per track): the exact f64 IoU of every pair that passes the f32 overlap pre-test;
+//     the detections above sigma_iou -- a handful per track even in crowded frames -- are kept as the track's
+//     candidate list, sorted by numpy's arg-max order (larger IoU first, lower index on ties);
+//   phase 2 (wave 0, in track order): the track takes its first candidate that is still free -- exactly the arg-max
+//     over the remaining detections when that exceeds sigma_iou, and "unmatched" otherwise.  A conflict costs one
+//     parallel LDS probe of <= 6 candidates instead of a re-evaluation of the whole IoU row.
+// EXACT FORM (rounds 1-3; the fallback): per track the arg-max over ALL detections, re-evaluated over the free ones on
+// a conflict.  A frame falls back to it when any pair's IoU is NaN (numpy's arg-max then returns the NaN and the track
+// stays unmatched -- kept literally), a track has more than TRK_CAND candidates, or sigma_iou < 0 (zero-IoU
+// detections would match).  Both forms make the decisions of the reference loop, bit for bit.
 // Detections, the per-track results and the det->track map live in LDS for the whole kernel.
 __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
     TrkState* __restrict__ st, ActiveSet set_a, ActiveSet set_b, int M, double sigma_iou, double sigma_h,
@@ -113,7 +122,8 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
   int* tlens = best_i + M;                   // [M]
   int* tids = tlens + M;                     // [M]
   volatile int* det_tid = tids + M;          // [M] track id that took det j, -1 while free
-  __shared__ int s_first_fail;
+  unsigned short* cand = (unsigned short*)(tids + 2 * (size_t)M);   // [M][TRK_CAND] per track: candidate detections, best first, 0xFFFF = none
+  __shared__ int s_first_fail[2], s_fallback;
   __shared__ double s_pv[TRK_THREADS];       // phase 1: per-segment partial arg-max (value, index) per track
   __shared__ int s_pi[TRK_THREADS];
   __shared__ int s_n_active, s_next_id, s_frame_num, s_nupd, s_nfin;
@@ -135,6 +145,17 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
   const ActiveSet cur = (g & 1) ? set_b : set_a;
   const ActiveSet nxt = (g & 1) ? set_a : set_b;
   const int frame = s_frame_num + 1;         // iouTracke_cal.py:118 (1-based)
+  // The track boxes of this wave's first phase-1 work item (chunk = wave % n_chunks, whatever the segment count turns out to
+  // be) are requested now, so that their HBM round trip runs under the unpack of the detections.
+  const int T = s_n_active;
+  double pf_tb[4] = {0, 0, 0, 0};
+  {
+    const int nch = (T + 63) >> 6;
+    const int t = nch > 0 ? (wave % nch) * 64 + lane : T;
+    if (t < T) {
+      pf_tb[0] = cur.box[t * 4 + 0]; pf_tb[1] = cur.box[t * 4 + 1]; pf_tb[2] = cur.box[t * 4 + 2]; pf_tb[3] = cur.box[t * 4 + 3];
+    }
+  }
 
   // ---- record header + this frame's detections -------------------------------------------------
   const long long cursor = s_cursor;
@@ -148,28 +169,51 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
   int n = 0;
   if (det_out) {
     // host unpack of iouTracke_cal.py:53-84 on device: per class plane take rows while
-    // score >= thr (f32 compare), box = row[1:5] * (w,h,w,h) in f32, then widen.
-    for (int c = 0; c < num_classes; ++c) {
-      const float* plane = det_out + (long long)c * top_k * 5;
-      if (tid == 0) s_first_fail = top_k;
-      __syncthreads();
-      for (int j = tid; j < top_k; j += TRK_THREADS)
-        if (!(plane[j * 5] >= score_thr)) atomicMin(&s_first_fail, j);
-      __syncthreads();
-      int cnt = s_first_fail;
-      if (n + cnt > M) cnt = M - n;
-      for (int j = tid; j < cnt; j += TRK_THREADS) {
-        const float* r = plane + j * 5;
-        const double b0 = (double)(r[1] * fw), b1 = (double)(r[2] * fh);
-        const double b2 = (double)(r[3] * fw), b3 = (double)(r[4] * fh), sc = (double)r[0];
-        double* d = dets + (long long)(n + j) * 5;
-        d[0] = b0; d[1] = b1; d[2] = b2; d[3] = b3; d[4] = sc;
-        double* l = dbox + (size_t)(n + j) * 4;
-        l[0] = b0; l[1] = b1; l[2] = b2; l[3] = b3;
-        fbox[n + j] = prefilter_box(b0, b1, b2, b3);
-        dscore[n + j] = sc;
+    // score >= thr (f32 compare), box = row[1:5] * (w,h,w,h) in f32, then widen.  All planes in one pass: a thread
+    // loads its row of every plane once (the loads of all planes are in flight together), the first failing row per
+    // plane is an LDS min, and the rows are written from the registers.
+    constexpr int UNPACK_C = 2;                // planes per pass (the detectors here have num_classes = 2)
+    for (int c0 = 0; c0 < num_classes; c0 += UNPACK_C) {
+      float row[UNPACK_C][5];
+      if (tid < UNPACK_C) s_first_fail[tid] = top_k;
+#pragma unroll
+      for (int cc = 0; cc < UNPACK_C; ++cc) {
+        const bool live = c0 + cc < num_classes && tid < top_k;
+        const float* r = det_out + ((long long)(c0 + cc) * top_k + (live ? tid : 0)) * 5;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) row[cc][k] = live ? r[k] : 0.0f;
       }
-      n += cnt;
+      __syncthreads();
+#pragma unroll
+      for (int cc = 0; cc < UNPACK_C; ++cc) {
+        if (c0 + cc < num_classes) {
+          if (tid < top_k && !(row[cc][0] >= score_thr)) atomicMin(&s_first_fail[cc], tid);
+          for (int j = tid + TRK_THREADS; j < top_k; j += TRK_THREADS)      // top_k > 1024: the rest from memory
+            if (!(det_out[((long long)(c0 + cc) * top_k + j) * 5] >= score_thr)) atomicMin(&s_first_fail[cc], j);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int cc = 0; cc < UNPACK_C; ++cc) {
+        if (c0 + cc >= num_classes) break;
+        const float* plane = det_out + (long long)(c0 + cc) * top_k * 5;
+        int cnt = s_first_fail[cc];
+        if (n + cnt > M) cnt = M - n;
+        for (int j = tid; j < cnt; j += TRK_THREADS) {
+          float rr[5];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) rr[k] = j == tid ? row[cc][k] : plane[j * 5 + k];
+          const double b0 = (double)(rr[1] * fw), b1 = (double)(rr[2] * fh);
+          const double b2 = (double)(rr[3] * fw), b3 = (double)(rr[4] * fh), sc = (double)rr[0];
+          double* d = dets + (long long)(n + j) * 5;
+          d[0] = b0; d[1] = b1; d[2] = b2; d[3] = b3; d[4] = sc;
+          double* l = dbox + (size_t)(n + j) * 4;
+          l[0] = b0; l[1] = b1; l[2] = b2; l[3] = b3;
+          fbox[n + j] = prefilter_box(b0, b1, b2, b3);
+          dscore[n + j] = sc;
+        }
+        n += cnt;
+      }
       __syncthreads();
     }
     if (n == 0) {   // :73-74 dummy row np.array([[0,0,0,0,0.4]]) (f64)
@@ -207,8 +251,142 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
   // extent, or one of them is the everything-box).  An empty intersection makes numpy's inter +0 and its IoU
   // 0 / (area_a + area_b) = +0 with both areas positive and finite, so all such detections tie at 0 and only the first
   // of them can be the arg-max; the (few) overlapping ones are remembered and evaluated exactly in f64 afterwards.
-  const int T = s_n_active;
-  {
+  // ---- phase 1, candidate form ---------------------------------------------------------------------
+  bool fast = sigma_iou >= 0.0;              // uniform (false for a NaN threshold too)
+  if (fast) {
+    int* cnt = best_i;                       // candidates found so far per track (best_i is free until phase 2 stages results)
+    for (int t = tid; t < T; t += TRK_THREADS) cnt[t] = 0;
+    if (tid == 0) s_fallback = 0;
+    __syncthreads();
+    const int n_chunks = (T + 63) >> 6;
+    // Work items = (chunk of 64 tracks) x (segment of the detections): S segments so that the 16 waves get equal shares
+    // (a work item costs its detections + ~24 detection-visits of set-up)
+    int S = 1;
+    {
+      long long best_cost = -1;
+      for (int s_ = 1; s_ <= 16 && n_chunks > 0; ++s_) {
+        if (s_ > 1 && (n + s_ - 1) / s_ < 16) break;
+        const long long cost = (long long)((n_chunks * s_ + NW - 1) / NW) * ((n + s_ - 1) / s_ + 24);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; S = s_; }
+      }
+    }
+    const double half_sigma = 0.5 * sigma_iou;
+    const float inf = __builtin_huge_valf();
+    bool bad = false;
+    for (int w = wave; w < n_chunks * S; w += NW) {
+      const int chunk = w % n_chunks, seg = w / n_chunks;
+      const int t = chunk * 64 + lane;
+      const bool in = t < T;
+      double tb[4] = {0, 0, 0, 0};
+      float4 tf = make_float4(inf, inf, -inf, -inf);          // overlaps nothing: lanes past the last track
+      if (in) {
+        if (w == wave) {                        // requested at the top of the frame
+          tb[0] = pf_tb[0]; tb[1] = pf_tb[1]; tb[2] = pf_tb[2]; tb[3] = pf_tb[3];
+        } else {
+          tb[0] = cur.box[t * 4 + 0]; tb[1] = cur.box[t * 4 + 1]; tb[2] = cur.box[t * 4 + 2]; tb[3] = cur.box[t * 4 + 3];
+        }
+        tf = prefilter_box(tb[0], tb[1], tb[2], tb[3]);
+        if (seg == 0) {
+          tmaxs[t] = cur.max_score[t];
+          tlens[t] = cur.len[t];
+          tids[t] = cur.id[t];
+        }
+      }
+      const int j_lo = (int)((long long)n * seg / S), j_hi = (int)((long long)n * (seg + 1) / S);
+      // four compares per pair (exact: see prefilter_box); a pair that fails them has IoU +0 (never a candidate, never NaN)
+      auto overlaps = [&](const float4 f) -> bool {
+        return (int)(f.z > tf.x) & (int)(tf.z > f.x) & (int)(f.w > tf.y) & (int)(tf.w > f.y);
+      };
+      // iou64(det j, track) with its division skipped when the quotient is certainly below sigma_iou: inter < (sigma/2) * uni
+      // implies ordered operands, uni > 0 and a quotient below sigma (the rounding of the product and of the division
+      // is 2^-53 relative against a factor of two), so neither a candidate nor a NaN is lost
+      auto exact = [&](int j) {
+        const double* a = dbox + (size_t)j * 4;
+        double dx = npmin(a[2], tb[2]) - npmax(a[0], tb[0]);
+        double dy = npmin(a[3], tb[3]) - npmax(a[1], tb[1]);
+        dx = npmax(dx, 0.0);
+        dy = npmax(dy, 0.0);
+        const double inter = dx * dy;
+        const double area_a = (a[2] - a[0]) * (a[3] - a[1]);
+        const double area_b = (tb[2] - tb[0]) * (tb[3] - tb[1]);
+        const double uni = area_a + area_b - inter;
+        if (inter < half_sigma * uni) return;
+        const double v = inter / uni;
+        if (v != v) {
+          bad = true;
+        } else if (v > sigma_iou) {
+          const int k = atomicAdd(&cnt[t], 1);
+          if (k < TRK_CAND) cand[(size_t)t * TRK_CAND + k] = (unsigned short)j;
+          else bad = true;
+        }
+      };
+      int j = j_lo;
+      constexpr int SB = 4;                     // broadcast reads in flight per round trip
+      for (; j + SB <= j_hi; j += SB) {
+        float4 f[SB];
+#pragma unroll
+        for (int k = 0; k < SB; ++k) f[k] = fbox[j + k];
+        bool m[SB], any = false;
+#pragma unroll
+        for (int k = 0; k < SB; ++k) { m[k] = overlaps(f[k]); any |= m[k]; }
+        if (__ballot(any) == 0ull) continue;
+#pragma unroll
+        for (int k = 0; k < SB; ++k)
+          if (__ballot(m[k]) != 0ull) { if (m[k]) exact(j + k); }
+      }
+      for (; j < j_hi; ++j) {
+        const bool m = overlaps(fbox[j]);
+        if (__ballot(m) != 0ull) { if (m) exact(j); }
+      }
+    }
+    if (bad) s_fallback = 1;
+    __syncthreads();
+    fast = s_fallback == 0;
+    TT(5)
+#ifdef FDT_TRK_TIMING
+    if (tid == 0 && !fast) g_trk_time[6] += 1;   // frames that fell back to the exact form
+#endif
+    if (fast) {
+      // sort each track's candidates into numpy's arg-max order (values recomputed: same function, same bits); a wave
+      // spends only the rounds its fullest list needs (most tracks have one candidate or none)
+      for (int t = tid; t < ((T + 63) & ~63); t += TRK_THREADS) {
+        const bool in = t < T;
+        const int k = in ? cnt[t] : 0;
+        int kmax = k;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, __shfl_xor(kmax, o, 64));
+        int jj[TRK_CAND];
+#pragma unroll
+        for (int i = 0; i < TRK_CAND; ++i) jj[i] = i < k ? (int)cand[(size_t)t * TRK_CAND + i] : 0xFFFF;
+        if (kmax >= 2) {
+          const double tb[4] = {in ? cur.box[t * 4 + 0] : 0.0, in ? cur.box[t * 4 + 1] : 0.0, in ? cur.box[t * 4 + 2] : 0.0,
+                                in ? cur.box[t * 4 + 3] : 0.0};
+          double v[TRK_CAND];
+#pragma unroll
+          for (int i = 0; i < TRK_CAND; ++i) {
+            v[i] = -1.0;
+            if (i < kmax && i < k) v[i] = iou64(dbox + (size_t)jj[i] * 4, tb);
+          }
+#pragma unroll
+          for (int i = 0; i < TRK_CAND - 1; ++i)
+#pragma unroll
+            for (int q = TRK_CAND - 1; q > i; --q) {
+              if (q >= kmax) continue;                    // uniform: nothing beyond the fullest list
+              const bool sw = better(v[q], jj[q], v[q - 1], jj[q - 1]);
+              const double tv = v[q]; const int tj = jj[q];
+              v[q] = sw ? v[q - 1] : v[q]; jj[q] = sw ? jj[q - 1] : jj[q];
+              v[q - 1] = sw ? tv : v[q - 1]; jj[q - 1] = sw ? tj : jj[q - 1];
+            }
+        }
+        if (in) {
+#pragma unroll
+          for (int i = 0; i < TRK_CAND; ++i) cand[(size_t)t * TRK_CAND + i] = (unsigned short)jj[i];
+        }
+      }
+    }
+  }
+  // ---- phase 1, exact form (fallback) --------------------------------------------------------------
+  if (!fast) {
     constexpr int KC = 4;                      // overlapping detections remembered per (track, segment)
     const int n_chunks = (T + 63) >> 6;
     const int S = (n_chunks > 0 && n_chunks < NW) ? NW / n_chunks : 1;
@@ -321,7 +499,132 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
     // out inside the chunk, the sequential loop of :129-148 has no cross-track dependence here and the chunk commits in
     // parallel (slots by prefix sums == what the loop would have assigned).  Otherwise the chunk runs the loop as
     // written, one track after the other, with the per-track values broadcast from the lanes that hold them.
-    for (int t0 = 0; t0 < T && n_alive > 0; t0 += 64) {
+    // ---- candidate form: the track takes its first free candidate ----
+    // Only tracks that can interact are serialised.  A track is SIMPLE when its first candidate is free and appears in no
+    // other candidate list of the chunk (dcnt, a per-detection reference count over the chunk's lists): whatever the others
+    // do it takes that detection, and nobody else can want it.  The remaining wanting tracks run the reference loop in
+    // track order among themselves (lanes 0..5 probe one candidate each); then the whole chunk commits with prefix sums --
+    // the slots the loop would have assigned.  The detections cannot run out inside a chunk with n_want < n_alive;
+    // otherwise the chunk runs the loop as written (the `break` of :130 needs the exact position).
+    int* dcnt = (int*)s_pv;                    // [M] ints of scratch (s_pv belongs to the exact form's phase 1), zero between chunks
+    static_assert(sizeof(double) * TRK_THREADS >= sizeof(int) * 1600, "s_pv holds one int per detection slot (M <= 1512)");
+    if (fast) {
+      for (int j = lane; j < n; j += 64) dcnt[j] = 0;
+      __builtin_amdgcn_wave_barrier();
+    }
+    for (int t0 = 0; fast && t0 < T && n_alive > 0; t0 += 64) {
+      const int t = t0 + lane;
+      const bool in = t < T;
+      const unsigned* cw = (const unsigned*)(cand + (size_t)(in ? t : 0) * TRK_CAND);   // 12 bytes per track, 4-byte aligned
+      const unsigned c01 = in ? cw[0] : 0xFFFFFFFFu, c23 = in ? cw[1] : 0xFFFFFFFFu, c45 = in ? cw[2] : 0xFFFFFFFFu;
+      static_assert(TRK_CAND == 6, "three dwords of candidates per track");
+      const double tmax = in ? tmaxs[t] : 0.0;
+      const int tlen = in ? tlens[t] : 0;
+      const int tidv = in ? tids[t] : 0;
+      const int bi = (int)(c01 & 0xFFFFu);
+      const bool want = in && bi != 0xFFFF;                 // :134: some detection is above sigma_iou
+      const unsigned long long want_m = __ballot(want);
+      const int n_want = __popcll(want_m);
+      if (want_m == 0ull) {                                 // nobody matches: only :146 is left
+        const bool fin = in && tmax > sigma_h && tlen > t_min;
+        const unsigned long long fin_m = __ballot(fin);
+        __builtin_amdgcn_wave_barrier();
+        if (fin) fin_ids[n_fin + __popcll(fin_m & lt_mask)] = tidv;
+        n_fin += __popcll(fin_m);
+        __builtin_amdgcn_wave_barrier();
+        continue;
+      }
+      if (n_want < n_alive) {
+        const int ck[TRK_CAND] = {(int)(c01 & 0xFFFFu), (int)(c01 >> 16), (int)(c23 & 0xFFFFu), (int)(c23 >> 16),
+                                  (int)(c45 & 0xFFFFu), (int)(c45 >> 16)};
+#pragma unroll
+        for (int k = 0; k < TRK_CAND; ++k)
+          if (ck[k] != 0xFFFF) atomicAdd(&dcnt[ck[k]], 1);
+        __builtin_amdgcn_wave_barrier();
+        const bool simple = want && det_tid[bi] == -1 && dcnt[bi] == 1;
+        unsigned long long seq_m = __ballot(want && !simple);
+        int mine = -1;                                      // the detection a serialised track ends up with
+        while (seq_m != 0ull) {
+          const int l = __ffsll((long long)seq_m) - 1;
+          seq_m &= seq_m - 1ull;
+          const unsigned a0 = __builtin_amdgcn_readlane(c01, l), a1 = __builtin_amdgcn_readlane(c23, l),
+                         a2 = __builtin_amdgcn_readlane(c45, l);
+          const int stid = __builtin_amdgcn_readlane(tidv, l);
+          const unsigned pair = lane < 2 ? a0 : (lane < 4 ? a1 : a2);
+          const int my = lane < TRK_CAND ? (int)((pair >> ((lane & 1) * 16)) & 0xFFFFu) : 0xFFFF;
+          const bool freec = my != 0xFFFF && det_tid[my] == -1;
+          const unsigned long long fm = __ballot(freec);
+          if (fm != 0ull) {
+            const int k = __ffsll((long long)fm) - 1;
+            const unsigned pk = k < 2 ? a0 : (k < 4 ? a1 : a2);
+            const int sbi = (int)((pk >> ((k & 1) * 16)) & 0xFFFFu);
+            if (lane == 0) det_tid[sbi] = stid;
+            if (lane == l) mine = sbi;
+            __builtin_amdgcn_wave_barrier();   // LDS ops of one wave complete in order; keep the compiler honest
+          }
+        }
+        const bool matched = simple || mine >= 0;
+        const int sel = simple ? bi : mine;
+        const unsigned long long mat_m = __ballot(matched);
+        const bool fin = in && !matched && tmax > sigma_h && tlen > t_min;   // :146
+        const unsigned long long fin_m = __ballot(fin);
+        __builtin_amdgcn_wave_barrier();                    // every lane holds its inputs in registers from here on
+        if (matched) {
+          const int slot = n_upd + __popcll(mat_m & lt_mask);
+          best_i[slot] = sel;                               // the track's new last box = detection sel
+          tmaxs[slot] = tmax;                               // max(track, det) (:141) is taken when the survivors are stored
+          tlens[slot] = tlen + 1;
+          tids[slot] = tidv;
+          if (simple) det_tid[sel] = tidv;
+        }
+        if (fin) fin_ids[n_fin + __popcll(fin_m & lt_mask)] = tidv;
+#pragma unroll
+        for (int k = 0; k < TRK_CAND; ++k)
+          if (ck[k] != 0xFFFF) dcnt[ck[k]] = 0;             // scratch back to zero for the next chunk
+        n_upd += __popcll(mat_m);
+        n_alive -= __popcll(mat_m);
+        n_fin += __popcll(fin_m);
+        __builtin_amdgcn_wave_barrier();
+        continue;
+      }
+      // the detections may run out inside this chunk: the loop as written, one track after the other
+      const int cnt = (T - t0) < 64 ? (T - t0) : 64;
+      const unsigned tmax_lo = (unsigned)__double_as_longlong(tmax), tmax_hi = (unsigned)(__double_as_longlong(tmax) >> 32);
+      for (int l = 0; l < cnt; ++l) {
+        if (n_alive == 0) break;                            // :130 has no else: remaining tracks vanish
+        const unsigned a0 = __builtin_amdgcn_readlane(c01, l), a1 = __builtin_amdgcn_readlane(c23, l),
+                       a2 = __builtin_amdgcn_readlane(c45, l);
+        const double stmax = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(tmax_hi, l) << 32) |
+                                                              (unsigned long long)(unsigned)__builtin_amdgcn_readlane(tmax_lo, l)));
+        const int stlen = __builtin_amdgcn_readlane(tlen, l);
+        const int stid = __builtin_amdgcn_readlane(tidv, l);
+        // lanes 0..5 probe one candidate each; the first free one in list order is the arg-max over the remaining rows
+        const unsigned pair = lane < 2 ? a0 : (lane < 4 ? a1 : a2);
+        const int my = lane < TRK_CAND ? (int)((pair >> ((lane & 1) * 16)) & 0xFFFFu) : 0xFFFF;
+        const bool freec = my != 0xFFFF && det_tid[my] == -1;
+        const unsigned long long fm = __ballot(freec);
+        if (fm != 0ull) {
+          const int k = __ffsll((long long)fm) - 1;
+          const unsigned pk = k < 2 ? a0 : (k < 4 ? a1 : a2);
+          const int sbi = (int)((pk >> ((k & 1) * 16)) & 0xFFFFu);
+          if (lane == 0) {
+            best_i[n_upd] = sbi;
+            tmaxs[n_upd] = stmax;
+            tlens[n_upd] = stlen + 1;
+            tids[n_upd] = stid;
+            det_tid[sbi] = stid;
+          }
+          ++n_upd;
+          --n_alive;
+          __builtin_amdgcn_wave_barrier();
+        } else if (stmax > sigma_h && stlen > t_min) {
+          if (lane == 0) fin_ids[n_fin] = stid;
+          ++n_fin;
+        }
+      }
+    }
+    // ---- exact form (fallback) ----
+    for (int t0 = 0; !fast && t0 < T && n_alive > 0; t0 += 64) {
       const int t = t0 + lane;
       const bool in = t < T;
       double bv = in ? best_v[t] : 0.0;
@@ -453,7 +756,8 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
     nxt.box[u * 4 + 1] = d[1];
     nxt.box[u * 4 + 2] = d[2];
     nxt.box[u * 4 + 3] = d[3];
-    nxt.max_score[u] = tmaxs[u];
+    const double sc = dscore[best_i[u]];                  // :141 max(track['max_score'], det score) (idempotent for the exact form)
+    nxt.max_score[u] = (sc > tmaxs[u]) ? sc : tmaxs[u];
     nxt.len[u] = tlens[u];
     nxt.id[u] = tids[u];
   }
@@ -620,6 +924,7 @@ extern "C" fdt_tracker* fdt_tracker_create(double sigma_iou, double sigma_h, int
   }
   // 160 KB of LDS per CU minus the kernel's static arrays (the 12 KB of per-segment partial arg-max results + counters)
   constexpr long long kDynLds = 160 * 1024 - (12 * 1024 + 256);
+  static_assert(1500ll * fdt::TRK_LDS_PER_SLOT <= kDynLds, "2 x top_k = 1500 slots (what the reference's Detect can emit) must fit");
   if ((long long)max_dets * fdt::TRK_LDS_PER_SLOT > kDynLds) {
     set_error("fdt_tracker_create: max_dets %d does not fit the LDS-resident frame state (limit %d)", max_dets,
               (int)(kDynLds / fdt::TRK_LDS_PER_SLOT));

@@ -149,7 +149,7 @@ int fdt_expand_dw(const float* x, int B, int Cin, int H, int W, const float* w1,
 /* ------------------------------------------------------------------ IoU tracker
  * The inline tracker of iouTracke_cal.py:113-156 (per frame) and :174-177 (finalise), as a
  * device-resident state machine.  A track is {bboxes, max_score, start_frame}.  One frame's detections
- * and association state live in LDS, which bounds max_dets at 1719 (the reference emits <= 2*750).  */
+ * and association state live in LDS, which bounds max_dets at 1512 (the reference emits <= 2*750).  */
 fdt_tracker* fdt_tracker_create(double sigma_iou, double sigma_h, int t_min, int max_dets,
                                 int log_frames);
 void fdt_tracker_destroy(fdt_tracker* t);
