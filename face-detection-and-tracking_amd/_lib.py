@@ -112,6 +112,8 @@ SIGNATURES = {
     "fdt_model_import_plan": (C.c_int, [_vp, C.c_char_p]),
     "fdt_model_profile_enable": (C.c_int, [_vp, C.c_int]),
     "fdt_model_profile_read": (C.c_int, [_vp, C.c_int, C.c_char_p, _vp, _vp, _c_int_p]),
+    "fdt_model_profile_segment": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "fdt_model_profile_segment_ms": (C.c_int, [_vp, _vp]),
     "fdt_model_flops": (C.c_int, [_vp, _c_f64_p]),
 }
 

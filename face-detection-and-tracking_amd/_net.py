@@ -306,6 +306,15 @@ class DetectorNet:
     def profile(self, on=True):
         _lib.check(_lib.lib().fdt_model_profile_enable(self._h, 1 if on else 0))
 
+    def profile_segment(self, first_op, last_op):
+        """One event pair around ops [first_op, last_op] of the next forwards (fdt_model_profile_segment); first_op < 0: off."""
+        _lib.check(_lib.lib().fdt_model_profile_segment(self._h, int(first_op), int(last_op)))
+
+    def profile_segment_ms(self):
+        ms = C.c_float(0)
+        _lib.check(_lib.lib().fdt_model_profile_segment_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
     def profile_read(self):
         L = _lib.lib()
         n = C.c_int(0)

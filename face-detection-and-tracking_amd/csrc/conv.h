@@ -25,6 +25,8 @@ enum ConvKind {
   CONV_3x3_S1_N8,   // same arithmetic class as CONV_3x3_S1, 8 output channels per workgroup on the packed-f32 VALU (conv_n8.h)
   CONV_3x3_S1_WINO44,  // same arithmetic class as CONV_3x3_S1, Winograd F(4x4,3x3): 36 taps, two input channels per stage (conv_wino44.h)
   CONV_3x3_D2_WINO44,  // same arithmetic class as CONV_3x3_S1_D2 (dilation 2), Winograd F(4x4,3x3) on the parity sub-lattices
+  CONV_1x1_S1_P16,     // CONV_1x1_S1 as a persistent-tile kernel (conv_1x1p.h): a workgroup walks several output tiles, the LDS
+  CONV_1x1_S1_P32,     // ring runs across them, register epilogue; 16 / 32 input channels per ring stage
   CONV_KIND_COUNT
 };
 
@@ -71,6 +73,9 @@ enum ConvTile {
   // Winograd F(4x4,3x3) (only valid with CONV_3x3_S1_WINO44): 16x32 px (4 x 8 tiles of 4x4), 64 ch, eight waves
   TILE_WINO44_32x64,
   TILE_WINO44B_32x64,  // twelve waves: a wave owns half a row of the position grid and forms its own B operands (no V buffer)
+  // persistent-tile 1x1 kernel (only valid with CONV_1x1_S1_P16 / _P32): 4x32 px, 64 / 128 ch
+  TILE_P_128x64,
+  TILE_P_128x128,
   CONV_TILE_COUNT
 };
 
@@ -107,6 +112,7 @@ struct ConvArgs {
   // workgroup -> (spatial tile, output-channel tile) map (FDT_BLOCK_MAP below): map_mode is the caller's choice
   // (CONV_MAP_*), n_sp / n_ct are filled in by launch_conv
   int map_mode, n_sp, n_ct;
+  int tiles_per_wg;       // persistent-tile kernels (conv_1x1p.h): consecutive output tiles one workgroup walks; filled in by launch_conv
 };
 
 enum { CONV_MAP_ROWS = 0, CONV_MAP_XCD_SPATIAL = 1, CONV_MAP_XCD_CHANNEL = 2 };
@@ -324,6 +330,7 @@ double conv_flops(const ConvArgs& a, ConvKind kind);
 // dynamic-LDS attribute once.
 int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a, hipStream_t st, int device = -1);
 bool conv_supported(ConvKind kind, ConvTile tile);
+bool conv_shape_supported(ConvKind kind, ConvTile tile, const ConvArgs& a);   // ... and this layer's shape / epilogue
 size_t conv_lds_bytes(ConvKind kind, ConvTile tile);   // dynamic LDS of the instantiation
 
 }  // namespace fdt

@@ -29,6 +29,7 @@
 #include "conv_kernel.h"
 #include "conv_wino.h"
 #include "conv_wino44.h"
+#include "conv_1x1p.h"
 
 namespace fdt {
 namespace {
@@ -181,6 +182,7 @@ struct Table {
     conv_fill_n8(e[CONV_3x3_S1_N8]);
     conv_fill_wino44(e[CONV_3x3_S1_WINO44]);
     conv_fill_wino44_d2(e[CONV_3x3_D2_WINO44]);
+    conv_fill_1x1_p(e[CONV_1x1_S1_P16], e[CONV_1x1_S1_P32]);
   }
 };
 
@@ -194,6 +196,7 @@ const ConvGeom kGeoms[CONV_KIND_COUNT] = {
     {3, 3, 2, 1, 1, 4, 0},  {7, 7, 2, 1, 3, 2, 0},  {7, 7, 4, 1, 3, 2, 0}, {5, 5, 2, 1, 2, 2, 0},
     {3, 3, 1, 1, 1, 8, 1},  {3, 3, 1, 2, 2, 8, 1},  {1, 1, 1, 1, 0, 32, 0},  {1, 1, 1, 1, 0, 64, 0},
     {7, 7, 2, 1, 1, 2, 0},  {3, 3, 1, 1, 1, 1, 0},  {3, 3, 1, 1, 1, 2, 2},  {3, 3, 1, 2, 2, 2, 2},
+    {1, 1, 1, 1, 0, 16, 0}, {1, 1, 1, 1, 0, 32, 0},
 };
 const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum ConvTile)
     {128, 128, 8, 16}, {128, 64, 8, 16}, {128, 32, 8, 16}, {64, 64, 8, 8},   {64, 128, 8, 8},
@@ -211,7 +214,9 @@ const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum 
     // packed-f32 VALU heads
     {2048, 8, 32, 64},
     // Winograd F(4x4,3x3): eight waves, twelve waves
-    {512, 64, 16, 32}, {512, 64, 16, 32}};
+    {512, 64, 16, 32}, {512, 64, 16, 32},
+    // persistent-tile 1x1
+    {128, 64, 4, 32}, {128, 128, 4, 32}};
 
 }  // namespace
 
@@ -224,7 +229,9 @@ ConvKind conv_base_kind(ConvKind k) {
     case CONV_3x3_D2_WINO:
     case CONV_3x3_D2_WINO44: return CONV_3x3_S1_D2;
     case CONV_1x1_S1_K32:
-    case CONV_1x1_S1_K64: return CONV_1x1_S1;
+    case CONV_1x1_S1_K64:
+    case CONV_1x1_S1_P16:
+    case CONV_1x1_S1_P32: return CONV_1x1_S1;
     default: return k;
   }
 }
@@ -232,6 +239,15 @@ bool tile_is_wino(ConvTile t) {
   return (t >= TILE_WINO_64x64 && t <= TILE_WINO8_64x64W) || t == TILE_WINO4_64x64R3 || t == TILE_WINO4_64x64W;
 }
 bool tile_is_wino44(ConvTile t) { return t == TILE_WINO44_32x64 || t == TILE_WINO44B_32x64; }
+bool kind_is_persistent(ConvKind k) { return k == CONV_1x1_S1_P16 || k == CONV_1x1_S1_P32; }
+static int device_cus(int dev) {
+  static std::atomic<int> cus[16];
+  int v = cus[dev].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+  cus[dev].store(v, std::memory_order_relaxed);
+  return v;
+}
 int tile_bm(ConvTile t) { return kTileDims[t][0]; }
 int tile_bn(ConvTile t) { return kTileDims[t][1]; }
 int tile_th(ConvTile t) { return kTileDims[t][2]; }
@@ -336,6 +352,19 @@ bool conv_combine_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
          (long long)a.ksplit * a.Cout * a.Hout * a.Wout * 4 < (1ll << 31);
 }
 
+// Shape limits of a kernel class beyond the (kind, tile) table: the autotuner and fdt_conv2d ask before they launch.
+bool conv_shape_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
+  if (!conv_supported(kind, tile)) return false;
+  if (kind == CONV_3x3_D2_WINO44 && (a.Win & 3)) return false;
+  if (kind_is_persistent(kind)) {
+    const int nstages = ceil_div(a.Cin, conv_geom(kind).kc);
+    const long long hw = (long long)a.Hin * a.Win;
+    return (a.Win & 3) == 0 && a.ksplit <= 1 && !a.up && !a.sk_count && !a.ws && nstages >= 2 &&
+           ((long long)a.Cout + 128) * hw * 4 < (1ll << 31) && (long long)a.Cin * hw * 4 < (1ll << 31);
+  }
+  return true;
+}
+
 double conv_flops(const ConvArgs& a, ConvKind kind) {
   const ConvGeom g = conv_geom(kind);
   return 2.0 * a.B * (double)a.Hout * a.Wout * a.Cout * a.Cin * g.kh * g.kw;
@@ -391,6 +420,27 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
   const int n_ct = ceil_div(a.Cout, tile_bn(tile));
   a.n_sp = tiles;
   a.n_ct = n_ct;
+  if (kind_is_persistent(kind)) {
+    // conv_1x1p.h: a workgroup walks tiles_per_wg consecutive tiles (channel tile fastest).  The grid is sized so that every
+    // CU holds its `resident` workgroups at once and all of them get the same number of tiles (+-1 at the end).
+    FDT_REQUIRE(conv_shape_supported(kind, tile, a), FDT_ERR_ARG,
+                "launch_conv: the persistent 1x1 kernel is not instantiated for this layer (needs Win %% 4 == 0, Cin >= 2 ring "
+                "stages, no split-K, no fused upsample-add, < 2 GB per image)");
+    const long long total = (long long)a.B * tiles * n_ct;
+    FDT_REQUIRE(total <= 0x7fffffffll, FDT_ERR_ARG, "launch_conv: grid too large");
+#ifdef FDT_EXPERIMENTS   // tools/experiments/r4_job6.sh: workgroups per CU the grid is sized for
+    static const int env_r = getenv("FDT_P1_RESIDENT") ? atoi(getenv("FDT_P1_RESIDENT")) : 0;
+#else
+    const int env_r = 0;
+#endif
+    const int resident = env_r > 0 ? env_r : conv_1x1p_resident(tile);
+    const long long slots = (long long)device_cus(dev) * resident;
+    const int k = (int)ceil_div_ll(total, slots);
+    a.tiles_per_wg = k;
+    hipLaunchKernelGGL(ke.fn, dim3((unsigned)ceil_div_ll(total, k)), dim3(ke.threads), ke.lds, st, a);
+    FDT_LAUNCH_CHECK();
+    return FDT_OK;
+  }
   FDT_REQUIRE(a.map_mode >= CONV_MAP_ROWS && a.map_mode <= CONV_MAP_XCD_CHANNEL, FDT_ERR_ARG, "launch_conv: bad map mode");
   const long long gx = a.map_mode == CONV_MAP_XCD_SPATIAL   ? (long long)ceil_div(tiles, 8) * 8 * n_ct
                        : a.map_mode == CONV_MAP_XCD_CHANNEL ? (long long)ceil_div(n_ct, 8) * 8 * tiles
@@ -462,6 +512,7 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
   if (kind == CONV_3x3_S1_D2 && tile == TILE_WINO44_32x64) kind = CONV_3x3_D2_WINO44;
   if (kind == CONV_3x3_S1_D2 && tile_is_wino((ConvTile)tile)) kind = CONV_3x3_D2_WINO;
   if (kind == CONV_3x3_S1 && tile == TILE_N8_32x64) kind = CONV_3x3_S1_N8;
+  if (kind == CONV_1x1_S1 && (tile == TILE_P_128x64 || tile == TILE_P_128x128)) kind = CONV_1x1_S1_P16;
   FDT_REQUIRE(tile >= 0 && tile < CONV_TILE_COUNT && conv_supported((ConvKind)kind, (ConvTile)tile), FDT_ERR_ARG,
               "fdt_conv2d: kernel (kind %d, tile %d) not instantiated", kind, tile);
   const bool combine = ksplit > 0 && (ksplit & FDT_SPLIT_COMBINE);   // in-kernel combine instead of the reduce pass

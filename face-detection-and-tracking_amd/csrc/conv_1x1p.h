@@ -34,7 +34,7 @@ struct P1x1 {
   static constexpr int NACC = MI * NI * 16;                  // accumulator registers = stores (and residual loads) per tile
   static constexpr size_t LDS_BYTES = (size_t)NBUF * STAGE * sizeof(float);
   static_assert(XSZ % 1024 == 0, "the pixel tile is staged with whole dwordx4 wave-instructions");
-  static_assert(NBUF >= 3 && NBUF <= 4, "ring of three or four");
+  static_assert(NBUF == 3, "ring of three (the host checks nst >= NBUF - 1 = 2)");
   static_assert((NBUF - 2) * LOADS + NACC <= 63 || true, "vmcnt is 6 bits: larger counts are clamped (safe: waits for more)");
 };
 
@@ -103,25 +103,27 @@ __global__ __launch_bounds__(256, P::RESIDENT) void conv1x1p_kernel(const ConvAr
 #pragma unroll
   for (int k = 0; k < P::NXV; ++k) nxoff[k] = cxoff[k];
 
-  // ---- the ring's issue cursor: (tile i_u, stage i_s), at most one tile ahead of the tile being computed (nst >= NBUF - 1) ---
+  // ---- the ring's issue cursor: (tile i_u, stage i_s), NBUF - 1 stages ahead of the stage being computed, i.e. in the tile
+  // being computed or in the next one (nst >= NBUF - 1, host check); the next tile is decoded when its first stage is issued
   int i_u = u_begin, i_s = 0, i_slot = 0;
-  bool i_next = false;                              // the cursor is in the `n*` tile
   int issued = 0, consumed = 0, issued_at_epi = 0;  // stage groups, flattened over the workgroup's tiles
-  auto issue_one = [&]() {
+  auto issue_one = [&](int u_cur) {
     if (i_u >= u_end) return;
-    if (i_next) issue(nxrs, nxoff, n_nt, i_s, i_slot);
-    else issue(cxrs, cxoff, c_nt, i_s, i_slot);
+    if (i_u == u_cur) {
+      issue(cxrs, cxoff, c_nt, i_s, i_slot);
+    } else {
+      if (i_s == 0) decode(i_u, nxrs, nxoff, n_nt, n_b, n_oy0, n_ox0);
+      issue(nxrs, nxoff, n_nt, i_s, i_slot);
+    }
     ++issued;
     i_slot = (i_slot + 1 == P::NBUF) ? 0 : i_slot + 1;
     if (++i_s == nst) {
       i_s = 0;
       ++i_u;
-      i_next = true;
-      if (i_u < u_end) decode(i_u, nxrs, nxoff, n_nt, n_b, n_oy0, n_ox0);
     }
   };
 #pragma unroll
-  for (int p = 0; p < P::NBUF - 1; ++p) issue_one();
+  for (int p = 0; p < P::NBUF - 1; ++p) issue_one(u_begin);
 
   // ---- per-lane LDS operand addresses (relative to a slot) ---------------------------------------------------------------
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256, P::RESIDENT) void conv1x1p_kernel(const ConvAr
       }
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      issue_one();
+      issue_one(u);
       if (s == nst - 1) {
         // bias and residual of THIS tile: requested one stage ahead of the epilogue (unconditional: out-of-range lanes read 0)
 #pragma unroll
@@ -271,7 +273,6 @@ __global__ __launch_bounds__(256, P::RESIDENT) void conv1x1p_kernel(const ConvAr
 #pragma unroll
     for (int k = 0; k < P::NXV; ++k) cxoff[k] = nxoff[k];
     c_nt = n_nt; c_b = n_b; c_oy0 = n_oy0; c_ox0 = n_ox0;
-    i_next = false;
   }
 }
 
@@ -286,6 +287,6 @@ using P_K16_N128 = P1x1<16, 128, 3, 2>;
 using P_K32_N64  = P1x1<32,  64, 3, 2>;
 
 }  // namespace
-void conv_fill_1x1_p(void* row);
+void conv_fill_1x1_p(void* row_k16, void* row_k32);
 int conv_1x1p_resident(ConvTile t);   // workgroups per CU a launch is sized for
 }  // namespace fdt

@@ -187,12 +187,16 @@ struct fdt_model {
 
   // profiling
   bool profile = false;
+  int seg_first = -1, seg_last = -1;   // segment timing (fdt_model_profile_segment): events only around ops [seg_first, seg_last]
+  hipEvent_t seg_ev[2] = {nullptr, nullptr};
   long long passes = 0;   // eager or captured passes through run_ops (the FDT_SKIP_OPS hook spares the first)
   std::vector<hipEvent_t> ev;
 
   ~fdt_model() {
     free_plan();
     for (auto e : ev) (void)hipEventDestroy(e);
+    for (auto e : seg_ev)
+      if (e) (void)hipEventDestroy(e);
     if (d_src_u8) (void)hipFree(d_src_u8);
     for (auto& sl : slots) sl.release();
     if (stream) (void)hipStreamDestroy(stream);
@@ -405,7 +409,12 @@ struct Builder {
     auto hint = m->hints.find(name);
     if (hint != m->hints.end() && m->hB == B && m->hH == m->tensors[0].H && m->hW == m->tensors[0].W &&
         conv_base_kind((ConvKind)hint->second.kind) == kind &&
-        conv_supported((ConvKind)hint->second.kind, (ConvTile)hint->second.tile)) {
+        conv_supported((ConvKind)hint->second.kind, (ConvTile)hint->second.tile) &&
+        // the persistent 1x1 class has shape limits of its own (conv.hip: conv_shape_supported); a plan entry that does not
+        // fit this layer is ignored like one for another shape
+        !(((ConvKind)hint->second.kind == CONV_1x1_S1_P16 || (ConvKind)hint->second.kind == CONV_1x1_S1_P32) &&
+          ((in.W & 3) || o.up_t >= 0 || hint->second.split != 1 ||
+           ceil_div(in.C, conv_geom((ConvKind)hint->second.kind).kc) < 2))) {
       kind = (ConvKind)hint->second.kind;     // e.g. the Winograd implementation of a 3x3/s1 layer
       op.kind = kind;
       op.tile = (ConvTile)hint->second.tile;
@@ -444,8 +453,10 @@ struct Builder {
     {
       ConvArgs probe = a;
       probe.ws = (float*)16;   // conv_combine_supported only asks whether there is one
-      static const int force = getenv("FDT_FORCE_COMBINE") ? atoi(getenv("FDT_FORCE_COMBINE")) : -1;   // experiment hook: 1 all / 0 none
+#ifdef FDT_EXPERIMENTS   // tools/experiments/force_combine.sh (make EXTRA=-DFDT_EXPERIMENTS): 1 all / 0 none
+      static const int force = getenv("FDT_FORCE_COMBINE") ? atoi(getenv("FDT_FORCE_COMBINE")) : -1;
       if (force >= 0) combine = force != 0 && ksplit <= (getenv("FDT_FORCE_COMBINE_MAXS") ? atoi(getenv("FDT_FORCE_COMBINE_MAXS")) : 4096);
+#endif
       op.combine = combine && conv_combine_supported(kind, op.tile, probe);
       if (op.combine) m->sk_counters = std::max(m->sk_counters, conv_sk_counters(kind, op.tile, a));
     }
@@ -1250,11 +1261,7 @@ int make_plan(fdt_model* m, int B, int H, int W) {
     FDT_TRY(dalloc((void**)&m->d_fb_probs, (size_t)B * P * 4));
   }
   FDT_TRY(dalloc(&m->d_ws, m->dplan.bytes));
-  if (m->ws_floats) {
-    FDT_TRY(dalloc((void**)&m->d_convws, (size_t)m->ws_floats * 4));
-    for (auto& op : m->ops)
-      if (op.type == OP_CONV && op.needs_ws) op.ca.ws = m->d_convws;
-  }
+  m->ws_floats = 0;   // the split-K workspace is sized and handed out by plan_reduces() below (one allocation per plan)
   if (m->sk_counters) {
     FDT_TRY(dalloc((void**)&m->d_skcnt, (size_t)m->sk_counters * sizeof(unsigned)));
     FDT_HIP(hipMemsetAsync(m->d_skcnt, 0, (size_t)m->sk_counters * sizeof(unsigned), m->stream));
@@ -1267,9 +1274,10 @@ int make_plan(fdt_model* m, int B, int H, int W) {
   m->pB = B;
   m->pH = H;
   m->pW = W;
-  // profiling events
+  // profiling events (the segment pair survives a re-plan: it is not tied to the op list)
   for (auto e : m->ev) (void)hipEventDestroy(e);
   m->ev.clear();
+  m->seg_first = m->seg_last = -1;
   return FDT_OK;
 }
 
@@ -1283,10 +1291,12 @@ int ensure_profile_events(fdt_model* m) {
   return FDT_OK;
 }
 
-// Experiment hook (tools/experiments/deletion.sh): FDT_SKIP_OPS="prefix,prefix" leaves the ops whose name starts with one
+// Experiment hook (tools/experiments/deletion.sh), compiled in only with -DFDT_EXPERIMENTS (make EXTRA=-DFDT_EXPERIMENTS; the
+// product library has no way to drop ops): FDT_SKIP_OPS="prefix,prefix" leaves the ops whose name starts with one
 // of the prefixes out of the launch sequence after the handle's first pass (so that everything downstream, Detect's
 // data-dependent NMS included, keeps reading plausible maps) -- what is a layer group worth to the multi-stream step?
-// Results are wrong by construction; never set in production.
+// Results are wrong by construction.
+#ifdef FDT_EXPERIMENTS
 bool op_skipped(const std::string& name) {
   static const std::vector<std::string> prefixes = [] {
     std::vector<std::string> v;
@@ -1307,6 +1317,9 @@ bool op_skipped(const std::string& name) {
     if (name.compare(0, p.size(), p) == 0) return true;
   return false;
 }
+#else
+static inline bool op_skipped(const std::string&) { return false; }
+#endif
 
 // The grouped head finalize: every OP_HEADFIN follows its head conv; the LAST one launches one kernel for all levels.  A head
 // conv that is split along K leaves its slabs in a region of its own (they must survive the other heads) and skips its reduce
@@ -1337,6 +1350,14 @@ int setup_heads(fdt_model* m) {
     if (m->ops[i].type != OP_HEADFIN && m->ops[i].type != OP_MBOXFIN) continue;
     Op& c = m->ops[i - 1];
     const Tensor& t = m->tensors[m->ops[i].in_t];
+    // the grouped finalize reads every level with ONE kernel chosen from the first level: all levels must be of that kind,
+    // and a head tensor has exactly the channels the kernel strides over (8 = loc + conf of PyramidBox, 6 per anchor of
+    // the FaceBoxes multibox layer)
+    const int anchors_i = m->ops[i].type == OP_MBOXFIN ? m->ops[i].anchors : 0;
+    FDT_REQUIRE(t.C == (anchors_i ? anchors_i * 6 : 8), FDT_ERR_STATE, "head tensor of %s has %d channels, the finalize kernel expects %d",
+                c.name.c_str(), t.C, anchors_i ? anchors_i * 6 : 8);
+    FDT_REQUIRE(l == 0 || (h.lv[0].anchors != 0) == (anchors_i != 0), FDT_ERR_STATE,
+                "head levels of different kinds (PyramidBox max-in-out / FaceBoxes multibox) in one graph");
     HeadLevel& L = h.lv[l++];
     L.HW = t.H * t.W;
     L.level0 = m->ops[i].level0;
@@ -1409,6 +1430,27 @@ OpAccess op_access(const fdt_model* m, const Op& op, int B) {
   return x;
 }
 
+// The handle's split-K workspace grows by replacement: the superseded buffer is freed (plan time / after an autotune: nothing
+// of this handle is in flight, and workspaces are never shared between handles).
+int grow_conv_workspace(fdt_model* m, long long need) {
+  if (!(need > m->ws_floats || (need && !m->d_convws))) return FDT_OK;
+  float* p = nullptr;
+  FDT_HIP(hipMalloc((void**)&p, (size_t)need * 4));
+  if (m->d_convws) {
+    FDT_HIP(hipDeviceSynchronize());
+    for (auto it = m->plan_allocs.begin(); it != m->plan_allocs.end(); ++it)
+      if (*it == (void*)m->d_convws) {
+        m->plan_allocs.erase(it);
+        break;
+      }
+    (void)hipFree(m->d_convws);
+  }
+  m->plan_allocs.push_back(p);
+  m->d_convws = p;
+  m->ws_floats = need;
+  return FDT_OK;
+}
+
 int plan_reduces(fdt_model* m, int B) {
   static const bool off = getenv("FDT_LAZY_REDUCE") && atoi(getenv("FDT_LAZY_REDUCE")) == 0;   // test hook: a reduce pass per layer
   std::vector<OpAccess> pend;          // accesses of the layers whose reduce pass is pending
@@ -1449,20 +1491,18 @@ int plan_reduces(fdt_model* m, int B) {
     }
   }
   m->flush_at_end = !pend.empty();
-  if (need > m->ws_floats || (need && !m->d_convws)) {
-    float* p = nullptr;
-    FDT_HIP(hipMalloc((void**)&p, (size_t)need * 4));
-    m->plan_allocs.push_back(p);
-    m->d_convws = p;
-    m->ws_floats = need;
-  }
+  FDT_TRY(grow_conv_workspace(m, need));
   for (auto& op : m->ops)
     if (op.type == OP_CONV && !op.head) op.ca.ws = op.ca.ksplit > 1 ? m->d_convws + op.ws_off : nullptr;
   return FDT_OK;
 }
 
 int run_ops(fdt_model* m, int B, hipStream_t st) {
-  const bool prof = m->profile;
+  // per-op events (fdt_model_profile_enable) xor one event pair around a contiguous run of ops (fdt_model_profile_segment):
+  // the second form leaves the launch sequence as it is in production -- lazy grouped reduce passes, no event packet
+  // between two kernels -- and measures what the per-op sums cannot: the ops back to back
+  const bool seg = m->profile && m->seg_first >= 0;
+  const bool prof = m->profile && !seg;
   if (prof) FDT_TRY(ensure_profile_events(m));
   const ConvArgs* pending[64];
   int npend = 0;
@@ -1471,12 +1511,17 @@ int run_ops(fdt_model* m, int B, hipStream_t st) {
     npend = 0;
     return FDT_OK;
   };
+  exp_skip_reduce = m->passes > 0 && op_skipped("@reduce");   // (experiment builds only; once per pass)
   for (size_t i = 0; i < m->ops.size(); ++i) {
     const Op& op = m->ops[i];
     if (op.flush_before) FDT_TRY(flush());
     if (prof) FDT_HIP(hipEventRecord(m->ev[i], st));
+    if (seg && (int)i == m->seg_first) FDT_HIP(hipEventRecord(m->seg_ev[0], st));
+    if (seg && (int)i == m->seg_last + 1) {   // the segment's deferred reduce passes belong to it
+      FDT_TRY(flush());
+      FDT_HIP(hipEventRecord(m->seg_ev[1], st));
+    }
     if (m->passes > 0 && op_skipped(op.name)) continue;   // first pass complete: later ones read its (stale) maps
-    exp_skip_reduce = m->passes > 0 && op_skipped("@reduce");
     switch (op.type) {
       case OP_CONV:
         FDT_TRY(launch_conv(op.kind, op.tile, op.ca, st, m->device));
@@ -1524,6 +1569,7 @@ int run_ops(fdt_model* m, int B, hipStream_t st) {
   }
   FDT_TRY(flush());
   if (prof) FDT_HIP(hipEventRecord(m->ev[m->ops.size()], st));
+  if (seg && m->seg_last + 1 == (int)m->ops.size()) FDT_HIP(hipEventRecord(m->seg_ev[1], st));
   exp_skip_reduce = false;
   ++m->passes;
   return FDT_OK;
@@ -1544,7 +1590,7 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
   if (fresh && st != m->stream) FDT_HIP(hipStreamSynchronize(m->stream));   // priors were built there
   const hipMemcpyKind kind = frames_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   float* x = m->tensors[0].d;
-  if (m->profile) {
+  if (m->profile && m->seg_first < 0) {
     FDT_TRY(ensure_profile_events(m));
     FDT_HIP(hipEventRecord(m->ev[m->ops.size() + 2], st));
   }
@@ -1589,12 +1635,12 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
     if (run_detect && m->arch == FDT_ARCH_FACEBOX) {
       FDT_TRY(launch_facebox_decode(m->dplan, m->d_ws, m->d_loc, m->d_conf, m->d_priors, m->conf_t, m->nms_t,
                                     m->d_fb_boxes, m->d_fb_probs, counts_p, st));
-      if (m->profile) FDT_HIP(hipEventRecord(m->ev[m->ops.size() + 1], st));
+      if (m->profile && m->seg_first < 0) FDT_HIP(hipEventRecord(m->ev[m->ops.size() + 1], st));
     } else if (run_detect) {
       if (!(m->passes > 1 && !m->profile && op_skipped("@detect")))   // (experiment hook: Detect left out of the un-profiled passes)
         FDT_TRY(launch_detect(m->dplan, m->d_ws, m->d_loc, m->d_conf, m->d_priors, 2, m->top_k, m->conf_t,
                               m->nms_t, 0.1f, 0.2f, out_p, counts_p, st));
-      if (m->profile) FDT_HIP(hipEventRecord(m->ev[m->ops.size() + 1], st));
+      if (m->profile && m->seg_first < 0) FDT_HIP(hipEventRecord(m->ev[m->ops.size() + 1], st));
     }
     return FDT_OK;
   };
@@ -2147,7 +2193,6 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
     const ConvKind base = conv_base_kind(op.kind);
     for (int k = 0; k < CONV_KIND_COUNT; ++k) {
       if (conv_base_kind((ConvKind)k) != base) continue;    // e.g. direct and Winograd 3x3/s1
-      if (k == CONV_3x3_D2_WINO44 && (op.ca.Win & 3)) continue;   // instantiated for Win % 4 == 0 only
       const int nstages = ceil_div(op.ca.Cin, conv_geom((ConvKind)k).kc);
       for (int t = 0; t < CONV_TILE_COUNT; ++t) {
         if (!conv_supported((ConvKind)k, (ConvTile)t)) continue;
@@ -2157,6 +2202,12 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
           if (split > 1 && (split > nstages / 2 || nstages < 8)) break;
           ConvArgs a = op.ca;
           a.ksplit = split;
+          {
+            ConvArgs probe = a;         // shape limits of the class (e.g. the persistent 1x1 kernel: no split-K, no fused upsample)
+            probe.ws = split > 1 ? (float*)16 : nullptr;
+            probe.sk_count = nullptr;
+            if (!conv_shape_supported((ConvKind)k, (ConvTile)t, probe)) continue;
+          }
           long long wsf = conv_ws_floats(a);
           if (wsf > kMaxWsFloats) break;
           ws_need = std::max(ws_need, wsf);
@@ -2268,13 +2319,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   long long need = 0;
   for (auto& op : m->ops)
     if (op.type == OP_CONV && op.needs_ws) need = std::max(need, conv_ws_floats(op.ca));
-  if (need > m->ws_floats || (need && !m->d_convws)) {
-    float* p = nullptr;
-    FDT_HIP(hipMalloc((void**)&p, (size_t)need * 4));
-    m->plan_allocs.push_back(p);
-    m->d_convws = p;
-    m->ws_floats = need;
-  }
+  FDT_TRY(grow_conv_workspace(m, need));
   for (auto& op : m->ops)
     if (op.type == OP_CONV) op.ca.ws = op.needs_ws ? m->d_convws : nullptr;
   long long cneed = 0;
@@ -2283,7 +2328,8 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   if (cneed > m->sk_counters || (cneed && !m->d_skcnt)) {
     unsigned* p = nullptr;
     FDT_HIP(hipMalloc((void**)&p, (size_t)cneed * sizeof(unsigned)));
-    FDT_HIP(hipMemset(p, 0, (size_t)cneed * sizeof(unsigned)));
+    FDT_HIP(hipMemsetAsync(p, 0, (size_t)cneed * sizeof(unsigned), m->stream));   // never the legacy stream (include/fdt.h)
+    FDT_HIP(hipStreamSynchronize(m->stream));
     m->plan_allocs.push_back(p);
     m->d_skcnt = p;
     m->sk_counters = cneed;
@@ -2361,6 +2407,37 @@ extern "C" int fdt_model_enable_graph(fdt_model* m, int on) {
 extern "C" int fdt_model_profile_enable(fdt_model* m, int on) {
   FDT_REQUIRE(m, FDT_ERR_ARG, "fdt_model_profile_enable: null handle");
   m->profile = on != 0;
+  m->seg_first = m->seg_last = -1;
+  return FDT_OK;
+}
+
+// Segment timing: ONE event pair around the contiguous ops [first_op, last_op] (indices as in fdt_model_profile_read) of
+// every following forward, instead of an event in front of every op; first_op < 0 switches profiling off.
+extern "C" int fdt_model_profile_segment(fdt_model* m, int first_op, int last_op) {
+  FDT_REQUIRE(m, FDT_ERR_ARG, "fdt_model_profile_segment: null handle");
+  if (first_op < 0) {
+    m->profile = false;
+    m->seg_first = m->seg_last = -1;
+    return FDT_OK;
+  }
+  FDT_REQUIRE(m->pB > 0 && !m->ops.empty(), FDT_ERR_STATE, "fdt_model_profile_segment: run a forward first");
+  FDT_REQUIRE(first_op <= last_op && last_op < (int)m->ops.size(), FDT_ERR_ARG,
+              "fdt_model_profile_segment: ops [%d, %d] outside the plan's %d ops", first_op, last_op, (int)m->ops.size());
+  FDT_HIP(hipSetDevice(m->device));
+  for (auto& e : m->seg_ev)
+    if (!e) FDT_HIP(hipEventCreate(&e));
+  m->profile = true;
+  m->seg_first = first_op;
+  m->seg_last = last_op;
+  return FDT_OK;
+}
+
+extern "C" int fdt_model_profile_segment_ms(fdt_model* m, float* ms) {
+  FDT_REQUIRE(m && ms, FDT_ERR_ARG, "fdt_model_profile_segment_ms: bad argument");
+  FDT_REQUIRE(m->profile && m->seg_first >= 0 && m->seg_ev[1], FDT_ERR_STATE,
+              "fdt_model_profile_segment_ms: no segment set (fdt_model_profile_segment) or no forward since");
+  FDT_HIP(hipEventSynchronize(m->seg_ev[1]));
+  FDT_HIP(hipEventElapsedTime(ms, m->seg_ev[0], m->seg_ev[1]));
   return FDT_OK;
 }
 

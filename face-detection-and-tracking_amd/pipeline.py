@@ -44,7 +44,10 @@ class DetectTrackPipeline:
                                   log_frames=max(log_frames, world * self.B))
         # non-default torch streams: their handles go through the C ABI, so torch.cuda.Event and the collective are
         # ordered with the library's launches
-        parts = int(os.environ.get("FDT_CU_PARTS", "1"))      # experiment: detector streams on CU partitions (fdt.h)
+        # experiment hooks (tools/experiments/*.sh) act only with FDT_EXPERIMENTS=1 in the environment
+        exp = (lambda k, d: os.environ.get(k, d)) if os.environ.get("FDT_EXPERIMENTS") == "1" else (lambda k, d: d)
+        self._exp_no_track = exp("FDT_EXP_NO_TRACK", "0") == "1"
+        parts = int(exp("FDT_CU_PARTS", "1"))      # experiment: detector streams on CU partitions (fdt.h)
         if parts > 1:
             self._raw_streams = []
             for k in range(self.NF):
@@ -53,11 +56,11 @@ class DetectTrackPipeline:
                 self._raw_streams.append(sp)
             self.det_streams = [torch.cuda.ExternalStream(sp.value, device=device) for sp in self._raw_streams]
         else:
-            alt = int(os.environ.get("FDT_DET_PRIO_ALT", "0"))     # every alt-th detector stream at high priority
+            alt = int(exp("FDT_DET_PRIO_ALT", "0"))     # every alt-th detector stream at high priority
             self.det_streams = [torch.cuda.Stream(device=device, priority=(-1 if alt and k % alt == 0 else 0))
                                 for k in range(self.NF)]
         # experiment hooks (docs/EXPERIMENTS.md R3-10): a priority of its own moves a stream to another pool of hardware queues
-        self.trk_stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("FDT_TRK_PRIO", "0")))
+        self.trk_stream = torch.cuda.Stream(device=device, priority=int(exp("FDT_TRK_PRIO", "0")))
         self.sp_det = [ctypes.c_void_p(s.cuda_stream) for s in self.det_streams]
         self.sp_trk = ctypes.c_void_p(self.trk_stream.cuda_stream)
         assert all(p.value for p in self.sp_det) and self.sp_trk.value, "need real stream handles"
@@ -105,7 +108,7 @@ class DetectTrackPipeline:
             # the one exchange step of the path: fixed-size per-frame box lists, rank order == frame order
             g = fp.exchange(self.sp_trk)
             n = self.world * self.B
-            if os.environ.get("FDT_EXP_NO_TRACK") == "1":       # experiment: what does the association cost the step?
+            if self._exp_no_track:       # experiment: what does the association cost the step?
                 pass
             elif self.multi_step:
                 self.tracker.step_dev_multi(ctypes.c_void_p(g.data_ptr()), n, self.REC, 2, self.top_k, self.W, self.H,
@@ -116,12 +119,62 @@ class DetectTrackPipeline:
                                           self.H, self.score_thresh, self.sp_trk)
             self.trk_done[k].record(self.trk_stream)
 
+    # ---- frames handed over ONE AT A TIME, executed `batch` at a time (cross-frame grouped launches) ----------------------
+    # A video source delivers single frames (iouTracke_cal.py:119-124), but at 640x480 a batch-1 forward is a chain of ~110
+    # launches of a few hundred workgroups each, and the chip is paid per launch: `batch` consecutive frames of one rank
+    # share ONE launch per layer (the handle's plan is the batch-`batch` plan), detection results and tracks are what the
+    # one-frame-at-a-time path gives (frames are independent until the tracker, which still sees them in frame order).
+    def step_frame(self, i, frame_dev):
+        """Frame i of this rank (uint8 [1, h, w, 3] or [h, w, 3] on the device).  The frame is copied into slot
+        (i // batch) % inflight's staging batch on that slot's stream; the batch's last frame launches forward + exchange +
+        association exactly like step().  flush() runs a partly filled batch (end of the video)."""
+        G = self.B
+        k, j = (i // G) % self.NF, i % G
+        st = self.det_streams[k]
+        if getattr(self, "_stage", None) is None:
+            h, w = self.source_hw if self.source_hw else (self.H, self.W)
+            self._stage = torch.empty((self.NF, G, h, w, 3), dtype=torch.uint8, device=self.dev)
+        with torch.cuda.stream(st):
+            if j == 0:
+                st.wait_event(self.trk_done[k])         # the slot's previous batch was consumed
+            self._stage[k, j].copy_(frame_dev.reshape(self._stage.shape[2:]), non_blocking=True)
+        self._pending = (i // G, k, j + 1)
+        if j == G - 1:
+            self._launch_group(i // G, k, G)
+
+    def flush(self):
+        """Run the partly filled batch, if any: the unused entries of the staging batch hold older frames whose records
+        the tracker is not shown."""
+        pend = getattr(self, "_pending", None)
+        if pend and pend[2] < self.B:
+            self._launch_group(*pend)
+        self._pending = None
+
+    def _launch_group(self, step, k, n_valid):
+        fp = self.fps[k]
+        st = self.det_streams[k]
+        self._pending = None
+        with torch.cuda.stream(st):
+            self._forward(k, self._stage[k])
+            self.det_done[k].record(st)
+        with torch.cuda.stream(self.trk_stream):
+            self.trk_stream.wait_event(self.det_done[k])
+            g = fp.exchange(self.sp_trk)
+            # gathered records are rank-major [world][batch][REC]; frame order is batch-major: frame (j, r) = j * world + r
+            for j in range(n_valid):
+                if self._exp_no_track:
+                    break
+                self.tracker.step_dev_multi(ctypes.c_void_p(g.data_ptr() + 4 * j * self.REC), self.world, self.B * self.REC, 2,
+                                            self.top_k, self.W, self.H, self.score_thresh, self.sp_trk)
+            self.trk_done[k].record(self.trk_stream)
+
     def record_of_slot(self, k):
         """Host copy of slot k's gathered records [world*B, 2, top_k, 5] (synchronises)."""
         torch.cuda.synchronize(self.dev)
         return self.fps[k].gathered.detach().cpu().numpy().reshape(self.world * self.B, 2, self.top_k, 5)
 
     def finish(self):
+        self.flush()
         torch.cuda.synchronize(self.dev)
         return self.tracker.finish()
 

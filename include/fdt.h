@@ -270,6 +270,13 @@ int fdt_model_enable_graph(fdt_model* m, int on);
 int fdt_model_profile_enable(fdt_model* m, int on);
 int fdt_model_profile_read(fdt_model* m, int max, char* names /* max*48 */, float* ms,
                            double* flops, int* n);
+/* Segment timing: ONE event pair around the contiguous ops [first_op, last_op] (indices of fdt_model_profile_read) of the
+ * next forwards, no event between two kernels and the production launch sequence (lazy grouped reduce passes; the
+ * segment's own deferred passes are flushed inside it): what a run of layers -- e.g. the backbone the MFMA bar of
+ * BASELINE.json is stated on -- takes back to back on one stream, which the sum of per-op event intervals overstates by
+ * one event packet per launch.  first_op < 0 switches profiling off.  Eager launches, like per-op profiling.         */
+int fdt_model_profile_segment(fdt_model* m, int first_op, int last_op);
+int fdt_model_profile_segment_ms(fdt_model* m, float* ms);
 /* Algorithmic HBM bytes of one forward of the current plan (every op reads its inputs and writes its output once,
  * f32; convs read their weights once): totals, and per op in the order of fdt_model_profile_read.               */
 int fdt_model_traffic(fdt_model* m, double* act_bytes, double* weight_bytes, int max, double* per_op, int* n);

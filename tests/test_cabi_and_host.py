@@ -166,6 +166,7 @@ def test_bench_host_helpers_and_committed_plans():
     assert bench.kernel_label(9, 22).startswith("conv_wino2_kernel<3x3d2_wino")
     assert bench.kernel_label(0, 12) == "conv_kernel<1x1s1, tile 12>"
     assert bench.kernel_label(13, 31) == "conv_n8_kernel<3x3s1_n8, tile 31>"
+    assert bench.kernel_label(16, 34) == "conv1x1p_kernel<1x1s1_p16, tile 34>"     # persistent-tile 1x1 (conv_1x1p.h)
     # the watchdog around the multi-GPU communicator set-up: result, exception and timeout
     import time
     assert bench.run_with_timeout(lambda: 7, 5.0) == (True, 7)
@@ -185,6 +186,7 @@ def test_bench_host_helpers_and_committed_plans():
     assert plan["conv2_SSH.conv1"][0] == 14 and plan["conv2_SSH.conv1"][1] in (32, 33)    # Winograd F(4x4,3x3)
     assert plan["conv2_SSH.conv2"][0] == 15 and plan["conv2_SSH.conv2"][1] == 32          # dilated F(4x4,3x3) on parity sub-lattices
     assert bench.kernel_label(14, 32).startswith("conv_wino44_kernel<3x3s1_wino44") and bench.WINO_RATIO[14] == 4.0
+    assert plan["layer1.1.conv3"][0] == 16 and plan["layer1.1.conv3"][2] == 1             # persistent-tile 1x1 on the 256^2 expand layers
     assert len(plan) == 105                                                               # every conv layer of Res50
     sh = open(os.path.join(ROOT, "tools", "refresh_profiles.sh")).read()
     assert all(("plan_of " + layer) in sh for layer in ("conv2_SSH.conv1", "conv2_SSH.conv2", "layer3.1.conv1", "layer1.0.conv3"))

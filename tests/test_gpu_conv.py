@@ -15,8 +15,10 @@ KINDS = {  # name: (k, stride, pad, dil)
     "1x1s1": (1, 1, 0, 1), "1x1s2": (1, 2, 0, 1), "3x3s1": (3, 1, 1, 1), "3x3d2": (3, 1, 2, 2),
     "3x3s2": (3, 2, 1, 1), "7x7s2": (7, 2, 3, 1), "7x7s4": (7, 4, 3, 1), "5x5s2": (5, 2, 2, 1),
     "7x7s2p1": (7, 2, 1, 1)}
-N_TILES = 34      # 14 direct + 11 Winograd F(2x2,3x3) (3x3 s1 / d2 only) + 4 ring-of-four (1x1 only) + 2 quarter-split Winograd
-                  # + 1 packed-f32 VALU tile for narrow heads (3x3 s1 only) + 1 Winograd F(4x4,3x3) (3x3 s1 only)
+N_TILES = 36      # 14 direct + 11 Winograd F(2x2,3x3) (3x3 s1 / d2 only) + 4 ring-of-four (1x1 only) + 2 quarter-split Winograd
+                  # + 1 packed-f32 VALU tile for narrow heads (3x3 s1 only) + 2 Winograd F(4x4,3x3) (3x3 s1 only)
+                  # + 2 persistent-tile 1x1 (1x1 s1 only)
+T_P64, T_P128 = 34, 35           # conv.h: TILE_P_128x64 / TILE_P_128x128 (kernel classes CONV_1x1_S1_P16 = 16, _P32 = 17)
 T_WINO44 = 32
 T_WINO44B = 33     # its twelve-wave form
 WINO44_TOL = 1e-4  # F(4x4,3x3): factors up to 8 in A^T / 5 in B^T amplify the f32 rounding of the transforms (2.7e-6 relative RMS
@@ -344,3 +346,39 @@ def test_channels_past_cin_read_as_zero(k, p, d, tile):
     assert rc == 0, lib().lib().fdt_last_error()
     assert np.isfinite(got[0]).all() and np.isnan(got[1]).all()
     assert rel_err(got[:1], exp) < WINO44_TOL
+
+
+@pytest.mark.parametrize("variant", [16 * 100 + T_P64, 16 * 100 + T_P128, 17 * 100 + T_P64])
+@pytest.mark.parametrize("shape", [(1, 64, 256, 256, 256), (2, 40, 250, 252, 136), (1, 256, 128, 160, 64)])
+def test_persistent_1x1_walks_tiles(variant, shape):
+    """conv_1x1p.h: the grids of these shapes give every workgroup 2..4 consecutive output tiles (1024+ tiles for 256 CUs x 2..4
+    resident workgroups), so the ring runs across tile boundaries, the next tile's stages are in flight under an epilogue and
+    stores are still draining when the next tile's MFMAs start.  Bit-identical to the one-tile-per-workgroup kernel of the
+    same class (same MFMA order, same epilogue arithmetic), and within f32 rounding of torch; bias / residual / ReLU, channel
+    tiles hanging over Cout, tiles hanging over the image, two images."""
+    B, Cin, H, W, Cout = shape
+    rng = np.random.default_rng(variant + H)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((B, Cout, H, W)).astype(np.float32)
+    for kw in (dict(res=res, act=1), dict(act=0), dict(act=2)):
+        rc, got = run_conv(x, w, b, 1, 1, 0, 1, tile=variant, **kw)
+        assert rc == 0, lib().lib().fdt_last_error()
+        rc, base = run_conv(x, w, b, 1, 1, 0, 1, tile=6, **kw)            # TILE_128x64W of the direct class
+        assert rc == 0, lib().lib().fdt_last_error()
+        assert np.array_equal(got, base), (variant, shape, list(kw), float(np.abs(got - base).max()))
+        assert rel_err(got, reference(x, w, b, 1, 1, 0, 1, **kw)) < 1e-5
+    rc, got = run_conv(x, w, None, 1, 1, 0, 1, tile=variant, act=0)       # no bias tensor
+    assert rc == 0 and rel_err(got, reference(x, w, None, 1, 1, 0, 1)) < 1e-5
+
+
+def test_persistent_1x1_refuses_what_it_is_not_built_for():
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 40, 20, 30)).astype(np.float32)           # W % 4 != 0
+    w = rng.standard_normal((64, 40, 1, 1)).astype(np.float32)
+    rc, _ = run_conv(x, w, None, 1, 1, 0, 1, tile=16 * 100 + T_P64)
+    assert rc != 0 and b"not instantiated" in lib().lib().fdt_last_error()
+    x = rng.standard_normal((1, 40, 20, 32)).astype(np.float32)
+    rc, _ = run_conv(x, w, None, 1, 1, 0, 1, tile=16 * 100 + T_P64, split=2)   # no split-K
+    assert rc != 0 and b"not instantiated" in lib().lib().fdt_last_error()

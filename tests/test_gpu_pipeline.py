@@ -168,6 +168,42 @@ def test_pipelined_streams_match_sequential_and_oracle(res50, synth, inflight, m
     pipe.close()
 
 
+@pytest.mark.parametrize("group,inflight,N", [(4, 2, 26), (2, 3, 25)])
+def test_frames_handed_over_one_at_a_time_run_as_grouped_launches(res50, synth, group, inflight, N):
+    """DetectTrackPipeline.step_frame: single frames in, `group` consecutive frames per launch (the handle runs its batch-`group`
+    plan), tracker in frame order; a partly filled last group is flushed by finish().  Same tracks as the one-frame-at-a-time
+    sequential path + the oracle tracker, bit for bit (frames are independent until the tracker)."""
+    H, W = 128, 160
+    dev = torch.device("cuda", 0)
+    res50.priorbox = M("layers").PriorBoxLayer(W, H); res50.firstTime = True
+    res50.detect = M("layers").Detect(2, 0, 750, 0.05, 0.35)
+    frames = moving_frames(synth, N, H, W, seed=11)
+    # the reference run uses the same batch-`group` forwards, synchronously (another batch size may pick other kernels for a
+    # layer, i.e. another summation order); images of a batch do not see each other, so the tail is padded with any frame
+    seq = []
+    for g0 in range(0, N, group):
+        chunk = frames[g0:g0 + group]
+        n = len(chunk)
+        if n < group:
+            chunk = np.concatenate([chunk, np.repeat(frames[:1], group - n, 0)])
+        y = res50(chunk).numpy()
+        seq += [y[j:j + 1] for j in range(n)]
+    ref = opp.IouTracker(0.4, 0.6, 5)
+    for y in seq:
+        with np.errstate(all="ignore"):
+            ref.step(opp.unpack_detections(y, W, H, 0.4))
+    want = tracks_key(ref.finish())
+    assert len(want) >= 2
+    pipe = M("pipeline").DetectTrackPipeline(res50, H, W, dev, inflight=inflight, batch=group, log_frames=8)
+    frames_d = torch.from_numpy(frames).to(dev)
+    for i in range(N):
+        pipe.step_frame(i, frames_d[i:i + 1])
+    got = tracks_key(pipe.finish())                     # N is not a multiple of the group: the tail is flushed here
+    assert got == want
+    pipe.close()
+    res50.firstTime = True                              # the handle is back to batch-1 plans for the tests that follow
+
+
 def test_cu_partitioned_streams_give_the_same_tracks(res50, synth, monkeypatch):
     """fdt_stream_create_partition (include/fdt.h): detector streams confined to halves of every XCD's compute units.  A speed
     experiment (slower: docs/EXPERIMENTS.md R3-6) -- the placement must not change a single bit."""
@@ -178,6 +214,7 @@ def test_cu_partitioned_streams_give_the_same_tracks(res50, synth, monkeypatch):
     frames_d = torch.from_numpy(moving_frames(synth, N, H, W, seed=9)).to(dev)
     out = []
     for parts in ("1", "2"):
+        monkeypatch.setenv("FDT_EXPERIMENTS", "1")        # pipeline.py honours its experiment hooks only with this
         monkeypatch.setenv("FDT_CU_PARTS", parts)
         pipe = M("pipeline").DetectTrackPipeline(res50, H, W, dev, inflight=4, log_frames=8)
         for i in range(N):

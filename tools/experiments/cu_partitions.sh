@@ -1,6 +1,7 @@
 #!/bin/bash
 # Detector streams confined to CU partitions (FDT_CU_PARTS, fdt_stream_create_partition): do frames in flight overlap better
 # when their kernels CANNOT compete for the same CUs?  Committed plans (tuned for 256 CUs); with and without graph replay.
+export FDT_EXPERIMENTS=1   # pipeline.py honours its experiment hooks only with this set
 for SZ in "" "--height 480 --width 640"; do
   for P in 1 2 4; do
     for G in 1 0; do

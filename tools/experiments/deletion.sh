@@ -2,6 +2,8 @@
 # What is each layer group worth to the multi-stream step?  FDT_SKIP_OPS (csrc/model.hip, experiment hook) leaves ops out of
 # the launch sequence by name prefix; results are wrong by construction, only the step time counts.
 #   bash tools/experiments/deletion.sh "--height 480 --width 640"      (or "" for 1024x1024)
+# the hooks this script sets are compiled in only with -DFDT_EXPERIMENTS (the product library ignores them):
+(cd face-detection-and-tracking_amd/csrc && touch model.hip conv.hip && make -s -j8 EXTRA=-DFDT_EXPERIMENTS > /dev/null)
 SZ="$1"
 SSH1=conv2_SSH.conv1,conv3_SSH.conv1,conv4_SSH.conv1,conv5_SSH.conv1,conv6_SSH.conv1,conv7_SSH.conv1
 CTX=conv2_SSH.conv2,conv3_SSH.conv2,conv4_SSH.conv2,conv5_SSH.conv2,conv6_SSH.conv2,conv7_SSH.conv2

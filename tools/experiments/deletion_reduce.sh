@@ -1,5 +1,7 @@
 #!/bin/bash
 # Ceiling of an in-kernel split-K combine: the reduce passes simply not launched (FDT_SKIP_OPS=@reduce, csrc/conv.hip hook).
+# the hooks this script sets are compiled in only with -DFDT_EXPERIMENTS (the product library ignores them):
+(cd face-detection-and-tracking_amd/csrc && touch model.hip conv.hip && make -s -j8 EXTRA=-DFDT_EXPERIMENTS > /dev/null)
 for SZ in "--height 480 --width 640" "" "--arch facebox"; do
   for SK in "" "@reduce"; do
     FDT_SKIP_OPS="$SK" python bench.py --steps 96 --warmup 12 --cpu-frames 0 --host-frames 0 --profile-frames 1 $SZ 2>/dev/null |
