@@ -399,6 +399,10 @@ def main():
     ap.add_argument("--arch", default="res50", choices=["res50", "try3", "facebox"],
                     help="facebox = config 5 of BASELINE.json (FaceBoxes, 1024x1024, --batch 16), single GPU")
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (one batched forward)")
+    ap.add_argument("--group", type=int, default=0,
+                    help="frames are handed to the pipeline ONE AT A TIME but executed GROUP at a time (one launch per layer for "
+                         "GROUP consecutive frames: pipeline.step_frame); a step stays one frame per GPU.  0 = auto: 4 for "
+                         "Res50 frames of at most 640x480 at --batch 1 (launch-bound there), else 1")
     ap.add_argument("--source", default="", help="HxW of raw source frames (e.g. 1080x1920): the frames are resized on the "
                     "GPU to --height x --width inside the timed step like iouTracke_cal.py:123 does with cv2.resize")
     ap.add_argument("--unique-frames", type=int, default=8)
@@ -459,6 +463,14 @@ def main():
     W = args.width or args.size
     sd = synth.make_state_dict(args.arch, seed=0)
     B = max(1, args.batch)
+    # cross-frame grouped launches: G consecutive frames of a rank share one launch per layer (the handle runs its batch-G
+    # plan); every leg below then works on batches of G, only the timed loop hands the frames over one by one
+    G = args.group if args.group > 0 else (4 if (args.arch == "res50" and B == 1 and H * W <= 640 * 480 and os.path.exists(
+        os.path.join(ROOT, "face-detection-and-tracking_amd", "tuned", "res50_%dx%d_b4.plan" % (W, H)))) else 1)
+    if G > 1:
+        if B != 1:
+            raise SystemExit("--group needs --batch 1 (a step is one frame per GPU)")
+        B = G
     # frames in flight: eight everywhere since round 3 (tools/experiments/inflight_repeat.sh, inflight_other_configs.sh, three
     # repetitions): Res50 1024^2 4 / 8 / 12 in flight = 258.3 / 265.3 / 268.2 frames/s over 256 steps and 255.9 / 261.2 / 259.7 over
     # the 20 steps the driver times; 640x480 605 / 613 / 614; batch 2: 285 (3) / 292 (8); try3 batch 1: 1237 (3) / 1417 (8);
@@ -572,15 +584,21 @@ def main():
     # initialisation, not a step: plan construction, weight tiling and HIP-graph capture of every in-flight handle happen
     # here (the compile step of this runtime), so that the W warm-up and K timed steps are steady-state steps whatever W is
     pipe.prime(frames_of(0))
+    if G > 1:
+        run_step = lambda f: pipe.step_frame(f, frames_d[f % U:f % U + 1])    # frame f of this rank, handed over alone
+    else:
+        run_step = lambda i: pipe.step(i, frames_of(i))
     for i in range(args.warmup):
-        pipe.step(i, frames_of(i))
+        run_step(i)
     sync_all()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record(pipe.trk_stream)
     for i in range(args.steps):
-        pipe.step(args.warmup + i, frames_of(args.warmup + i))
+        run_step(args.warmup + i)
+    if G > 1:
+        pipe.flush()                            # a partly filled last group runs inside the timed region
     e1.record(pipe.trk_stream)
     torch.cuda.synchronize()
     if world > 1:
@@ -592,7 +610,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    n_cand_last = int(pipe.counts[(args.warmup + args.steps - 1) % NF].cpu()[1])
+    n_total = args.warmup + args.steps           # steps = frames per rank when G > 1, else batches of B
+    n_cand_last = int(pipe.counts[(((n_total - 1) // G) if G > 1 else (n_total - 1)) % NF].cpu()[1])
     tracks = pipe.finish()
     mine = pipe.fps[0].mine
     counts0 = pipe.counts[0]
@@ -616,9 +635,10 @@ def main():
     if rank == 0 and world == 1:
         trk = importlib.import_module("face-detection-and-tracking_amd.tracker")
         seq = trk.IouTracker(0.4, 0.6, 5, max_dets=2 * top_k, log_frames=256)
-        for i in range(args.warmup + args.steps):
+        n_batches = (n_total + G - 1) // G if G > 1 else n_total
+        for i in range(n_batches):
             forward_dev(i)
-            for b in range(B):
+            for b in range(min(B, n_total - i * G) if G > 1 else B):
                 seq.step_dev(ctypes.c_void_p(mine.data_ptr() + 4 * b * REC), 2, top_k, W, H, 0.4, stream)
             torch.cuda.synchronize()
         seq_tracks = seq.finish()
@@ -775,11 +795,12 @@ def main():
                                   % (seg_ms["backbone"][1], seg_ms["backbone"][2])}
                          if bb[0] and "backbone" in seg_ms else None),
             # the timed region itself (frames overlap on several streams): FLOPs of a step / ms_per_step
+            # (a profiled forward covers G frames when launches are grouped; a step is one frame)
             "timed_step": {"ms_per_step": round(step_ms, 4),
-                           "achieved_executed": round(tf(exe, step_ms), 2),
-                           "frac_executed": round(tf(exe, step_ms) / PEAK_F32_MFMA_TFLOPS, 4),
-                           "achieved_algorithmic": round(tf(alg, step_ms), 2),
-                           "frac_algorithmic": round(tf(alg, step_ms) / PEAK_F32_MFMA_TFLOPS, 4)},
+                           "achieved_executed": round(tf(exe / max(G, 1), step_ms), 2),
+                           "frac_executed": round(tf(exe / max(G, 1), step_ms) / PEAK_F32_MFMA_TFLOPS, 4),
+                           "achieved_algorithmic": round(tf(alg / max(G, 1), step_ms), 2),
+                           "frac_algorithmic": round(tf(alg / max(G, 1), step_ms) / PEAK_F32_MFMA_TFLOPS, 4)},
             "by_kernel": [{"kernel": kernel_label(k, t), "launches": g[0], "ms": round(g[1], 4),
                            "executed_tflops": round(tf(g[3], g[1]), 1), "algorithmic_tflops": round(tf(g[2], g[1]), 1)}
                           for (k, t), g in sorted(groups.items(), key=lambda kv: -kv[1][1])[:6]],
@@ -878,7 +899,7 @@ def main():
                           "says): the oracle end to end on this host's cores"}
 
     if rank == 0:
-        frames = args.steps * world * B
+        frames = args.steps * world * (1 if G > 1 else B)
         line = {
             "metric": "frames/sec (detect+track) at %dx%d" % (W, H),
             "value": round(frames / dt, 3),
@@ -895,8 +916,14 @@ def main():
             "config": {"workload": "PyramidBox-%s %dx%d synthetic u8 frames%s, batch=%d per GPU, decode+NMS+IoU-tracker "
                                    "on device" % ("Res50" if args.arch == "res50" else "MobileNetV2-try3", W, H,
                                                   " resized on the GPU from %dx%d sources" % (SW, SH) if args.source else "",
-                                                  B),
-                       "frames_per_step": world * B, "frames_in_flight_per_gpu": NF, "kernel_plan": plan_src,
+                                                  1 if G > 1 else B),
+                       "frames_per_step": world * (1 if G > 1 else B),
+                       "frames_grouped_per_launch": G if G > 1 else None,
+                       "grouping": ("frames are handed to the pipeline one at a time (a step = one frame per GPU); %d consecutive "
+                                    "frames of a GPU share ONE launch per layer (pipeline.step_frame: staged into the slot's "
+                                    "batch, the handle runs its batch-%d plan), the tracker sees them in frame order; "
+                                    "--group 1 is the one-launch-chain-per-frame form" % (G, G)) if G > 1 else None,
+                       "frames_in_flight_per_gpu": NF * (G if G > 1 else 1), "kernel_plan": plan_src,
                        "hip_graph": bool(args.graph), "weight_copies_per_gpu": 1,
                        "primed": "plan + HIP-graph capture of every in-flight handle before the warm-up steps (initialisation)",
                        "parallelism": "frame-parallel x%d%s" % (

@@ -115,6 +115,23 @@ SIGNATURES = {
     "fdt_model_profile_segment": (C.c_int, [_vp, C.c_int, C.c_int]),
     "fdt_model_profile_segment_ms": (C.c_int, [_vp, _vp]),
     "fdt_model_flops": (C.c_int, [_vp, _c_f64_p]),
+    "fdt_model_get_detect": (C.c_int, [_vp, _c_int_p, _vp, _vp, _c_int_p]),
+    "fdt_pipeline_create": (_vp, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_float, C.c_double, C.c_double, C.c_int, C.c_int]),
+    "fdt_pipeline_destroy": (None, [_vp]),
+    "fdt_pipeline_prime": (C.c_int, [_vp, _vp]),
+    "fdt_pipeline_step": (C.c_int, [_vp, C.c_longlong, _vp]),
+    "fdt_pipeline_step_frame": (C.c_int, [_vp, C.c_longlong, _vp]),
+    "fdt_pipeline_flush": (C.c_int, [_vp]),
+    "fdt_pipeline_sync": (C.c_int, [_vp]),
+    "fdt_pipeline_tracker": (_vp, [_vp]),
+    "fdt_pipeline_slot": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "fdt_pipeline_mark": (C.c_int, [_vp, C.c_int]),
+    "fdt_pipeline_elapsed_ms": (C.c_int, [_vp, _vp]),
+    "fdt_dev_malloc": (C.c_int, [C.POINTER(_vp), C.c_longlong]),
+    "fdt_dev_free": (C.c_int, [_vp]),
+    "fdt_dev_upload": (C.c_int, [_vp, _vp, C.c_longlong]),
+    "fdt_dev_download": (C.c_int, [_vp, _vp, C.c_longlong]),
 }
 
 _lib = None

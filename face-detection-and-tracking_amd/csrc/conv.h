@@ -115,7 +115,7 @@ struct ConvArgs {
   int tiles_per_wg;       // persistent-tile kernels (conv_1x1p.h): consecutive output tiles one workgroup walks; filled in by launch_conv
 };
 
-enum { CONV_MAP_ROWS = 0, CONV_MAP_XCD_SPATIAL = 1, CONV_MAP_XCD_CHANNEL = 2 };
+enum { CONV_MAP_ROWS = 0, CONV_MAP_XCD_SPATIAL = 1, CONV_MAP_XCD_CHANNEL = 2, CONV_MAP_XCD_REGION = 3, CONV_MAP_COUNT = 4 };
 
 // Workgroup map.  CONV_MAP_ROWS: id = channel_tile * n_sp + spatial_tile (all spatial tiles of one channel tile
 // first; consecutive workgroups land on different XCDs).  The two XCD-aware maps use that workgroups are dealt
@@ -124,6 +124,11 @@ enum { CONV_MAP_ROWS = 0, CONV_MAP_XCD_SPATIAL = 1, CONV_MAP_XCD_CHANNEL = 2 };
 //           the output-channel tiles of one spatial tile back to back -> the input patch is fetched into L2 once;
 //   XCD_CHANNEL (weights are the bigger operand):    the XCD owns the channel tiles n = 8*(q / n_sp) + lane8 and walks
 //           the spatial tiles -> every XCD streams only its 1/8 of the weights.
+//   XCD_REGION (round 4): like XCD_SPATIAL, but the XCD owns a CONTIGUOUS run of ceil(n_sp / 8) spatial tiles (s = lane8 *
+//           per + q / n_ct) instead of every eighth one -- neighbouring tiles share their halo rows and the 128-byte lines
+//           their row segments straddle, and with interleaved ownership each of those lines is fetched from HBM once PER
+//           XCD (measured with the TCC's read-request size classes, profiles/r04/conv_hbm_traffic.json: 3.0x the input on
+//           the F(4x4) kernel's 160-byte row pieces, 2.0x on 8x16-pixel tiles' 64-byte rows).
 // Workgroups decoded outside the tile grid exit at once.  Pure speed: nothing depends on the placement.  Measured on
 // the Res50 graph the XCD-aware maps cut the conv kernels' HBM fetches by a quarter but are not faster on every
 // layer (the MFMA-bound ones lose a little), so the map is a per-layer choice of the autotuner.
@@ -137,6 +142,12 @@ enum { CONV_MAP_ROWS = 0, CONV_MAP_XCD_SPATIAL = 1, CONV_MAP_XCD_CHANNEL = 2 };
     } else if ((a_).map_mode == CONV_MAP_XCD_CHANNEL) {                         \
       s_ = q_ % (a_).n_sp;                                                      \
       n_ = (q_ / (a_).n_sp) * 8 + l8_;                                          \
+    } else if ((a_).map_mode == CONV_MAP_XCD_REGION) {                          \
+      const int per_ = ((a_).n_sp + 7) >> 3;                                    \
+      n_ = q_ % (a_).n_ct;                                                      \
+      s_ = q_ / (a_).n_ct;                                                      \
+      if (s_ >= per_) return;                                                   \
+      s_ += l8_ * per_;                                                         \
     } else {                                                                    \
       s_ = id_ % (a_).n_sp;                                                     \
       n_ = id_ / (a_).n_sp;                                                     \

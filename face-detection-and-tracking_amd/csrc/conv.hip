@@ -441,10 +441,10 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
     FDT_LAUNCH_CHECK();
     return FDT_OK;
   }
-  FDT_REQUIRE(a.map_mode >= CONV_MAP_ROWS && a.map_mode <= CONV_MAP_XCD_CHANNEL, FDT_ERR_ARG, "launch_conv: bad map mode");
-  const long long gx = a.map_mode == CONV_MAP_XCD_SPATIAL   ? (long long)ceil_div(tiles, 8) * 8 * n_ct
-                       : a.map_mode == CONV_MAP_XCD_CHANNEL ? (long long)ceil_div(n_ct, 8) * 8 * tiles
-                                                            : (long long)tiles * n_ct;
+  FDT_REQUIRE(a.map_mode >= CONV_MAP_ROWS && a.map_mode < CONV_MAP_COUNT, FDT_ERR_ARG, "launch_conv: bad map mode");
+  const long long gx = (a.map_mode == CONV_MAP_XCD_SPATIAL || a.map_mode == CONV_MAP_XCD_REGION)
+                           ? (long long)ceil_div(tiles, 8) * 8 * n_ct
+                           : a.map_mode == CONV_MAP_XCD_CHANNEL ? (long long)ceil_div(n_ct, 8) * 8 * tiles : (long long)tiles * n_ct;
   FDT_REQUIRE(gx <= 0x7fffffffll && (long long)a.B * a.ksplit <= 65535, FDT_ERR_ARG, "launch_conv: grid too large");
   dim3 grid((unsigned)gx, 1, a.B * a.ksplit);
   const bool odd = ke.fn_odd && (a.Win & 3);
@@ -611,6 +611,7 @@ extern "C" int fdt_debug_conv_bench(int kind, int tile, int ksplit, int B, int C
     FDT_HIP(hipMemsetAsync(dcnt.p, 0, nc, st));
     a.sk_count = dcnt.as<unsigned>();
   }
+  if (const char* mm = getenv("FDT_CONV_MAP")) a.map_mode = atoi(mm);   // tuning hook: workgroup map (conv.h CONV_MAP_*)
   hipEvent_t e0, e1;
   FDT_HIP(hipEventCreate(&e0)); FDT_HIP(hipEventCreate(&e1));
   for (int i = 0; i < 2; ++i) FDT_TRY(launch_conv((ConvKind)kind, (ConvTile)tile, a, st));

@@ -1779,6 +1779,15 @@ extern "C" fdt_model* fdt_model_clone(fdt_model* src) {
   return m.release();
 }
 
+extern "C" int fdt_model_get_detect(fdt_model* m, int* top_k, float* conf_thresh, float* nms_thresh, int* nms_top_k) {
+  FDT_REQUIRE(m, FDT_ERR_ARG, "fdt_model_get_detect: null handle");
+  if (top_k) *top_k = m->top_k;
+  if (conf_thresh) *conf_thresh = m->conf_t;
+  if (nms_thresh) *nms_thresh = m->nms_t;
+  if (nms_top_k) *nms_top_k = m->nms_top_k;
+  return FDT_OK;
+}
+
 extern "C" int fdt_model_set_tensor(fdt_model* m, const char* name, const float* data, int ndim,
                                     const long long* dims) {
   FDT_REQUIRE(m && name && ndim >= 0 && ndim <= 8, FDT_ERR_ARG, "fdt_model_set_tensor: bad argument");
@@ -2275,8 +2284,8 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
       a.ws = best.split > 1 ? tmp_ws : nullptr;
       a.sk_count = best.combine ? tmp_cnt : nullptr;
       a.defer_reduce = op.head && best.split > 1 ? 1 : 0;
-      float map_ms[3] = {1e30f, 1e30f, 1e30f};
-      for (int mm = 0; mm < 3 && rc == FDT_OK; ++mm) {
+      float map_ms[CONV_MAP_COUNT] = {1e30f, 1e30f, 1e30f, 1e30f};
+      for (int mm = 0; mm < CONV_MAP_COUNT && rc == FDT_OK; ++mm) {
         a.map_mode = mm;
         for (int it = 0; it < iters + 2 && rc == FDT_OK; ++it) {
           (void)hipEventRecord(e0, st);
@@ -2289,7 +2298,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
         }
       }
       // an XCD-aware map that is no slower (within timer noise) is preferred: it re-fetches less from HBM
-      for (int mm = 1; mm < 3; ++mm)
+      for (int mm = 1; mm < CONV_MAP_COUNT; ++mm)
         if (map_ms[mm] <= 1.005f * map_ms[CONV_MAP_ROWS] && map_ms[mm] < map_ms[best_map == CONV_MAP_ROWS ? mm : best_map] * 1.0001f)
           best_map = mm;
     }
@@ -2375,7 +2384,7 @@ extern "C" int fdt_model_import_plan(fdt_model* m, const char* text) {
       if (nf == 4) d = CONV_MAP_ROWS;      // plans written before the workgroup map became a choice
       if (nf <= 5) cb = 0;                 // ... and before the in-kernel split-K combine existed
       FDT_REQUIRE(a >= 0 && a < CONV_KIND_COUNT && b >= 0 && b < CONV_TILE_COUNT && c >= 1 && c <= 4096 &&
-                      d >= CONV_MAP_ROWS && d <= CONV_MAP_XCD_CHANNEL && (cb == 0 || cb == 1),
+                      d >= CONV_MAP_ROWS && d < CONV_MAP_COUNT && (cb == 0 || cb == 1),
                   FDT_ERR_ARG, "fdt_model_import_plan: bad entry '%s'", line.c_str());
       hints[name] = {a, b, c, d, cb};
     } else {

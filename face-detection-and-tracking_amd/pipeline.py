@@ -189,3 +189,89 @@ class DetectTrackPipeline:
         for sp in getattr(self, "_raw_streams", []):   # CU-partitioned detector streams (FDT_CU_PARTS): nothing is in flight any more
             _lib.check(_lib.lib().fdt_stream_destroy(sp))
         self._raw_streams = []
+
+
+class CabiPipeline:
+    """The same pipeline behind the C ABI (fdt_pipeline_*, include/fdt.h): libfdt_hip.so owns the in-flight handles, the HIP
+    streams and events, the per-slot Detect records and the device tracker -- nothing here but pointers, so a caller without
+    torch (tests/test_gpu_cabi_pipeline.py drives it from plain C) runs the timed path too.  Frames are device pointers
+    (a torch tensor's data_ptr(), or fdt_dev_malloc memory).  `comm`: an fdt_comm_init_rank handle for world > 1."""
+
+    def __init__(self, net, H, W, device_index=0, inflight=3, batch=1, comm=None, world=1, rank=0, source_hw=None,
+                 score_thresh=0.4, sigma_iou=0.4, sigma_h=0.6, t_min=5, log_frames=256, plan_text=None):
+        L = _lib.lib()
+        net.firstTime = True
+        net._sync_attributes(H, W)                         # PriorBox / Detect settings onto the handle (clones copy them)
+        self.H, self.W, self.B, self.NF, self.world, self.rank = H, W, max(1, batch), max(1, inflight), world, rank
+        self.top_k = net.detect.top_k
+        self.REC = 2 * self.top_k * 5
+        sh, sw = source_hw if source_hw else (0, 0)
+        self._p = L.fdt_pipeline_create(net._h, int(device_index), H, W, self.NF, self.B,
+                                        plan_text.encode() if plan_text else None, comm, rank, world, sh, sw,
+                                        float(score_thresh), float(sigma_iou), float(sigma_h), int(t_min), int(log_frames))
+        if not self._p:
+            raise _lib.FdtError(_lib.FDT_ERR_HIP, (L.fdt_last_error() or b"").decode())
+        self._L = L
+        self._trk = IouTracker.borrowed(L.fdt_pipeline_tracker(self._p), sigma_iou, sigma_h, t_min)
+
+    @staticmethod
+    def _ptr(frames):
+        return ctypes.c_void_p(frames.data_ptr() if hasattr(frames, "data_ptr") else int(frames))
+
+    def prime(self, frames_dev):
+        _lib.check(self._L.fdt_pipeline_prime(self._p, self._ptr(frames_dev)))
+
+    def step(self, i, frames_dev):
+        _lib.check(self._L.fdt_pipeline_step(self._p, int(i), self._ptr(frames_dev)))
+
+    def step_frame(self, i, frame_dev):
+        _lib.check(self._L.fdt_pipeline_step_frame(self._p, int(i), self._ptr(frame_dev)))
+
+    def flush(self):
+        _lib.check(self._L.fdt_pipeline_flush(self._p))
+
+    def sync(self):
+        _lib.check(self._L.fdt_pipeline_sync(self._p))
+
+    def mark(self, which):
+        _lib.check(self._L.fdt_pipeline_mark(self._p, int(which)))
+
+    def elapsed_ms(self):
+        ms = ctypes.c_float(0)
+        _lib.check(self._L.fdt_pipeline_elapsed_ms(self._p, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def slot(self, k):
+        """(model handle, stream, record ptr, gathered-records ptr, counts ptr) of slot k, as c_void_p."""
+        out = [ctypes.c_void_p() for _ in range(5)]
+        _lib.check(self._L.fdt_pipeline_slot(self._p, int(k), *[ctypes.byref(o) for o in out]))
+        return tuple(out)
+
+    def record_of_slot(self, k):
+        """Host copy of slot k's gathered records [world*B, 2, top_k, 5] (synchronises)."""
+        import numpy as np
+        self.sync()
+        g = self.slot(k)[3]
+        out = np.empty((self.world * self.B, 2, self.top_k, 5), np.float32)
+        _lib.check(self._L.fdt_dev_download(_lib.ptr(out), g, out.nbytes))
+        return out
+
+    def counts_of_slot(self, k):
+        import numpy as np
+        self.sync()
+        out = np.empty((self.B, 2), np.int32)
+        _lib.check(self._L.fdt_dev_download(_lib.ptr(out), self.slot(k)[4], out.nbytes))
+        return out
+
+    def finish(self):
+        self.flush()
+        self.sync()
+        return self._trk.finish()
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self._L.fdt_pipeline_destroy(self._p)
+            self._p = None
+            self._trk.close()
+
+    __del__ = close

@@ -17,9 +17,18 @@ class IouTracker:
             raise _lib.FdtError(_lib.FDT_ERR_HIP, (_lib.lib().fdt_last_error() or b"").decode())
         self.sigma_iou, self.sigma_h, self.t_min = sigma_iou, sigma_h, t_min
 
+    @classmethod
+    def borrowed(cls, handle, sigma_iou=0.4, sigma_h=0.6, t_min=5):
+        """A view of a tracker another object owns (fdt_pipeline_tracker): finish() / tracks work, close() does not destroy."""
+        t = object.__new__(cls)
+        t._h, t._borrowed = handle, True
+        t.sigma_iou, t.sigma_h, t.t_min = sigma_iou, sigma_h, t_min
+        return t
+
     def close(self):
         if getattr(self, "_h", None):
-            _lib.lib().fdt_tracker_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                _lib.lib().fdt_tracker_destroy(self._h)
             self._h = None
 
     __del__ = close

@@ -201,6 +201,7 @@ int fdt_model_set_priorbox(fdt_model* m, int width, int height, int n_levels,
 /* net.detect = Detect(2,0,top_k,conf_thresh,nms_thresh)  (My_test.py:36)                     */
 int fdt_model_set_detect(fdt_model* m, int top_k, float conf_thresh, float nms_thresh,
                          int nms_top_k);
+int fdt_model_get_detect(fdt_model* m, int* top_k, float* conf_thresh, float* nms_thresh, int* nms_top_k);   /* any may be NULL */
 /* y = net(x)  pyramid.py:218-351 (Res50), pyramid_mb2_try3.py:218-340 (try3).
  * frames: B images in `format`; out: [B,2,top_k,5] f32; counts: [B,2] or NULL.               */
 int fdt_model_forward(fdt_model* m, const void* frames, int format, int B, int H, int W,
@@ -303,6 +304,47 @@ int fdt_comm_group_end(void);
 int fdt_allgather_dets(fdt_comm* c, int local_index, const float* local_dev, float* all_dev,
                        long long floats_per_rank, void* stream);
 void fdt_comm_destroy(fdt_comm* c);
+
+/* ------------------------------------------------------------------ the per-GPU detect + track pipeline
+ * The loop of iouTracke_cal.py:117-156 as it is timed: `inflight` frames in flight, slot k = step % inflight owns a model
+ * handle (m itself and fdt_model_clone()s of it: one weight copy), a HIP stream, its Detect record [batch][2][top_k][5] and
+ * candidate counts; the exchange (world > 1: fdt_allgather_dets on `comm`) and the strictly sequential association run on one
+ * more stream; HIP events order  detect(step i, slot k) -> exchange + track(step i) -> detect(step i + inflight, slot k).
+ * Frames are DEVICE pointers to `batch` raw u8 BGR HWC frames (src_h x src_w > 0: raw source frames, resized on the GPU
+ * like iouTracke_cal.py:123; else height x width); nothing waits for the host until fdt_pipeline_sync.  Same launches, same
+ * bits as calling fdt_model_forward_dev + fdt_tracker_step_dev_multi one frame at a time (tests/test_gpu_cabi_pipeline.py:
+ * a plain-C driver without any other GPU runtime).  m must be finalized with its PriorBox / Detect set; plan_text (may be
+ * NULL) = fdt_model_import_plan for every slot.  m is borrowed and must outlive the pipeline; so must comm.            */
+typedef struct fdt_pipeline fdt_pipeline;
+fdt_pipeline* fdt_pipeline_create(fdt_model* m, int device, int height, int width, int inflight, int batch,
+                                  const char* plan_text, fdt_comm* comm, int rank, int world, int src_h, int src_w,
+                                  float score_thresh /* iouTracke_cal.py:61: 0.4 */, double sigma_iou, double sigma_h,
+                                  int t_min, int log_frames);
+void fdt_pipeline_destroy(fdt_pipeline* p);
+/* initialisation, not a step: every slot's forward twice (plan + weight tiling, HIP-graph capture); tracker untouched */
+int fdt_pipeline_prime(fdt_pipeline* p, const void* frames_dev);
+/* enqueue step i: detection of `batch` frames on slot i % inflight, exchange, association of the step's world * batch frames */
+int fdt_pipeline_step(fdt_pipeline* p, long long i, const void* frames_dev);
+/* frames handed over ONE at a time (what a video source delivers), executed `batch` at a time: frame i of this rank is
+ * copied into the staging batch of slot (i / batch) % inflight; the batch's last frame launches it (one launch per layer for
+ * `batch` consecutive frames).  fdt_pipeline_flush runs a partly filled batch (end of the video).                       */
+int fdt_pipeline_step_frame(fdt_pipeline* p, long long i, const void* frame_dev);
+int fdt_pipeline_flush(fdt_pipeline* p);
+int fdt_pipeline_sync(fdt_pipeline* p);
+/* the pipeline's device tracker: fdt_tracker_finish / _num_tracks / _track_info / _track_boxes after fdt_pipeline_sync */
+fdt_tracker* fdt_pipeline_tracker(fdt_pipeline* p);
+/* what slot k owns (any output may be NULL): its handle, stream (hipStream_t), record, gathered records, counts */
+int fdt_pipeline_slot(fdt_pipeline* p, int slot, fdt_model** model, void** det_stream, float** record_dev,
+                      float** gathered_dev, int** counts_dev);
+/* timing events on the tracker stream: mark(0) ... steps ... mark(1); elapsed_ms waits for mark 1 */
+int fdt_pipeline_mark(fdt_pipeline* p, int which);
+int fdt_pipeline_elapsed_ms(fdt_pipeline* p, float* ms);
+/* plain device buffers (hipMalloc / hipFree / blocking copies on the calling thread's private stream) for callers that
+ * link no GPU runtime of their own                                                                                  */
+int fdt_dev_malloc(void** ptr, long long bytes);
+int fdt_dev_free(void* ptr);
+int fdt_dev_upload(void* dst_dev, const void* src_host, long long bytes);
+int fdt_dev_download(void* dst_host, const void* src_dev, long long bytes);
 
 #ifdef __cplusplus
 }

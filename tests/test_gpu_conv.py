@@ -88,7 +88,7 @@ def test_every_tile_variant_matches_torch(kind):
     assert tested >= 4
 
 
-@pytest.mark.parametrize("mode", [1, 2])      # conv.h: CONV_MAP_XCD_SPATIAL / CONV_MAP_XCD_CHANNEL
+@pytest.mark.parametrize("mode", [1, 2, 3])   # conv.h: CONV_MAP_XCD_SPATIAL / CONV_MAP_XCD_CHANNEL / CONV_MAP_XCD_REGION
 def test_xcd_aware_workgroup_maps(mode, monkeypatch):
     """The XCD-aware workgroup -> tile maps (incl. the padding workgroups that exit at once) compute the same
     convolution as the row-major map."""
