@@ -560,8 +560,17 @@ def main():
         return par.FrameParallel(rank, world, rec, dev)
 
     SH, SW = (int(v) for v in args.source.lower().split("x")) if args.source else (H, W)
-    pipe = pipeline.DetectTrackPipeline(net, H, W, dev, inflight=NF, batch=B, exchange_factory=make_exchange, world=world,
-                                        rank=rank, source_hw=(SH, SW) if args.source else None, plan_text=plan_text)
+    # The timed loop is driven through the C ABI (fdt_pipeline_*: the library owns the in-flight handles, streams, events,
+    # records and the tracker; torch holds the synthetic frames) whenever the exchange is the library's own -- one rank, or
+    # RCCL behind fdt_allgather_dets.  The torch.distributed form of the exchange (gloo rehearsal on one GPU, fallback after
+    # a failed communicator) keeps the Python pipeline, whose exchange object it is.
+    use_cabi = os.environ.get("FDT_BENCH_PIPELINE", "cabi") == "cabi" and (world == 1 or comm is not None)
+    if use_cabi:
+        pipe = pipeline.CabiPipeline(net, H, W, local_rank, inflight=NF, batch=B, comm=comm, world=world, rank=rank,
+                                     source_hw=(SH, SW) if args.source else None, plan_text=plan_text)
+    else:
+        pipe = pipeline.DetectTrackPipeline(net, H, W, dev, inflight=NF, batch=B, exchange_factory=make_exchange, world=world,
+                                            rank=rank, source_hw=(SH, SW) if args.source else None, plan_text=plan_text)
     top_k = pipe.top_k
     REC = pipe.REC
 
@@ -594,29 +603,43 @@ def main():
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    e0.record(pipe.trk_stream)
+    pipe.mark(0) if use_cabi else e0.record(pipe.trk_stream)      # HIP events on the tracker stream (the last one of a step)
     for i in range(args.steps):
         run_step(args.warmup + i)
     if G > 1:
         pipe.flush()                            # a partly filled last group runs inside the timed region
-    e1.record(pipe.trk_stream)
+    pipe.mark(1) if use_cabi else e1.record(pipe.trk_stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    gpu_ms = e0.elapsed_time(e1)
+    gpu_ms = pipe.elapsed_ms() if use_cabi else e0.elapsed_time(e1)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_total = args.warmup + args.steps           # steps = frames per rank when G > 1, else batches of B
-    n_cand_last = int(pipe.counts[(((n_total - 1) // G) if G > 1 else (n_total - 1)) % NF].cpu()[1])
+    last_slot = (((n_total - 1) // G) if G > 1 else (n_total - 1)) % NF
+    n_cand_last = int(pipe.counts_of_slot(last_slot).reshape(-1)[1]) if use_cabi else int(pipe.counts[last_slot].cpu()[1])
     tracks = pipe.finish()
-    mine = pipe.fps[0].mine
-    counts0 = pipe.counts[0]
-    stream = pipe.sp_det[0]
-    torch.cuda.set_stream(pipe.det_streams[0])
+
+    class _Ptr:                                  # a raw device pointer with the data_ptr() the legs below ask for
+        def __init__(self, p):
+            self.p = int(p.value)
+
+        def data_ptr(self):
+            return self.p
+
+    if use_cabi:
+        _, st0, rec0, _, cnt0 = pipe.slot(0)     # slot 0 = the handle `net` itself
+        mine, counts0, stream = _Ptr(rec0), _Ptr(cnt0), st0
+        torch.cuda.set_stream(torch.cuda.ExternalStream(st0.value, device=dev))
+    else:
+        mine = pipe.fps[0].mine
+        counts0 = pipe.counts[0]
+        stream = pipe.sp_det[0]
+        torch.cuda.set_stream(pipe.det_streams[0])
 
     def forward_dev(i):
         f = frames_of(i)
@@ -925,6 +948,8 @@ def main():
                                     "--group 1 is the one-launch-chain-per-frame form" % (G, G)) if G > 1 else None,
                        "frames_in_flight_per_gpu": NF * (G if G > 1 else 1), "kernel_plan": plan_src,
                        "hip_graph": bool(args.graph), "weight_copies_per_gpu": 1,
+                       "timed_loop": ("C ABI (fdt_pipeline_*: handles, streams, events, records, tracker owned by libfdt_hip.so)"
+                                      if use_cabi else "pipeline.DetectTrackPipeline (torch streams / events; torch.distributed exchange)"),
                        "primed": "plan + HIP-graph capture of every in-flight handle before the warm-up steps (initialisation)",
                        "parallelism": "frame-parallel x%d%s" % (
                            world, (", all-gather of box lists: " + ("RCCL via fdt_allgather_dets (C ABI)" if comm is not None

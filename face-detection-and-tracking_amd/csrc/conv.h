@@ -27,6 +27,8 @@ enum ConvKind {
   CONV_3x3_D2_WINO44,  // same arithmetic class as CONV_3x3_S1_D2 (dilation 2), Winograd F(4x4,3x3) on the parity sub-lattices
   CONV_1x1_S1_P16,     // CONV_1x1_S1 as a persistent-tile kernel (conv_1x1p.h): a workgroup walks several output tiles, the LDS
   CONV_1x1_S1_P32,     // ring runs across them, register epilogue; 16 / 32 input channels per ring stage
+  CONV_7x7_S2_U8,      // CONV_7x7_S2 / _S4 reading the raw uint8 HWC BGR frame: the (float)u8 - mean (/ scale) of the ingest
+  CONV_7x7_S4_U8,      // happens in the conv's own staging (conv_stem_u8.h); ConvArgs.in_u8 instead of ConvArgs.in
   CONV_KIND_COUNT
 };
 
@@ -76,6 +78,7 @@ enum ConvTile {
   // persistent-tile 1x1 kernel (only valid with CONV_1x1_S1_P16 / _P32): 4x32 px, 64 / 128 ch
   TILE_P_128x64,
   TILE_P_128x128,
+  TILE_128x32W,        // 4x32 px, 32 ch (the u8 stem of FaceBoxes: 24 output channels)
   CONV_TILE_COUNT
 };
 
@@ -112,6 +115,9 @@ struct ConvArgs {
   // workgroup -> (spatial tile, output-channel tile) map (FDT_BLOCK_MAP below): map_mode is the caller's choice
   // (CONV_MAP_*), n_sp / n_ct are filled in by launch_conv
   int map_mode, n_sp, n_ct;
+  const unsigned char* in_u8;   // CONV_7x7_S*_U8 only: [B][Hin][Win][3] raw BGR bytes (instead of `in`); value = ((float)u8 -
+  float u8_mean[3];             // u8_mean[c]) / u8_scale, the arithmetic of the ingest kernel (ops.hip: preprocess_kernel)
+  float u8_scale;
   int tiles_per_wg;       // persistent-tile kernels (conv_1x1p.h): consecutive output tiles one workgroup walks; filled in by launch_conv
 };
 

@@ -30,6 +30,7 @@
 #include "conv_wino.h"
 #include "conv_wino44.h"
 #include "conv_1x1p.h"
+#include "conv_stem_u8.h"
 
 namespace fdt {
 namespace {
@@ -183,6 +184,7 @@ struct Table {
     conv_fill_wino44(e[CONV_3x3_S1_WINO44]);
     conv_fill_wino44_d2(e[CONV_3x3_D2_WINO44]);
     conv_fill_1x1_p(e[CONV_1x1_S1_P16], e[CONV_1x1_S1_P32]);
+    conv_fill_stem_u8(e[CONV_7x7_S2_U8], e[CONV_7x7_S4_U8]);
   }
 };
 
@@ -196,7 +198,7 @@ const ConvGeom kGeoms[CONV_KIND_COUNT] = {
     {3, 3, 2, 1, 1, 4, 0},  {7, 7, 2, 1, 3, 2, 0},  {7, 7, 4, 1, 3, 2, 0}, {5, 5, 2, 1, 2, 2, 0},
     {3, 3, 1, 1, 1, 8, 1},  {3, 3, 1, 2, 2, 8, 1},  {1, 1, 1, 1, 0, 32, 0},  {1, 1, 1, 1, 0, 64, 0},
     {7, 7, 2, 1, 1, 2, 0},  {3, 3, 1, 1, 1, 1, 0},  {3, 3, 1, 1, 1, 2, 2},  {3, 3, 1, 2, 2, 2, 2},
-    {1, 1, 1, 1, 0, 16, 0}, {1, 1, 1, 1, 0, 32, 0},
+    {1, 1, 1, 1, 0, 16, 0}, {1, 1, 1, 1, 0, 32, 0}, {7, 7, 2, 1, 3, 4, 0},  {7, 7, 4, 1, 3, 4, 0},
 };
 const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum ConvTile)
     {128, 128, 8, 16}, {128, 64, 8, 16}, {128, 32, 8, 16}, {64, 64, 8, 8},   {64, 128, 8, 8},
@@ -216,7 +218,9 @@ const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum 
     // Winograd F(4x4,3x3): eight waves, twelve waves
     {512, 64, 16, 32}, {512, 64, 16, 32},
     // persistent-tile 1x1
-    {128, 64, 4, 32}, {128, 128, 4, 32}};
+    {128, 64, 4, 32}, {128, 128, 4, 32},
+    // 4x32 px, 32 ch
+    {128, 32, 4, 32}};
 
 }  // namespace
 
@@ -232,6 +236,8 @@ ConvKind conv_base_kind(ConvKind k) {
     case CONV_1x1_S1_K64:
     case CONV_1x1_S1_P16:
     case CONV_1x1_S1_P32: return CONV_1x1_S1;
+    case CONV_7x7_S2_U8: return CONV_7x7_S2;
+    case CONV_7x7_S4_U8: return CONV_7x7_S4;
     default: return k;
   }
 }
@@ -240,6 +246,7 @@ bool tile_is_wino(ConvTile t) {
 }
 bool tile_is_wino44(ConvTile t) { return t == TILE_WINO44_32x64 || t == TILE_WINO44B_32x64; }
 bool kind_is_persistent(ConvKind k) { return k == CONV_1x1_S1_P16 || k == CONV_1x1_S1_P32; }
+bool kind_is_u8_stem(ConvKind k) { return k == CONV_7x7_S2_U8 || k == CONV_7x7_S4_U8; }
 static int device_cus(int dev) {
   static std::atomic<int> cus[16];
   int v = cus[dev].load(std::memory_order_relaxed);
@@ -356,6 +363,10 @@ bool conv_combine_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
 bool conv_shape_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
   if (!conv_supported(kind, tile)) return false;
   if (kind == CONV_3x3_D2_WINO44 && (a.Win & 3)) return false;
+  if (kind_is_u8_stem(kind))   // the raw-frame stem: three input channels, one stage, plain epilogue, one channel tile per 32 / 64 couts
+    return a.in_u8 != nullptr && a.Cin == 3 && a.ksplit <= 1 && !a.ws && !a.res && !a.up && !a.sk_count &&
+           (long long)(a.Cout + 64) * a.Hout * a.Wout * 4 < (1ll << 31);
+  if (a.in_u8) return false;   // every other class reads f32 NCHW
   if (kind_is_persistent(kind)) {
     const int nstages = ceil_div(a.Cin, conv_geom(kind).kc);
     const long long hw = (long long)a.Hin * a.Win;
@@ -382,8 +393,11 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
               "launch_conv: output %dx%d does not match input %dx%d for kind %d", a.Hout, a.Wout, a.Hin,
               a.Win, kind);
   FDT_REQUIRE(a.B >= 1 && a.Cin >= 1 && a.Cout >= 1 && a.out_coff >= 0 &&
-                  a.out_coff + a.Cout <= a.out_ctot && a.in && a.w && a.out,
+                  a.out_coff + a.Cout <= a.out_ctot && (a.in || a.in_u8) && a.w && a.out,
               FDT_ERR_ARG, "launch_conv: bad channel/pointer arguments");
+  FDT_REQUIRE(kind_is_persistent(kind) || conv_shape_supported(kind, tile, a), FDT_ERR_ARG,
+              "launch_conv: kernel class %d is not instantiated for this layer (raw-frame stem needs ConvArgs.in_u8 and Cin = 3; every "
+              "other class reads f32)", (int)kind);
   if (a.res) FDT_REQUIRE(a.res_coff + a.Cout <= a.res_ctot, FDT_ERR_ARG, "launch_conv: bad residual slice");
   if (a.up) FDT_REQUIRE(a.up_h * 2 >= a.Hout && a.up_w * 2 >= a.Wout && a.up_h >= 1 && a.up_w >= 1,
                         FDT_ERR_ARG, "launch_conv: upsample source too small");
