@@ -241,7 +241,7 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
 
 
 KIND_NAMES = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2", "3x3s1_wino", "3x3d2_wino", "1x1s1_k32",
-              "1x1s1_k64", "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44", "1x1s1_p16", "1x1s1_p32"]
+              "1x1s1_k64", "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44", "1x1s1_p16", "1x1s1_p32", "7x7s2_u8", "7x7s4_u8"]
 WINO_KINDS = (8, 9, 14, 15)   # conv.h: Winograd kinds execute fewer MACs than the direct form:
 WINO_RATIO = {8: 2.25, 9: 2.25, 14: 4.0, 15: 4.0}   # F(2x2,3x3) 16/36 of them, F(4x4,3x3) (CONV_3x3_{S1,D2}_WINO44) 36/144
 
@@ -254,6 +254,8 @@ def kernel_label(kind, tile):
         return "%s<%s, tile %d>" % (k, KIND_NAMES[kind], tile)
     if kind == 13:            # conv.h: CONV_3x3_S1_N8, the vector-ALU kernel of the narrow heads (conv_n8.h)
         return "conv_n8_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
+    if kind in (18, 19):      # conv.h: CONV_7x7_S2_U8 / _S4_U8, the stem conv on the raw uint8 frame (conv_stem_u8.h)
+        return "conv_stem_u8_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
     if kind in (16, 17):      # conv.h: CONV_1x1_S1_P16 / _P32, the persistent-tile 1x1 kernel (conv_1x1p.h)
         return "conv1x1p_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
     return "conv_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)

@@ -116,6 +116,7 @@ SIGNATURES = {
     "fdt_model_profile_segment_ms": (C.c_int, [_vp, _vp]),
     "fdt_model_flops": (C.c_int, [_vp, _c_f64_p]),
     "fdt_model_get_detect": (C.c_int, [_vp, _c_int_p, _vp, _vp, _c_int_p]),
+    "fdt_model_fuse_ingest": (C.c_int, [_vp, C.c_int]),
     "fdt_pipeline_create": (_vp, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_float, C.c_double, C.c_double, C.c_int, C.c_int]),
     "fdt_pipeline_destroy": (None, [_vp]),

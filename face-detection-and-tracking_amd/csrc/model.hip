@@ -63,6 +63,12 @@ struct Op {
   bool lazy = false;      // OP_CONV: the reduce pass waits, with others, for the first op that needs its result (plan_reduces)
   bool flush_before = false;   // any op: the pending reduce passes run (as one launch) before this op
   long long ws_off = 0;   // lazy: this layer's slabs inside the shared workspace
+  // the 7x7 stem on the input tensor also exists as a raw-uint8 kernel (conv_stem_u8.h): launched instead of [ingest kernel +
+  // this op] whenever a forward is fed uint8 frames (fdt_model::u8_src)
+  bool u8_stem = false;
+  ConvKind u8_kind = CONV_7x7_S2_U8;
+  ConvTile u8_tile = TILE_128x64W;
+  const float* u8_w = nullptr;
 };
 
 struct DevW {
@@ -101,8 +107,10 @@ struct GraphKey {   // everything a captured forward bakes in besides the plan i
   const void* counts;
   int run_detect;
   float conf_t, nms_t;
+  int first_op;        // 1: the stem ran eagerly in front of the graph on the caller's uint8 frame (fused ingest)
   bool operator<(const GraphKey& o) const {
-    return std::tie(out, counts, run_detect, conf_t, nms_t) < std::tie(o.out, o.counts, o.run_detect, o.conf_t, o.nms_t);
+    return std::tie(out, counts, run_detect, conf_t, nms_t, first_op) <
+           std::tie(o.out, o.counts, o.run_detect, o.conf_t, o.nms_t, o.first_op);
   }
 };
 
@@ -171,6 +179,16 @@ struct fdt_model {
   int* d_counts = nullptr;
   void* d_ws = nullptr;
   DetectPlan dplan;
+  // fused ingest (conv_stem_u8.h): the uint8 frames of the forward being enqueued, their mean / scale; whether the last
+  // forward ran fused (tensor "input" is then not materialised until somebody asks for it)
+  int fuse_stem = 1;   // 0 off; 1 (default): the stride-2 stem (Res50: neutral in time, one launch and 25 MB per frame less); 2: also the
+                       // stride-4 stem of FaceBoxes (measured SLOWER there: 230 vs 182 us per batch of 16 -- 19 source pixels staged
+                       // per output pixel through byte loads; kept selectable, profiles/r04/fused_ingest_ab.txt)
+  const unsigned char* u8_src = nullptr;
+  float u8_mean[3] = {0.f, 0.f, 0.f};
+  float u8_scale = 1.0f;
+  bool last_fused = false;
+  const unsigned char* last_u8_src = nullptr;
   unsigned char* d_frames_u8 = nullptr;
   unsigned char* d_src_u8 = nullptr;   // un-resized source frames (host entry point of the resize ingest)
   size_t src_bytes = 0;
@@ -510,6 +528,19 @@ struct Builder {
       DevW dw;
       int r = device_weights(m, name, kind, op.tile, dw);
       if (r != FDT_OK) return fail(r);
+      // the stem on the input tensor also gets its raw-uint8 form (conv_stem_u8.h; Res50: 7x7 / 2 -> 64, FaceBoxes: 7x7 / 4 -> 24)
+      if (in_t == 0 && in.C == 3 && o.groups == 1 && !o.cout2 && o.res_t < 0 && o.up_t < 0 &&
+          (conv_base_kind(kind) == CONV_7x7_S2 || conv_base_kind(kind) == CONV_7x7_S4)) {
+        op.u8_kind = conv_base_kind(kind) == CONV_7x7_S2 ? CONV_7x7_S2_U8 : CONV_7x7_S4_U8;
+        op.u8_tile = conv_base_kind(kind) == CONV_7x7_S2 ? TILE_128x64W : TILE_128x32W;
+        if (conv_supported(op.u8_kind, op.u8_tile)) {
+          DevW du;
+          r = device_weights(m, name, op.u8_kind, op.u8_tile, du);
+          if (r != FDT_OK) return fail(r);
+          op.u8_w = du.w;
+          op.u8_stem = true;
+        }
+      }
       a.in = in.d;
       a.w = dw.w;
       a.bias = dw.bias;
@@ -1497,7 +1528,23 @@ int plan_reduces(fdt_model* m, int B) {
   return FDT_OK;
 }
 
-int run_ops(fdt_model* m, int B, hipStream_t st) {
+// The raw-frame stem of op (conv_stem_u8.h) on the uint8 frames of the forward being enqueued.
+int launch_u8_stem(fdt_model* m, const Op& op, hipStream_t st) {
+  ConvArgs a = op.ca;
+  a.in = nullptr;
+  a.in_u8 = m->u8_src;
+  for (int c = 0; c < 3; ++c) a.u8_mean[c] = m->u8_mean[c];
+  a.u8_scale = m->u8_scale;
+  a.w = op.u8_w;
+  a.ksplit = 1;
+  a.ws = nullptr;
+  a.sk_count = nullptr;
+  a.defer_reduce = 0;
+  a.map_mode = CONV_MAP_ROWS;
+  return launch_conv(op.u8_kind, op.u8_tile, a, st, m->device);
+}
+
+int run_ops(fdt_model* m, int B, hipStream_t st, size_t first_op = 0) {
   // per-op events (fdt_model_profile_enable) xor one event pair around a contiguous run of ops (fdt_model_profile_segment):
   // the second form leaves the launch sequence as it is in production -- lazy grouped reduce passes, no event packet
   // between two kernels -- and measures what the per-op sums cannot: the ops back to back
@@ -1512,7 +1559,7 @@ int run_ops(fdt_model* m, int B, hipStream_t st) {
     return FDT_OK;
   };
   exp_skip_reduce = m->passes > 0 && op_skipped("@reduce");   // (experiment builds only; once per pass)
-  for (size_t i = 0; i < m->ops.size(); ++i) {
+  for (size_t i = first_op; i < m->ops.size(); ++i) {
     const Op& op = m->ops[i];
     if (op.flush_before) FDT_TRY(flush());
     if (prof) FDT_HIP(hipEventRecord(m->ev[i], st));
@@ -1524,6 +1571,10 @@ int run_ops(fdt_model* m, int B, hipStream_t st) {
     if (m->passes > 0 && op_skipped(op.name)) continue;   // first pass complete: later ones read its (stale) maps
     switch (op.type) {
       case OP_CONV:
+        if (op.u8_stem && m->u8_src) {
+          FDT_TRY(launch_u8_stem(m, op, st));
+          break;
+        }
         FDT_TRY(launch_conv(op.kind, op.tile, op.ca, st, m->device));
         if (op.lazy) {
           if (npend == 64) FDT_TRY(flush());
@@ -1594,6 +1645,17 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
     FDT_TRY(ensure_profile_events(m));
     FDT_HIP(hipEventRecord(m->ev[m->ops.size() + 2], st));
   }
+  // Fused ingest (conv_stem_u8.h): with uint8 frames and a 7x7 stem on the input tensor, the (float)u8 - mean (/ 255) of
+  // iouTracke_cal.py:40-46 / My_test_facebox.py:14-15 happens in the stem conv's staging -- the f32 NCHW frame is never
+  // written.  The stem then reads the caller's device frames in place, the H2D landing buffer, or the resized uint8 image.
+  const bool fused = m->fuse_stem && format == FDT_FRAME_U8_HWC_BGR && !m->ops.empty() && m->ops[0].u8_stem &&
+                     (m->fuse_stem >= 2 || m->ops[0].u8_kind == CONV_7x7_S2_U8);
+  m->u8_src = nullptr;
+  if (fused) {
+    const bool fb = m->arch == FDT_ARCH_FACEBOX;
+    m->u8_mean[0] = fb ? 0.f : 104.f; m->u8_mean[1] = fb ? 0.f : 117.f; m->u8_mean[2] = fb ? 0.f : 123.f;
+    m->u8_scale = fb ? 255.0f : 1.0f;
+  }
   if (format == FDT_FRAME_U8_HWC_BGR && src_h > 0 && (src_h != H || src_w != W)) {
     // device-side ingest: cv2.resize(frame, (W, H)) + mean subtraction in one kernel
     const unsigned char* src = (const unsigned char*)frames;
@@ -1609,7 +1671,10 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
       FDT_HIP(hipMemcpyAsync(m->d_src_u8, frames, bytes, kind, st));
       src = m->d_src_u8;
     }
-    if (m->arch == FDT_ARCH_FACEBOX)
+    if (fused) {
+      FDT_TRY(launch_resize_u8(src, B, src_h, src_w, H, W, m->d_frames_u8, st));   // the resized uint8 image; the stem converts
+      m->u8_src = m->d_frames_u8;
+    } else if (m->arch == FDT_ARCH_FACEBOX)
       FDT_TRY(launch_resize_preprocess(src, B, src_h, src_w, H, W, 0.f, 0.f, 0.f, 255.0f, x, st));
     else
       FDT_TRY(launch_resize_preprocess(src, B, src_h, src_w, H, W, 104.f, 117.f, 123.f, 1.0f, x, st));
@@ -1619,19 +1684,27 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
       FDT_HIP(hipMemcpyAsync(m->d_frames_u8, frames, (size_t)B * H * W * 3, kind, st));
       src = m->d_frames_u8;
     }
-    if (m->arch == FDT_ARCH_FACEBOX)
+    if (fused)
+      m->u8_src = src;
+    else if (m->arch == FDT_ARCH_FACEBOX)
       FDT_TRY(launch_preprocess(src, B, H, W, 0.f, 0.f, 0.f, 255.0f, x, st));
     else
       FDT_TRY(launch_preprocess(src, B, H, W, 104.f, 117.f, 123.f, 1.0f, x, st));
   } else {
     FDT_HIP(hipMemcpyAsync(x, frames, (size_t)B * 3 * H * W * 4, kind, st));
   }
+  m->last_fused = m->u8_src != nullptr;
+  m->last_u8_src = m->u8_src;
   // everything after the ingest kernel: one hipGraphLaunch once the plan has run eagerly (which also sets the
   // per-function LDS attributes) -- the graph bakes in the plan, the output buffers and the thresholds
   float* out_p = out_dev ? out_dev : m->d_out;
   int* counts_p = counts_dev ? counts_dev : m->d_counts;
+  // graph path: the raw-frame stem reads a per-call pointer, so it runs eagerly in front of the graph (where the ingest kernel
+  // used to), and the graph covers the ops behind it
+  const size_t first_op = (m->use_graph && !m->profile && m->u8_src) ? 1 : 0;
+  if (first_op) FDT_TRY(launch_u8_stem(m, m->ops[0], st));
   auto body = [&]() -> int {
-    FDT_TRY(run_ops(m, B, st));
+    FDT_TRY(run_ops(m, B, st, first_op));
     if (run_detect && m->arch == FDT_ARCH_FACEBOX) {
       FDT_TRY(launch_facebox_decode(m->dplan, m->d_ws, m->d_loc, m->d_conf, m->d_priors, m->conf_t, m->nms_t,
                                     m->d_fb_boxes, m->d_fb_probs, counts_p, st));
@@ -1646,7 +1719,7 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
   };
   if (m->use_graph && !m->profile) {
     const GraphKey key{run_detect ? (const void*)out_p : nullptr, run_detect ? (const void*)counts_p : nullptr,
-                       run_detect ? 1 : 0, m->conf_t, m->nms_t};
+                       run_detect ? 1 : 0, m->conf_t, m->nms_t, (int)first_op};
     auto it = m->graphs.find(key);
     if (it != m->graphs.end()) {
       m->graph_used[key] = ++m->graph_clock;
@@ -1709,6 +1782,7 @@ extern "C" fdt_model* fdt_model_create(int arch, int device) {
     return nullptr;
   }
   if (const char* g = getenv("FDT_GRAPH")) m->use_graph = atoi(g) != 0;
+  if (const char* g = getenv("FDT_FUSE_INGEST")) m->fuse_stem = atoi(g);   // A/B: 0 = ingest kernel + planar stem conv, 2 = also FaceBoxes
   if (arch == FDT_ARCH_TRY3 || arch == FDT_ARCH_TRY4 || arch == FDT_ARCH_TRY5) {   // pyramid_mb2_try3.py:216
     m->conf_t = 0.2f;
     m->nms_t = 0.35f;
@@ -1776,7 +1850,14 @@ extern "C" fdt_model* fdt_model_clone(fdt_model* src) {
   m->hH = src->hH;
   m->hW = src->hW;
   m->use_graph = src->use_graph;
+  m->fuse_stem = src->fuse_stem;
   return m.release();
+}
+
+extern "C" int fdt_model_fuse_ingest(fdt_model* m, int on) {
+  FDT_REQUIRE(m, FDT_ERR_ARG, "fdt_model_fuse_ingest: null handle");
+  m->fuse_stem = on < 0 ? 0 : (on > 2 ? 2 : on);
+  return FDT_OK;
 }
 
 extern "C" int fdt_model_get_detect(fdt_model* m, int* top_k, float* conf_thresh, float* nms_thresh, int* nms_top_k) {
@@ -2151,6 +2232,16 @@ extern "C" int fdt_model_get_tensor(fdt_model* m, const char* name, float* out, 
     d[2] = 4;
     d[3] = 1;
   } else {
+    if (k == "input" && m->last_fused && m->last_u8_src && !m->tensors.empty()) {
+      // the fused ingest never wrote the f32 frame: form it now from the uint8 frames of the last forward (valid while the
+      // caller's device frames are; the library's own landing / resize buffers always are)
+      const bool fb = m->arch == FDT_ARCH_FACEBOX;
+      FDT_HIP(hipSetDevice(m->device));
+      FDT_HIP(hipDeviceSynchronize());
+      FDT_TRY(launch_preprocess(m->last_u8_src, m->pB, m->pH, m->pW, fb ? 0.f : 104.f, fb ? 0.f : 117.f, fb ? 0.f : 123.f,
+                                fb ? 255.0f : 1.0f, m->tensors[0].d, m->stream));
+      FDT_HIP(hipStreamSynchronize(m->stream));
+    }
     for (auto& t : m->tensors)
       if (t.name == k) {
         src = t.d;
@@ -2467,9 +2558,12 @@ extern "C" int fdt_model_profile_read(fdt_model* m, int max, char* names, float*
     if (flops) flops[i] = i < nops ? m->ops[i].flops : 0.0;
     if (names) {
       std::string nm = i < nops ? m->ops[i].name : std::string(i == nops ? "detect" : "ingest");
-      if (i < (int)m->ops.size() && m->ops[i].type == OP_CONV)
-        nm += "#k" + std::to_string((int)m->ops[i].kind) + "t" + std::to_string((int)m->ops[i].tile) + "s" +
-              std::to_string(m->ops[i].ca.ksplit);
+      if (i < (int)m->ops.size() && m->ops[i].type == OP_CONV) {
+        const Op& o_ = m->ops[i];
+        const bool u8 = o_.u8_stem && m->last_fused;      // the raw-frame stem ran in its place
+        nm += "#k" + std::to_string((int)(u8 ? o_.u8_kind : o_.kind)) + "t" + std::to_string((int)(u8 ? o_.u8_tile : o_.tile)) + "s" +
+              std::to_string(u8 ? 1 : o_.ca.ksplit);
+      }
       snprintf(names + (size_t)i * 48, 48, "%s", nm.c_str());
     }
   }

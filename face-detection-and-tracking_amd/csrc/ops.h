@@ -12,6 +12,7 @@ int launch_preprocess(const unsigned char* frames, int B, int H, int W, float m0
 
 // cv2.resize(frame, (W, H)) [INTER_LINEAR, 8UC3] fused with the ingest above: iouTracke_cal.py:123 +
 // :40-46, FACEBOX/My_test_facebox.py:13-15.  frames: [B][SH][SW][3] u8.
+int launch_resize_u8(const unsigned char* frames, int B, int SH, int SW, int H, int W, unsigned char* out, hipStream_t st);
 int launch_resize_preprocess(const unsigned char* frames, int B, int SH, int SW, int H, int W, float m0,
                              float m1, float m2, float div, float* out, hipStream_t st);
 

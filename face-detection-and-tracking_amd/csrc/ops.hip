@@ -43,7 +43,7 @@ __device__ __forceinline__ void resize_coef(int d, double scale, int ssize, int&
 
 __global__ void resize_preprocess_kernel(const unsigned char* __restrict__ in, int SH, int SW, int H, int W,
                                          double scale_y, double scale_x, float m0, float m1, float m2,
-                                         float div, float* __restrict__ out) {
+                                         float div, float* __restrict__ out, unsigned char* __restrict__ out_u8) {
   const int b = blockIdx.z;
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
@@ -63,6 +63,10 @@ __global__ void resize_preprocess_kernel(const unsigned char* __restrict__ in, i
     int h1 = r1[sx0 * 3 + c] * ax0 + r1[sx1 * 3 + c] * ax1;
     int v = ((((by0 * (h0 >> 4)) >> 16) + ((by1 * (h1 >> 4)) >> 16) + 2) >> 2);
     v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    if (out_u8) {      // the resized image itself, HWC like its source: the raw-frame stem conv (conv_stem_u8.h) converts it
+      out_u8[((long long)b * hw + (long long)y * W + x) * 3 + c] = (unsigned char)v;
+      continue;
+    }
     float f = (float)v - mean[c];
     if (div != 1.0f) f /= div;
     o[c * hw] = f;
@@ -506,7 +510,17 @@ int launch_resize_preprocess(const unsigned char* frames, int B, int SH, int SW,
   FDT_REQUIRE(H <= 65535 && B <= 65535, FDT_ERR_ARG, "resize: grid too large");
   dim3 grid(ceil_div(W, 64), H, B);
   hipLaunchKernelGGL(resize_preprocess_kernel, grid, dim3(64), 0, st, frames, SH, SW, H, W, (double)SH / H,
-                     (double)SW / W, m0, m1, m2, div, out);
+                     (double)SW / W, m0, m1, m2, div, out, (unsigned char*)nullptr);
+  FDT_LAUNCH_CHECK();
+  return FDT_OK;
+}
+
+// cv2.resize(src, (W, H)) alone: the resized uint8 HWC image (what the reference's detect_face() has before its float conversion)
+int launch_resize_u8(const unsigned char* frames, int B, int SH, int SW, int H, int W, unsigned char* out, hipStream_t st) {
+  FDT_REQUIRE(H <= 65535 && B <= 65535, FDT_ERR_ARG, "resize: grid too large");
+  dim3 grid(ceil_div(W, 64), H, B);
+  hipLaunchKernelGGL(resize_preprocess_kernel, grid, dim3(64), 0, st, frames, SH, SW, H, W, (double)SH / H,
+                     (double)SW / W, 0.f, 0.f, 0.f, 1.0f, (float*)nullptr, out);
   FDT_LAUNCH_CHECK();
   return FDT_OK;
 }

@@ -201,6 +201,12 @@ int fdt_model_set_priorbox(fdt_model* m, int width, int height, int n_levels,
 /* net.detect = Detect(2,0,top_k,conf_thresh,nms_thresh)  (My_test.py:36)                     */
 int fdt_model_set_detect(fdt_model* m, int top_k, float conf_thresh, float nms_thresh,
                          int nms_top_k);
+/* Fused ingest (on: 0 off, 1 = default: the stride-2 stem of Res50, 2 = also the stride-4 stem of FaceBoxes, where it measured
+ * slower and is therefore not the default; env FDT_FUSE_INGEST at create time): with uint8 frames and a 7x7 stem the
+ * (float)u8 - mean (/ 255) of iouTracke_cal.py:40-46 / My_test_facebox.py:14-15 happens inside the stem convolution's staging
+ * (csrc/conv_stem_u8.h) -- no f32 NCHW copy of the frame is written.  Same bits as the two-launch form (on = 0).  Tensor
+ * "input" is then formed on request (fdt_model_get_tensor) from the uint8 frames of the last forward.                     */
+int fdt_model_fuse_ingest(fdt_model* m, int on);
 int fdt_model_get_detect(fdt_model* m, int* top_k, float* conf_thresh, float* nms_thresh, int* nms_top_k);   /* any may be NULL */
 /* y = net(x)  pyramid.py:218-351 (Res50), pyramid_mb2_try3.py:218-340 (try3).
  * frames: B images in `format`; out: [B,2,top_k,5] f32; counts: [B,2] or NULL.               */

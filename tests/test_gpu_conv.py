@@ -15,9 +15,9 @@ KINDS = {  # name: (k, stride, pad, dil)
     "1x1s1": (1, 1, 0, 1), "1x1s2": (1, 2, 0, 1), "3x3s1": (3, 1, 1, 1), "3x3d2": (3, 1, 2, 2),
     "3x3s2": (3, 2, 1, 1), "7x7s2": (7, 2, 3, 1), "7x7s4": (7, 4, 3, 1), "5x5s2": (5, 2, 2, 1),
     "7x7s2p1": (7, 2, 1, 1)}
-N_TILES = 36      # 14 direct + 11 Winograd F(2x2,3x3) (3x3 s1 / d2 only) + 4 ring-of-four (1x1 only) + 2 quarter-split Winograd
+N_TILES = 37      # 14 direct + 11 Winograd F(2x2,3x3) (3x3 s1 / d2 only) + 4 ring-of-four (1x1 only) + 2 quarter-split Winograd
                   # + 1 packed-f32 VALU tile for narrow heads (3x3 s1 only) + 2 Winograd F(4x4,3x3) (3x3 s1 only)
-                  # + 2 persistent-tile 1x1 (1x1 s1 only)
+                  # + 2 persistent-tile 1x1 (1x1 s1 only) + the 4x32-px x 32-ch tile of the raw-frame FaceBoxes stem
 T_P64, T_P128 = 34, 35           # conv.h: TILE_P_128x64 / TILE_P_128x128 (kernel classes CONV_1x1_S1_P16 = 16, _P32 = 17)
 T_WINO44 = 32
 T_WINO44B = 33     # its twelve-wave form

@@ -214,3 +214,26 @@ def test_three_batches_in_flight_on_cloned_handles(net):
             assert np.array_equal(probs[b, :c[b]], want[b][1]) and np.array_equal(boxes[b, :c[b]], want[b][0])
     for c_ in clones:
         c_.close()
+
+
+def test_fused_ingest_facebox_bits(fb_sd):
+    """FaceBoxes: conv1 (7x7 / 4, 3 -> 24) on the raw uint8 frame with the /255 in its staging (conv_stem_u8.h, class 19) == the
+    ingest kernel + planar conv1, bit for bit, also behind the 4K resize."""
+    L = M("_lib")
+    d, _ = load_npz("facebox_r2")
+    frames = np.stack([d["img%d_frame" % i] for i in (0, 1)])
+    res = []
+    for fuse in (2, 0):                                  # 2: the stride-4 stem too (not the default: slower, DESIGN.md)
+        n = M("FACEBOX.networks").FaceBox()
+        n.load_state_dict(fb_sd)
+        L.check(L.lib().fdt_model_fuse_ingest(n._h, fuse))
+        r = n.detect_frames(frames)
+        SH, SW = 1080, 1920
+        yi = (np.arange(SH) * 1024) // SH
+        xi = (np.arange(SW) * 1024) // SW
+        r2 = n.detect_frames(np.ascontiguousarray(frames[:, yi][:, :, xi]))
+        res.append((r, r2, n.get_tensor("input").copy()))
+        n.close()
+    for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and len(a[1]) >= 3
+    assert np.array_equal(res[0][2], res[1][2])

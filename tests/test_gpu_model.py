@@ -539,3 +539,45 @@ def test_try3_with_fused_inverted_residual_heads(try3_sd, synth, monkeypatch):
     n = int((outs["0"][0, 1, :, 0] > 0).sum())
     d_iou, d_sc = match_detections(outs["1"][0, 1], outs["0"][0, 1], n)
     assert n > 5 and d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
+
+
+@pytest.mark.parametrize("H,W,B", [(136, 200, 1), (256, 256, 2), (480, 640, 1)])
+def test_fused_ingest_gives_the_bits_of_the_two_launch_form(res50_sd, synth, H, W, B):
+    """conv_stem_u8.h: the 7x7 stem reading the raw uint8 frame (mean subtraction in its staging) against preprocess_kernel +
+    the planar stem conv: same accumulation order -> the stem tensor, the Detect record and the (lazily formed) "input" tensor
+    are bit-identical; host frames, device frames, and the device-side resize in front (tiles hanging over the map, the
+    zero padding of the converted domain at every image border, two images)."""
+    import ctypes
+    L = M("_lib")
+    nets = []
+    for fuse in (1, 0):
+        n = M("pyramid").build_sfd('test', 640, 2)
+        n.load_state_dict(res50_sd)
+        n.priorbox = M("layers").PriorBoxLayer(W, H)
+        n.detect = M("layers").Detect(2, 0, 750, 0.05, 0.35)
+        L.check(L.lib().fdt_model_fuse_ingest(n._h, fuse))
+        nets.append(n)
+    frames = synth.make_frames(B, H, W, seed=3 * H + B)
+    outs = []
+    for n in nets:
+        y = n(frames if B > 1 else frames[0]).numpy()
+        outs.append((y, n.get_tensor("stem"), n.get_tensor("input")))
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][2], outs[1][2])
+    assert np.array_equal(outs[0][2], np.concatenate([opb.preprocess(f) for f in frames]))
+    # the fused handle really ran the raw-frame kernel (kernel class 18 = CONV_7x7_S2_U8), the other one the planar class 5
+    for n, k in zip(nets, ("#k18t", "#k5t")):
+        n.profile(True)
+        n(frames if B > 1 else frames[0])
+        assert n.profile_read()[0][0].startswith("conv1" + k), n.profile_read()[0][0]
+        n.profile(False)
+    # device frames (zero copy) and the resize ingest
+    fd = torch.from_numpy(frames).cuda()
+    ydev = [n(fd if B > 1 else fd[0]).numpy() for n in nets]
+    assert np.array_equal(ydev[0], ydev[1]) and np.array_equal(ydev[0], outs[0][0])
+    big = synth.make_frames(B, 2 * H + 6, 2 * W + 10, seed=5)
+    yr = [n.forward_resized(big, (W, H)).numpy() for n in nets]
+    assert np.array_equal(yr[0], yr[1])
+    assert np.array_equal(nets[0].get_tensor("input"), nets[1].get_tensor("input"))
+    for n in nets:
+        n.close()
