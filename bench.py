@@ -752,16 +752,24 @@ def main():
         (dk, dt_), dg = max(groups.items(), key=lambda kv: kv[1][1])
         # HBM bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (PMC
         # cannot be read from inside the process); the committed summary of the current round is quoted here.
-        traffic = traffic_src = traffic_cal = None
-        for rnd in ("r03", "r02", "r01"):
+        traffic = traffic_src = traffic_cal = traffic_classes = traffic_ratio = None
+        for rnd in ("r04", "r03", "r02", "r01"):
             tj = os.path.join(ROOT, "profiles", rnd, "conv_hbm_traffic.json")
             if args.arch == "res50" and H == 1024 and W == 1024 and os.path.exists(tj):
                 tdata = json.load(open(tj))
                 traffic = round(tdata["hbm_bytes_per_launch"])
                 if tdata.get("hbm_bytes_per_launch_calibrated"):
                     traffic_cal = round(tdata["hbm_bytes_per_launch_calibrated"])
-                traffic_src = "profiles/%s/conv_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, all conv " \
-                              "kernels, bytes/launch)" % rnd
+                if tdata.get("by_class"):       # round 4: read requests by SIZE CLASS (exact on a known-byte copy), per kernel class
+                    traffic_ratio = round(tdata["ratio"], 3)
+                    traffic_classes = [{"class": c["cls"], "launches_per_frame": c["launches_per_frame"], "ratio": c["ratio"],
+                                        "bytes_per_launch": c["bytes_per_launch"],
+                                        "algorithmic_bytes_per_launch": c["algorithmic_bytes_per_launch"]} for c in tdata["by_class"][:8]]
+                    traffic_src = "profiles/%s/conv_hbm_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B} / TCC_EA0_WRREQ{,_64B}: " \
+                                  "bytes by request size class, calibrated on a 1 GiB copy; per dispatch, joined with the op list)" % rnd
+                else:
+                    traffic_src = "profiles/%s/conv_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, all conv " \
+                                  "kernels, bytes/launch)" % rnd
                 break
         tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         step_ms = dt / args.steps * 1e3
@@ -780,10 +788,12 @@ def main():
             "algorithmic_gflop_per_launch": round(dg[2] / dg[0] / 1e9, 3),
             "executed_gflop_per_launch": round(dg[3] / dg[0] / 1e9, 3),
             "traffic": traffic, "traffic_source": traffic_src, "traffic_calibrated": traffic_cal,
+            "traffic_over_algorithmic": traffic_ratio, "traffic_by_class": traffic_classes,
             "traffic_note": ("QUOTED from the committed PMC summary named in traffic_source (separate rocprofv3 --pmc passes of "
                              "this command on an earlier run), NOT measured in this run: hardware counters cannot be read from "
                              "inside the process") if traffic is not None else None,
             "algorithmic_bytes_per_launch": round((3.52e9 + 0.2688e9) / 105) if args.arch == "res50" and H == 1024 and W == 1024 else None,
+            # (fdt_model_traffic counts the residual / upsample reads too: 38.2 MB per launch in profiles/r04/conv_hbm_traffic.json)
             # all conv launches of a frame (serial profile pass on one stream)
             "conv_stack": {"launches_per_frame": n_conv, "ms_per_frame": round(conv_ms / B, 3),
                            "algorithmic_gflop_per_frame": round(alg / B / 1e9, 3),

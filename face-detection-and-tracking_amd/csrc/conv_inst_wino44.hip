@@ -12,3 +12,12 @@ void conv_fill_wino44_d2(void* row) {
   r[TILE_WINO44_32x64] = wino44d2_entry();
 }
 }  // namespace fdt
+
+#ifdef FDT_W44_STAMPS
+extern "C" int fdt_debug_w44_times(long long* out) {
+  FDT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(fdt::g_w44_time), 64));
+  long long z[8] = {0};
+  FDT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(fdt::g_w44_time), z, 64));
+  return FDT_OK;
+}
+#endif

@@ -136,9 +136,19 @@ using W44 = W44T<true>;
 using W44odd = W44T<false>;
 using W44D2 = W44T<true, 2>;
 
+#ifdef FDT_W44_STAMPS   // diagnostic build (tools/experiments/w44_stamps.sh): where does a workgroup's time go?  Constant-rate clock
+__device__ long long g_w44_time[8];   // (100 MHz), summed over workgroups: [0] prologue [1] main loop [2] epilogue round 0 [3] round 1 [4] workgroups
+#define W44_STAMP(i) if (threadIdx.x == 0) { const long long c_ = wall_clock64(); atomicAdd((unsigned long long*)&g_w44_time[i], (unsigned long long)(c_ - w44_t_)); w44_t_ = c_; }
+#else
+#define W44_STAMP(i)
+#endif
+
 template <class T>
 __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef FDT_W44_STAMPS
+  long long w44_t_ = wall_clock64();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -570,6 +580,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
       if (!(FDT_W44_EXP & 16)) wait_ops(cur, N0{});                       // also: this wave's V writes are done
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
+    W44_STAMP(0)
     int s = 0;
     for (; s + 3 < nst; s += 4) {
       super_step(S0{}, X, Y, s);
@@ -594,6 +605,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     default: main_loop(std::integral_constant<int, 7>{}); break;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the (clamped) LDS-DMA of the k-steps past the end must not land in the exchange buffer
+  W44_STAMP(1)
 
   // ---- output transform Y = A^T M A,  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1] -----------------
   // This wave holds positions 9 pg .. 9 pg + 8 of M, i.e. (pg even) row 3 pg / 2 whole + columns 0..2 of the next row, or
@@ -741,8 +753,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
         }
       }
     }
+    W44_STAMP(2 + round)
   }
   if (wt) splitk_combine_tile<512>(a, b, sp_tile + a.n_sp * n_tile, n_tile * T::BN, T::BN, oy0, ox0, T::TH, T::TW, (unsigned*)smem);
+#ifdef FDT_W44_STAMPS
+  if (threadIdx.x == 0) atomicAdd((unsigned long long*)&g_w44_time[4], 1ull);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

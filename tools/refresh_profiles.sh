@@ -3,10 +3,10 @@
 # passes (FETCH_SIZE, WRITE_SIZE) summarised per kernel, MFMA-busy PMC of the dominant Winograd kernel and of the three
 # 1x1 instantiations that take the most time, the per-layer HIP-event table and the bench lines of the other
 # configurations.  Run through gpurun from the repo root:
-#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh r03'
+#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r04'
 # Outputs land in gpurun_out/profiles_<round>/ (copy them into profiles/<round>/ afterwards).
 set -e -o pipefail
-R=${1:-r03}
+R=${1:-r04}
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT /tmp/raw
 export TMPDIR=/tmp
@@ -24,16 +24,15 @@ B="python bench.py --steps 48 --warmup 8 --cpu-frames 0 --host-frames 0"
 timeout -k 10 400 python bench.py --steps 64 --warmup 8 > $OUT/bench_line_res50_1024.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt --output-format csv -- $B > $OUT/bench_under_rocprof.log 2>&1
 cp /tmp/raw/kt_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv
-# that command runs 8 priming + 8 warm-up + 48 timed + 56 parity (sequential re-run) + 5 profiled forwards
-python tools/rocprof_conv_summary.py $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv 125 $OUT/bench_line_res50_1024.json > $OUT/rocprof_vs_bench.txt
+# that command runs 16 priming (two per slot) + 8 warm-up + 48 timed + 56 parity (sequential re-run) + 5 per-op profiled + 2 x 5 segment-timed forwards
+python tools/rocprof_conv_summary.py $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv 143 $OUT/bench_line_res50_1024.json > $OUT/rocprof_vs_bench.txt
+# HBM traffic by request size class, per dispatch (tools/experiments/traffic_r4.sh has the calibration passes)
 P="python bench.py --steps 8 --warmup 2 --cpu-frames 0 --host-frames 0 --inflight 1 --profile-frames 1 --graph 0"
-for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/raw -o pmc_$C --output-format csv -- $P > /tmp/raw/pmc_$C.log 2>&1
-  python tools/summarize_pmc.py /tmp/raw/pmc_${C}_counter_collection.csv $OUT/pmc_${C}_by_kernel.csv
-done
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/raw -o calib --output-format csv -- python tools/one_conv.py 0 0 1 256 256 256 128 > /tmp/raw/calib.log 2>&1
-python tools/summarize_pmc.py /tmp/raw/calib_counter_collection.csv $OUT/pmc_FETCH_SIZE_calibration_1x1_67MB.csv
-python tools/traffic_json.py $OUT/pmc_FETCH_SIZE_by_kernel.csv $OUT/pmc_WRITE_SIZE_by_kernel.csv 105 $OUT/conv_hbm_traffic.json $OUT/pmc_FETCH_SIZE_calibration_1x1_67MB.csv
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d /tmp/raw -o fwd_rd --output-format csv -- $P > /tmp/raw/fwd_rd.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -d /tmp/raw -o fwd_wr --output-format csv -- $P > /tmp/raw/fwd_wr.log 2>&1
+python tools/dump_ops.py > $OUT/ops_1024.json 2> /tmp/raw/dump_ops.err
+CAL=""; [ -d profiles/$R/traffic ] && CAL=profiles/$R/traffic
+python tools/traffic_by_class.py /tmp/raw/fwd_rd_counter_collection.csv /tmp/raw/fwd_wr_counter_collection.csv $OUT/ops_1024.json $OUT/conv_hbm_traffic.json $CAL > $OUT/conv_hbm_traffic_summary.txt
 # matrix-pipe occupancy of the production kernels (one kernel per process; SQ counters + GRBM in one pass)
 #        name                       kind tile split cin  h   w  cout res
 pmc_one() {
@@ -56,7 +55,8 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VA
   python tools/summarize_pmc.py /tmp/raw/valu_head_counter_collection.csv $OUT/pmc_valu_head_512to8_256x256.csv || echo "head PMC pass failed (counters unavailable)" > $OUT/pmc_valu_head_512to8_256x256.csv
 echo "face_loc.0 $K_HEAD" >> $OUT/pmc_mfma_kernels.txt
 timeout -k 10 300 python tools/profile_layers.py > $OUT/per_layer_hip_events_res50_1024.txt
-timeout -k 10 300 python bench.py --steps 64 --warmup 8 --height 480 --width 640 > $OUT/bench_line_res50_640x480.json
+timeout -k 10 300 python bench.py --steps 256 --warmup 32 --height 480 --width 640 > $OUT/bench_line_res50_640x480.json
+timeout -k 10 300 python bench.py --steps 256 --warmup 32 --height 480 --width 640 --group 1 --cpu-frames 0 --host-frames 0 > $OUT/bench_line_res50_640x480_group1.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt480 --output-format csv -- python bench.py --steps 64 --warmup 8 --height 480 --width 640 --cpu-frames 0 --host-frames 0 > $OUT/bench_640x480_under_rocprof.log 2>&1
 cp /tmp/raw/kt480_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_res50_640x480.csv
 timeout -k 10 200 python tools/profile_layers.py --height 480 --width 640 > $OUT/per_layer_hip_events_res50_640x480.txt

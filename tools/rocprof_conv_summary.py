@@ -8,7 +8,10 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 frames = float(sys.argv[2])
-conv = [r for r in rows if "conv_kernel" in r["Name"] or "conv_wino" in r["Name"]]
+once = [r for r in rows if "head_finalize_all_kernel" in r["Name"]]     # launched exactly once per forward
+if once:
+    frames = float(sum(int(r["Calls"]) for r in once))                  # (the argument is only the fallback)
+conv = [r for r in rows if any(k in r["Name"] for k in ("conv_kernel", "conv_wino", "conv1x1p_kernel", "conv_stem_u8_kernel", "conv_n8_kernel"))]
 red = [r for r in rows if "splitk_reduce" in r["Name"]]
 tot = lambda rs: sum(float(r["TotalDurationNs"]) for r in rs)
 calls = lambda rs: sum(int(r["Calls"]) for r in rs)

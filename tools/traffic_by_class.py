@@ -22,7 +22,7 @@ TILE = ["128x128", "128x64", "128x32", "64x64", "64x128", "128x128W", "128x64W",
 
 
 def is_conv(n):
-    return ("conv_kernel" in n or "conv_wino" in n or "conv1x1p" in n or "conv_n8" in n) and "reduce" not in n
+    return any(k in n for k in ("conv_kernel", "conv_wino", "conv1x1p_kernel", "conv_stem_u8_kernel", "conv_n8_kernel")) and "reduce" not in n
 
 
 def per_dispatch(path):
