@@ -225,7 +225,17 @@ __device__ __forceinline__ void add_upsampled_x2(const float* __restrict__ u, in
 // Visibility across the XCDs' L2s (MI355X_MICROARCH.md, "Valid forms"): every slab byte is stored `sc1`
 // (write-through), every storing wave drains its stores (`s_waitcnt vmcnt(0)`) in front of the workgroup barrier behind
 // which ONE lane adds to the counter (agent scope), the last arriver's waves load the slabs only behind a barrier
-// that lane joins after its add has returned, and every slab load is a `buffer_load ... sc1`.
+// that lane joins after its add has returned, and every slab load is a `buffer_load ... sc1`.  That is the guide's
+// measured sc1-only hand-off -- measured at ONE workgroup per CU; the conv kernels run two to four.  So the ticket is
+// taken with ACQ_REL ordering at agent scope on top of it (round 4): the release half writes back whatever of this
+// workgroup's stores an L2 still holds before the add, the acquire half invalidates the adding CU's L1 before the last
+// arriver's waves are released to their loads.  The feature is off in every committed plan (docs/EXPERIMENTS.md R3-4:
+// not faster); where it is used, it rests on the architectural form, with the sc1 path as the fast case.
+// Data-register hazard of the hand-written stores: a store of MORE than 8 bytes reads its data registers up to two wait
+// states after issue (hence `s_nop 1` behind the dwordx4 form); the dwordx2 / dword forms read theirs at issue.
+// One counter array serves all layers of a handle: correct because a handle's convs run strictly in order on one stream
+// (the last arriver of a tile resets its counter before the launch ends, and the next launch that uses it is ordered
+// behind this one) -- a caller that runs two convs of one handle concurrently must give them separate counters.
 typedef float slab_f4 __attribute__((ext_vector_type(4)));
 typedef float slab_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void slab_store4(float* p, float x, float y, float z, float w, bool wt) {
@@ -264,7 +274,8 @@ __device__ __forceinline__ void splitk_combine_tile(const ConvArgs& a, int b, in
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned* c = a.sk_count + (long long)b * a.n_sp * a.n_ct + tile_id;
-    const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the acquire's L1 invalidate has completed before the barrier below releases the other waves
     const unsigned last = old == (unsigned)a.ksplit - 1u ? 1u : 0u;
     if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     *flag = last;

@@ -13,7 +13,13 @@
 //   * the depthwise 3x3 reads that tile (taps in the stand-alone kernel's order, + bias, ReLU6) and stores 16-byte
 //     strips of the output.
 // 50-80 KB of LDS per workgroup -> two or three workgroups per CU, so one's GEMM phase overlaps the other's stencil
-// phase.  The 1x1 project conv that follows stays a separate launch (its input is 6x smaller than the expanded map).
+// phase.
+// Round 4 (PROJ): the 1x1 project conv + BN (+ the residual of a stride-1, inp == oup block; pyramid_mb2_try3.py:115-134) runs in
+// the same kernel for oup <= 32: the depthwise output of a chunk stays in LDS (it overwrites the chunk's rows of the expanded
+// tile, which its own wave has just consumed) and feeds a [oup x 32] x [32 x pixels] GEMM on the f32 MFMA whose accumulator
+// lives across the chunks -- same k pairing and order as the stand-alone 1x1 kernel, so the block's output is bit-identical;
+// the residual is read from the staged input patch.  The hidden tensor (6x the input) then never reaches HBM at all, and the
+// block is one launch instead of two.
 #include <atomic>
 
 #include "common.h"
@@ -46,16 +52,23 @@ struct IrTile {
 // grid: (tiles_x * tiles_y, 1, B); 256 threads; dynamic LDS: (Cin + 32) * NPOSP + 32 * Cin floats.
 // KS = Cin / 2 when known at compile time (the GEMM loop is then fully unrolled: all operand reads of a column tile are in
 // flight before its first MFMA), 0 = runtime loop.
-template <int S, int KS>
+template <int S, int KS, bool PROJ = false>
 __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict__ x, int Cin, int H, int W,
                                                         const float* __restrict__ w1, const float* __restrict__ b1,
                                                         const float* __restrict__ wdw, const float* __restrict__ bdw,
-                                                        int hid, float* __restrict__ out, int Ho, int Wo) {
+                                                        int hid, float* __restrict__ out, int Ho, int Wo,
+                                                        const float* __restrict__ wp = nullptr, const float* __restrict__ bp = nullptr,
+                                                        int oup = 0, int residual = 0) {
   using T = IrTile<S>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                                   // [Cin][NPOSP]
   float* hs = smem + (size_t)Cin * T::NPOSP;          // [32][NPOSP]
   float* ws = hs + 32 * T::NPOSP;                     // [Cin][32]: this chunk's expand weights, k-major (A operand)
+  float* wps = ws + 32 * Cin;                         // PROJ: [2][32 k][32 oup] project weights of the chunk, double buffered
+  constexpr int NPX = T::TH * T::TW;                  // output pixels of the tile: 128 (stride 1) / 64 (stride 2)
+  f32x16 pacc;                                        // PROJ: out[oup rows][32 pixels of this wave's tile row], across the chunks
+#pragma unroll
+  for (int r = 0; r < 16; ++r) pacc[r] = 0.0f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int tiles_x = (Wo + T::TW - 1) / T::TW;
@@ -104,6 +117,14 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict_
       const int k = e >> 5, rr = e & 31;
       const int hw = ch * 32 + rr;
       ws[e] = hw < hid ? w1[(long long)hw * Cin + k] : 0.0f;
+    }
+    if constexpr (PROJ) {   // wps[k][o] = Wp[o][chunk's hidden channel k]; zeros past oup / hid (the padded rows then add 0)
+      float* wq = wps + (ch & 1) * 1024;
+      for (int e = tid; e < 1024; e += 256) {
+        const int k = e >> 5, o = e & 31;
+        const int hw = ch * 32 + k;
+        wq[e] = (o < oup && hw < hid) ? wp[(long long)o * hid + hw] : 0.0f;
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the patch (first chunk) has landed
     __syncthreads();
@@ -205,6 +226,20 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict_
         }
         const int ox = ox0 + cg * 4;
         float* ob = out + ((long long)b * hid + hc) * Ho * Wo;
+        if constexpr (PROJ) {
+          // the chunk's depthwise output stays in LDS as the project GEMM's B operand, in the first NPX floats of this
+          // channel's row of the expanded tile: the eight threads of a channel sit in one wave and have all read their
+          // strips above (LDS operations of a wave complete in order), no other wave touches this row
+          __builtin_amdgcn_wave_barrier();
+          float* dsr = hs + (size_t)cl * T::NPOSP + cg * 4;
+#pragma unroll
+          for (int o = 0; o < T::TH; ++o) {
+            float4 y;
+            y.x = fminf(fmaxf(acc[o][0] + bb, 0.0f), 6.0f); y.y = fminf(fmaxf(acc[o][1] + bb, 0.0f), 6.0f);
+            y.z = fminf(fmaxf(acc[o][2] + bb, 0.0f), 6.0f); y.w = fminf(fmaxf(acc[o][3] + bb, 0.0f), 6.0f);
+            *reinterpret_cast<float4*>(dsr + o * T::TW) = y;
+          }
+        } else
 #pragma unroll
         for (int o = 0; o < T::TH; ++o) {
           const int oy = oy0 + o;
@@ -223,6 +258,44 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict_
       }
     }
     __syncthreads();
+    if constexpr (PROJ) {
+      // ---- project: pacc[oup][pixels] += Wp[:, chunk] . dw[chunk][pixels]; wave w owns tile row w (32 pixels); channel
+      // pairs ascending = the k order of the stand-alone 1x1 kernel.  (The padded hidden channels of a last, partly filled
+      // chunk hold ReLU6(0 + 0) = 0 from the expand phase and zero weights here.)
+      if (wave < T::TH) {
+        const float* acol = wps + (ch & 1) * 1024 + half * 32 + l31;
+        const float* bcol = hs + (size_t)half * T::NPOSP + wave * T::TW + l31;
+        float av[16], bw[16];
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+          av[s2] = acol[s2 * 64];
+          bw[s2] = bcol[(size_t)s2 * 2 * T::NPOSP];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bw[s2], pacc, 0, 0, 0);
+      }
+      // no barrier here: the next chunk's expand writes hs only behind its own barrier, which every wave reaches after this
+      // phase; the project weights are double buffered
+    }
+  }
+  if constexpr (PROJ) {
+    // ---- epilogue of the block: + folded BN bias, + residual (the block's own input, from the staged patch), no activation
+    // (pyramid_mb2_try3.py:115-117: linear bottleneck); lane = pixel l31 of tile row `wave`, register r = output channel
+    if (wave < T::TH) {
+      const int oy = oy0 + wave, ox = ox0 + l31;
+      if (oy < Ho && ox < Wo) {
+        float* ob = out + (long long)b * oup * Ho * Wo + (long long)oy * Wo + ox;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (o < oup) {
+            float v = pacc[r] + bp[o];
+            if (residual) v += xs[(size_t)o * T::NPOSP + (wave + 1) * T::PWP + l31 + 1];   // stride 1, inp == oup: x[o][oy][ox]
+            ob[(long long)o * Ho * Wo] = v;
+          }
+        }
+      }
+    }
   }
 }
 
@@ -233,6 +306,7 @@ size_t expand_dw_lds_bytes(int Cin, int stride, int hid) {
   (void)hid;
   return ((size_t)(Cin + 32) * npp + 32 * (size_t)Cin) * sizeof(float);
 }
+size_t ir_block_lds_bytes(int Cin, int stride, int hid) { return expand_dw_lds_bytes(Cin, stride, hid) + 2 * 1024 * sizeof(float); }
 
 int launch_expand_dw(const float* x, int B, int Cin, int H, int W, const float* w1, const float* b1, const float* wdw,
                      const float* bdw, int hid, int stride, float* out, int Ho, int Wo, hipStream_t st, int dev) {

@@ -237,3 +237,33 @@ def test_fused_ingest_facebox_bits(fb_sd):
     for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and len(a[1]) >= 3
     assert np.array_equal(res[0][2], res[1][2])
+
+
+def test_config5_as_baseline_words_it_4k_sources_and_batch_16_in_one_call(net, fb_sd):
+    """BASELINE.json configs[4] in ONE call: sixteen 2160x3840 uint8 sources (the six multi-face images, pixel-replicated like
+    bench.py builds its frames) resized on the GPU and detected as one batch.  Image b of the batch equals the single-image call
+    bit for bit (images of a batch do not see each other), the resized input of every image is bit-exact against the oracle's
+    resize, and the faces match the oracle end to end."""
+    from oracle import ingest as oin
+    d, meta = load_npz("facebox_r2")
+    SH, SW, B = 2160, 3840, 16
+    yi = (np.arange(SH) * 1024) // SH
+    xi = (np.arange(SW) * 1024) // SW
+    uniq = [np.ascontiguousarray(d["img%d_frame" % i][yi][:, xi]) for i in range(6)]
+    frames = np.stack([uniq[b % 6] for b in range(B)])                 # 398 MB of sources
+    res = net.detect_frames(frames)
+    x = net.get_tensor("input")
+    assert x.shape == (B, 3, 1024, 1024)
+    singles = [net.detect_frames(u[None])[0] for u in uniq]
+    for b, (bx, pr) in enumerate(res):
+        sb, sp = singles[b % 6]
+        assert np.array_equal(pr, sp) and np.array_equal(bx, sb) and len(pr) >= 3
+    for i in range(6):
+        small = oin.resize_linear_u8(uniq[i], 1024, 1024)
+        assert np.array_equal(x[i], small.transpose(2, 0, 1).astype(np.float32) / np.float32(255))
+        assert np.array_equal(x[i + 6], x[i])
+        rb, rp = ofb.detect(fb_sd, small)
+        bx, pr = res[i]
+        assert len(pr) == len(rp)
+        iou = opp.calculate_iou(rb.astype(np.float64), bx.astype(np.float64))
+        assert (1 - iou.max(1)).max() <= 1e-3 and np.abs(pr[iou.argmax(1)] - rp).max() <= 1e-4
