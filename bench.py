@@ -737,9 +737,9 @@ def main():
                         (layer.startswith("features.") or layer.startswith("layer6.") or layer.startswith("smooth_")):
                     dwb += float(per_op_bytes[j_])
                     dwm += ms
-                    dw_kernels.add("expand_dw_kernel (1x1 expand + depthwise 3x3 fused)" if layer.endswith(".expand_dw")
+                    dw_kernels.add("expand_dw_kernel (1x1 expand + depthwise 3x3 (+ 1x1 project) fused)" if layer.endswith((".expand_dw", ".expand_dw_project"))
                                    else "dwconv3_vec_kernel (depthwise 3x3 + BN + ReLU6)")
-                if layer.endswith(".expand_dw"):      # its 1x1 expand runs on the matrix cores: part of the conv stack too
+                if layer.endswith((".expand_dw", ".expand_dw_project")):      # its 1x1 GEMMs run on the matrix cores: part of the conv stack too
                     other_ms -= ms
                     conv_ms += ms; alg += fl; exe += fl; n_conv += 1
                 continue

@@ -58,6 +58,8 @@ SIGNATURES = {
     "fdt_conv2d": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "fdt_expand_dw": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "fdt_ir_block": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int,
+                               _vp]),
     "fdt_facebox_anchors": (C.c_int, [_vp]),
     "fdt_facebox_decode": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_float, C.c_float, _vp, _vp, _c_int_p]),
     "fdt_tracker_create": (_vp, [C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]),

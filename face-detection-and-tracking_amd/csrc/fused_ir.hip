@@ -318,7 +318,7 @@ int launch_expand_dw(const float* x, int B, int Cin, int H, int W, const float* 
   const int th = stride == 1 ? IrTile<1>::TH : IrTile<2>::TH;
   dim3 grid((unsigned)(ceil_div(Wo, 32) * ceil_div(Ho, th)), 1, (unsigned)B);
   typedef void (*Kern)(const float*, int, int, int, const float*, const float*, const float*, const float*, int, float*, int,
-                       int);
+                       int, const float*, const float*, int, int);
   const int ks = Cin >> 1;
   Kern fn = nullptr;
   if (stride == 1)
@@ -337,12 +337,77 @@ int launch_expand_dw(const float* x, int B, int Cin, int H, int W, const float* 
   } else if (dev >= 16) {
     FDT_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
-  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, x, Cin, H, W, w1, b1, wdw, bdw, hid, out, Ho, Wo);
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, x, Cin, H, W, w1, b1, wdw, bdw, hid, out, Ho, Wo, (const float*)nullptr,
+                     (const float*)nullptr, 0, 0);
+  FDT_LAUNCH_CHECK();
+  return FDT_OK;
+}
+
+// The whole InvertedResidual block (expand + depthwise + project (+ residual)) as one launch; oup <= 32.
+int launch_ir_block(const float* x, int B, int Cin, int H, int W, const float* w1, const float* b1, const float* wdw,
+                    const float* bdw, int hid, int stride, const float* wp, const float* bp, int oup, int residual, float* out,
+                    int Ho, int Wo, hipStream_t st, int dev) {
+  FDT_REQUIRE(stride == 1 || stride == 2, FDT_ERR_ARG, "ir_block: stride %d", stride);
+  FDT_REQUIRE(Cin >= 2 && (Cin & 1) == 0 && hid >= 1 && B >= 1 && B <= 65535 && oup >= 1 && oup <= 32 && wp && bp, FDT_ERR_ARG,
+              "ir_block: bad channel counts (the fused project handles up to 32 output channels)");
+  FDT_REQUIRE(!residual || (stride == 1 && oup == Cin), FDT_ERR_ARG, "ir_block: a residual block has stride 1 and inp == oup");
+  FDT_REQUIRE(Ho == (H - 1) / stride + 1 && Wo == (W - 1) / stride + 1, FDT_ERR_ARG, "ir_block: output size mismatch");
+  const size_t lds = ir_block_lds_bytes(Cin, stride, hid);
+  FDT_REQUIRE(lds <= 160 * 1024, FDT_ERR_ARG, "ir_block: %d -> %d channels do not fit LDS", Cin, hid);
+  const int th = stride == 1 ? IrTile<1>::TH : IrTile<2>::TH;
+  dim3 grid((unsigned)(ceil_div(Wo, 32) * ceil_div(Ho, th)), 1, (unsigned)B);
+  typedef void (*Kern)(const float*, int, int, int, const float*, const float*, const float*, const float*, int, float*, int,
+                       int, const float*, const float*, int, int);
+  const int ks = Cin >> 1;
+  Kern fn = nullptr;
+  if (stride == 1)
+    fn = ks == 8 ? expand_dw_kernel<1, 8, true> : ks == 12 ? expand_dw_kernel<1, 12, true> : ks == 16 ? expand_dw_kernel<1, 16, true>
+                                                                                                    : expand_dw_kernel<1, 0, true>;
+  else
+    fn = ks == 8 ? expand_dw_kernel<2, 8, true> : ks == 12 ? expand_dw_kernel<2, 12, true> : ks == 16 ? expand_dw_kernel<2, 16, true>
+                                                                                                    : expand_dw_kernel<2, 0, true>;
+  static std::atomic<unsigned long long> seen[16];
+  if (dev < 0) FDT_HIP(hipGetDevice(&dev));
+  const int slot = (stride - 1) * 4 + (ks == 8 ? 0 : ks == 12 ? 1 : ks == 16 ? 2 : 3);
+  if (dev >= 16 || !((seen[dev].load(std::memory_order_acquire) >> slot) & 1ull)) {
+    FDT_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (dev < 16) seen[dev].fetch_or(1ull << slot, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, x, Cin, H, W, w1, b1, wdw, bdw, hid, out, Ho, Wo, wp, bp, oup, residual);
   FDT_LAUNCH_CHECK();
   return FDT_OK;
 }
 
 }  // namespace fdt
+
+// Stand-alone op (host pointers): the whole InvertedResidual of pyramid_mb2_try3.py:96-134 with expand_ratio != 1 and its
+// BatchNorms folded: y = BN(conv1x1_project(ReLU6(BN(dw3x3(ReLU6(BN(conv1x1_expand(x)))))))) (+ x for a stride-1, inp == oup block).
+extern "C" int fdt_ir_block(const float* x, int B, int Cin, int H, int W, const float* w1, const float* b1, const float* wdw,
+                            const float* bdw, int hid, int stride, const float* wp, const float* bp, int oup, int residual,
+                            float* out) {
+  const hipStream_t st = fdt::thread_stream();   // never the legacy stream (common.h)
+  using namespace fdt;
+  FDT_REQUIRE(x && w1 && b1 && wdw && bdw && wp && bp && out && B >= 1 && H >= 1 && W >= 1 && oup >= 1, FDT_ERR_ARG, "fdt_ir_block: bad argument");
+  FDT_REQUIRE(stride == 1 || stride == 2, FDT_ERR_ARG, "fdt_ir_block: stride must be 1 or 2");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  FDT_REQUIRE(st, FDT_ERR_HIP, "%s: could not create the calling thread's private stream", __func__);
+  DevBuf dx, dw1, db1, dwd, dbd, dwp, dbp, dout;
+  const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * oup * Ho * Wo;
+  FDT_TRY(dx.alloc(nx * 4)); FDT_TRY(dw1.alloc((size_t)hid * Cin * 4)); FDT_TRY(db1.alloc((size_t)hid * 4));
+  FDT_TRY(dwd.alloc((size_t)hid * 36)); FDT_TRY(dbd.alloc((size_t)hid * 4)); FDT_TRY(dwp.alloc((size_t)oup * hid * 4));
+  FDT_TRY(dbp.alloc((size_t)oup * 4)); FDT_TRY(dout.alloc(no * 4));
+  FDT_HIP(copy_sync(dx.p, x, nx * 4, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(dw1.p, w1, (size_t)hid * Cin * 4, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(db1.p, b1, (size_t)hid * 4, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(dwd.p, wdw, (size_t)hid * 36, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(dbd.p, bdw, (size_t)hid * 4, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(dwp.p, wp, (size_t)oup * hid * 4, hipMemcpyHostToDevice, st));
+  FDT_HIP(copy_sync(dbp.p, bp, (size_t)oup * 4, hipMemcpyHostToDevice, st));
+  FDT_TRY(launch_ir_block(dx.as<float>(), B, Cin, H, W, dw1.as<float>(), db1.as<float>(), dwd.as<float>(), dbd.as<float>(), hid,
+                          stride, dwp.as<float>(), dbp.as<float>(), oup, residual, dout.as<float>(), Ho, Wo, st, -1));
+  FDT_HIP(copy_sync(out, dout.p, no * 4, hipMemcpyDeviceToHost, st));
+  return FDT_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Stand-alone op (host pointers): ReLU6(BN(dw3x3(ReLU6(BN(conv1x1(x)))))) with the BatchNorms already folded into

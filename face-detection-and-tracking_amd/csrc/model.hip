@@ -54,6 +54,9 @@ struct Op {
   const float* bias = nullptr;
   const float* w2 = nullptr;     // OP_EXPDW: depthwise taps / bias (w, bias = the 1x1 expand)
   const float* bias2 = nullptr;
+  const float* w3 = nullptr;     // OP_EXPDW with the block's 1x1 project in the same kernel (fused_ir.hip: PROJ): [oup][hid] / [oup]
+  const float* bias3 = nullptr;
+  int oup = 0, residual = 0;
   int hid = 0;
   int level0 = 0, p_off = 0, anchors = 1;
   bool needs_ws = false;
@@ -668,26 +671,32 @@ struct Builder {
 
   // conv[0..5] of an InvertedResidual with expand_ratio != 1 as ONE kernel (fused_ir.hip): 1x1 expand + BN + ReLU6 and the
   // depthwise 3x3 + BN + ReLU6; the expanded tensor never reaches HBM.  pyramid_mb2_try3.py:96-114.
-  int expand_dw(const std::string& p, int in_t, int hid, int stride) {
+  // oup > 0: the block's 1x1 project conv (conv.6) + BN (conv.7) (+ residual) in the same kernel: the whole block, output [oup]
+  int expand_dw(const std::string& p, int in_t, int hid, int stride, int oup = 0, bool residual = false) {
     if (rc != FDT_OK) return -1;
     const Tensor in = m->tensors[in_t];
     const int Ho = (in.H - 1) / stride + 1, Wo = (in.W - 1) / stride + 1;
-    const std::string n1 = p + ".conv.0", bn1 = p + ".conv.1", n2 = p + ".conv.3", bn2 = p + ".conv.4";
-    int out_t = new_tensor(n2, hid, Ho, Wo);
+    const std::string n1 = p + ".conv.0", bn1 = p + ".conv.1", n2 = p + ".conv.3", bn2 = p + ".conv.4", n3 = p + ".conv.6",
+                      bn3 = p + ".conv.7";
+    int out_t = oup ? new_tensor(n3, oup, Ho, Wo) : new_tensor(n2, hid, Ho, Wo);
     if (out_t < 0) return -1;
     const HostT* w1 = get(n1 + ".weight");
     const HostT* w2 = get(n2 + ".weight");
-    std::vector<float> s1, b1, s2, b2;
+    const HostT* w3 = oup ? get(n3 + ".weight") : nullptr;
+    std::vector<float> s1, b1, s2, b2, s3, b3;
     fold(bn1, nullptr, hid, s1, b1);
     fold(bn2, nullptr, hid, s2, b2);
+    if (oup) fold(bn3, nullptr, oup, s3, b3);
     Op op;
     op.type = OP_EXPDW;
-    op.name = p + ".expand_dw";
+    op.name = p + (oup ? ".expand_dw_project" : ".expand_dw");
     op.in_t = in_t;
     op.out_t = out_t;
     op.stride = stride;
     op.hid = hid;
-    op.flops = 2.0 * B * ((double)in.H * in.W * in.C * hid + (double)Ho * Wo * hid * 9);
+    op.oup = oup;
+    op.residual = residual ? 1 : 0;
+    op.flops = 2.0 * B * ((double)in.H * in.W * in.C * hid + (double)Ho * Wo * hid * 9 + (double)Ho * Wo * hid * oup);
     memset(&op.ca, 0, sizeof(op.ca));
     if (!m->dry) {
       if (rc != FDT_OK) return -1;
@@ -723,6 +732,30 @@ struct Builder {
       op.bias = d1.bias;
       op.w2 = d2.w;
       op.bias2 = d2.bias;
+      if (oup) {
+        if ((int)w3->v.size() != oup * hid) {
+          set_error("weight shape mismatch for the project conv of the fused block %s", p.c_str());
+          return fail(FDT_ERR_STATE);
+        }
+        DevW d3;
+        auto it3 = m->W->wcache.find(p + "|expdw3");
+        if (it3 == m->W->wcache.end()) {
+          std::vector<float> a(w3->v);
+          for (int c = 0; c < oup; ++c)
+            for (int k = 0; k < hid; ++k) a[(size_t)c * hid + k] *= s3[c];     // the folding conv() applies to a 1x1 (one rounding per weight)
+          if (hipMalloc((void**)&d3.w, a.size() * 4) != hipSuccess || hipMalloc((void**)&d3.bias, (size_t)oup * 4) != hipSuccess) {
+            set_error("hipMalloc failed for %s", p.c_str());
+            return fail(FDT_ERR_HIP);
+          }
+          (void)copy_sync(d3.w, a.data(), a.size() * 4, hipMemcpyHostToDevice, m->stream);
+          (void)copy_sync(d3.bias, b3.data(), (size_t)oup * 4, hipMemcpyHostToDevice, m->stream);
+          m->W->wcache[p + "|expdw3"] = d3;
+        } else {
+          d3 = it3->second;
+        }
+        op.w3 = d3.w;
+        op.bias3 = d3.bias;
+      }
     }
     m->ops.push_back(op);
     m->flops_per_frame += op.flops / B;
@@ -899,6 +932,14 @@ struct Builder {
     bool fuse = t != 1 && (inp & 1) == 0 && (stride == 1 || stride == 2) && (long long)xin.H * xin.W >= 256ll * 256;
     if (const char* e = getenv("FDT_FUSE_IR")) fuse = t != 1 && (inp & 1) == 0 && atoi(e) != 0;
     if (fuse && expand_dw_lds_bytes(inp, stride, hid) > 80 * 1024) fuse = false;   // keep two workgroups per CU
+    // round 4: the 1x1 project + BN (+ residual) can run in the same kernel when the block has at most 32 output channels
+    // (fused_ir.hip: PROJ; one launch per block, bit-identical).  Measured on try3 at batch 8 it is 2 % SLOWER end to end
+    // (2001-2018 vs 2052-2060 frames/s: the kernel is bound by its three barriers per chunk, and the project phase adds a
+    // dependent 16-MFMA chain inside them, while the launch it saves was overlapped anyway; docs/EXPERIMENTS.md R4-9) --
+    // so it is opt-in: FDT_FUSE_IR=2 (0 none, 1 expand + depthwise wherever it fits, unset: that on the large maps).
+    const int fuse_env = getenv("FDT_FUSE_IR") ? atoi(getenv("FDT_FUSE_IR")) : -1;
+    if (fuse && oup <= 32 && fuse_env == 2 && ir_block_lds_bytes(inp, stride, hid) <= 80 * 1024)
+      return expand_dw(p, h, hid, stride, oup, stride == 1 && inp == oup);
     if (fuse) {
       h = expand_dw(p, h, hid, stride);
       i += 6;
@@ -1604,8 +1645,12 @@ int run_ops(fdt_model* m, int B, hipStream_t st, size_t first_op = 0) {
       case OP_EXPDW: {
         const Tensor& in = m->tensors[op.in_t];
         const Tensor& out = m->tensors[op.out_t];
-        FDT_TRY(launch_expand_dw(in.d, B, in.C, in.H, in.W, op.w, op.bias, op.w2, op.bias2, op.hid, op.stride, out.d, out.H,
-                                 out.W, st, m->device));
+        if (op.oup)
+          FDT_TRY(launch_ir_block(in.d, B, in.C, in.H, in.W, op.w, op.bias, op.w2, op.bias2, op.hid, op.stride, op.w3, op.bias3, op.oup,
+                                  op.residual, out.d, out.H, out.W, st, m->device));
+        else
+          FDT_TRY(launch_expand_dw(in.d, B, in.C, in.H, in.W, op.w, op.bias, op.w2, op.bias2, op.hid, op.stride, out.d, out.H,
+                                   out.W, st, m->device));
         break;
       }
       case OP_HEADFIN:
@@ -2590,8 +2635,8 @@ extern "C" int fdt_model_traffic(fdt_model* m, double* act_bytes, double* weight
       if (op.ca.up) b += 4.0 * op.ca.B * (double)op.ca.Cout * op.ca.up_h * op.ca.up_w;
       w = 4.0 * ((double)op.ca.Cout * op.ca.Cin * g.kh * g.kw + op.ca.Cout);
     } else if (op.type == OP_EXPDW) {
-      b = tb(op.in_t) + tb(op.out_t);
-      w = 4.0 * op.hid * (m->tensors[op.in_t].C + 1 + 9 + 1);
+      b = tb(op.in_t) + tb(op.out_t);        // (the residual of a whole-block launch is the staged input itself)
+      w = 4.0 * op.hid * (m->tensors[op.in_t].C + 1 + 9 + 1) + 4.0 * op.oup * (op.hid + 1);
     } else if (op.type == OP_HEADFIN || op.type == OP_MBOXFIN) {
       b = 2.0 * tb(op.in_t);
     } else {

@@ -67,5 +67,10 @@ int launch_multibox_finalize(const float* locmap, const float* confmap, long lon
 int launch_expand_dw(const float* x, int B, int Cin, int H, int W, const float* w1, const float* b1, const float* wdw,
                      const float* bdw, int hid, int stride, float* out, int Ho, int Wo, hipStream_t st, int device = -1);
 size_t expand_dw_lds_bytes(int Cin, int stride, int hid);
+// ... and with the 1x1 project conv + BN (+ residual) of the block in the same kernel (oup <= 32): the whole InvertedResidual
+int launch_ir_block(const float* x, int B, int Cin, int H, int W, const float* w1, const float* b1, const float* wdw,
+                    const float* bdw, int hid, int stride, const float* wp, const float* bp, int oup, int residual, float* out,
+                    int Ho, int Wo, hipStream_t st, int dev);
+size_t ir_block_lds_bytes(int Cin, int stride, int hid);
 
 }  // namespace fdt

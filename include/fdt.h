@@ -145,6 +145,10 @@ int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const float* w_oihw
  * (host pointers; the detector graphs use the same kernel on device tensors).  Cin even.                          */
 int fdt_expand_dw(const float* x, int B, int Cin, int H, int W, const float* w1, const float* b1, const float* wdw,
                   const float* bdw, int hid, int stride, float* out);
+/* The whole InvertedResidual (pyramid_mb2_try3.py:96-134, expand_ratio != 1, BatchNorms folded) in one launch: expand, depthwise,
+ * 1x1 project (wp [oup][hid], bp [oup]; oup <= 32) and, residual != 0 (stride 1, oup == Cin), + x.  out: [B][oup][Ho][Wo].      */
+int fdt_ir_block(const float* x, int B, int Cin, int H, int W, const float* w1, const float* b1, const float* wdw,
+                 const float* bdw, int hid, int stride, const float* wp, const float* bp, int oup, int residual, float* out);
 
 /* ------------------------------------------------------------------ IoU tracker
  * The inline tracker of iouTracke_cal.py:113-156 (per frame) and :174-177 (finalise), as a

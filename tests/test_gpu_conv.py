@@ -284,6 +284,44 @@ def test_fused_expand_depthwise(stride, shape):
     assert rel_err(out, y) < 1e-5, (shape, stride, rel_err(out, y))
 
 
+@pytest.mark.parametrize("stride,residual", [(1, 1), (1, 0), (2, 0)])
+@pytest.mark.parametrize("shape", [(16, 96, 24, 40, 64), (24, 144, 24, 37, 50), (24, 144, 32, 64, 96), (32, 100, 17, 9, 33)])
+def test_whole_inverted_residual_in_one_launch(stride, residual, shape):
+    """fused_ir.hip with PROJ: expand + depthwise + 1x1 project (+ residual) of an InvertedResidual (pyramid_mb2_try3.py:96-134,
+    BatchNorms folded) as ONE kernel: against torch, and bit-identical to the two-launch form (fdt_expand_dw, then the
+    stand-alone 1x1 conv with the residual fused) -- same k pairing and order in the project GEMM.  Odd sizes, hidden widths that
+    are not multiples of 32 (a partly filled last chunk), output widths below 32, batch 2."""
+    Cin, hid, oup, H, W = shape
+    if residual:
+        oup = Cin
+    rng = np.random.default_rng(Cin * 11 + H + stride + residual)
+    x = rng.standard_normal((2, Cin, H, W)).astype(np.float32)
+    w1 = (rng.standard_normal((hid, Cin)) / np.sqrt(Cin)).astype(np.float32)
+    b1 = rng.standard_normal(hid).astype(np.float32)
+    wd = (rng.standard_normal((hid, 9)) / 3).astype(np.float32)
+    bd = rng.standard_normal(hid).astype(np.float32)
+    wp = (rng.standard_normal((oup, hid)) / np.sqrt(hid)).astype(np.float32)
+    bp = rng.standard_normal(oup).astype(np.float32)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = np.empty((2, oup, Ho, Wo), np.float32)
+    L = lib()
+    rc = L.lib().fdt_ir_block(L.ptr(x), 2, Cin, H, W, L.ptr(w1), L.ptr(b1), L.ptr(wd), L.ptr(bd), hid, stride, L.ptr(wp), L.ptr(bp),
+                              oup, residual, L.ptr(out))
+    assert rc == 0, L.lib().fdt_last_error()
+    h = F.relu6(F.conv2d(torch.from_numpy(x), torch.from_numpy(w1)[:, :, None, None], torch.from_numpy(b1)))
+    d = F.relu6(F.conv2d(h, torch.from_numpy(wd).reshape(hid, 1, 3, 3), torch.from_numpy(bd), stride, 1, 1, hid))
+    y = F.conv2d(d, torch.from_numpy(wp)[:, :, None, None], torch.from_numpy(bp))
+    if residual:
+        y = y + torch.from_numpy(x)
+    assert rel_err(out, y.numpy()) < 1e-5, (shape, stride, residual, rel_err(out, y.numpy()))
+    # the two-launch form of the same block
+    dw = np.empty((2, hid, Ho, Wo), np.float32)
+    assert L.lib().fdt_expand_dw(L.ptr(x), 2, Cin, H, W, L.ptr(w1), L.ptr(b1), L.ptr(wd), L.ptr(bd), hid, stride, L.ptr(dw)) == 0
+    rc, two = run_conv(dw, np.ascontiguousarray(wp[:, :, None, None]), bp, 1, 1, 0, 1, res=x if residual else None, act=0, tile=6)
+    assert rc == 0, L.lib().fdt_last_error()
+    assert np.array_equal(out, two), float(np.abs(out - two).max())
+
+
 @pytest.mark.parametrize("shape", [(64, 40, 48, 96), (37, 31, 45, 70), (7, 16, 32, 64), (256, 64, 64, 128), (2, 5, 3, 3)])
 @pytest.mark.parametrize("tile", [T_WINO44, T_WINO44B])
 def test_winograd_f4x4(shape, tile):

@@ -241,9 +241,9 @@ def test_fused_ingest_facebox_bits(fb_sd):
 
 def test_config5_as_baseline_words_it_4k_sources_and_batch_16_in_one_call(net, fb_sd):
     """BASELINE.json configs[4] in ONE call: sixteen 2160x3840 uint8 sources (the six multi-face images, pixel-replicated like
-    bench.py builds its frames) resized on the GPU and detected as one batch.  Image b of the batch equals the single-image call
-    bit for bit (images of a batch do not see each other), the resized input of every image is bit-exact against the oracle's
-    resize, and the faces match the oracle end to end."""
+    bench.py builds its frames) resized on the GPU and detected as one batch.  Equal images of the batch give equal bits, every image
+    matches its single-image call to f32 rounding, the resized input of every image is bit-exact against the oracle's resize, and
+    the faces match the oracle end to end."""
     from oracle import ingest as oin
     d, meta = load_npz("facebox_r2")
     SH, SW, B = 2160, 3840, 16
@@ -256,8 +256,11 @@ def test_config5_as_baseline_words_it_4k_sources_and_batch_16_in_one_call(net, f
     assert x.shape == (B, 3, 1024, 1024)
     singles = [net.detect_frames(u[None])[0] for u in uniq]
     for b, (bx, pr) in enumerate(res):
+        # same image twice in the batch: same bits (images of a batch do not see each other); against the batch-1 call only to
+        # f32 rounding -- a batch-1 plan may pick other tiles / split-K for a layer, i.e. another summation order
+        assert np.array_equal(pr, res[b % 6][1]) and np.array_equal(bx, res[b % 6][0]) and len(pr) >= 3
         sb, sp = singles[b % 6]
-        assert np.array_equal(pr, sp) and np.array_equal(bx, sb) and len(pr) >= 3
+        assert len(pr) == len(sp) and np.allclose(pr, sp, atol=1e-5) and np.allclose(bx, sb, atol=1e-5)
     for i in range(6):
         small = oin.resize_linear_u8(uniq[i], 1024, 1024)
         assert np.array_equal(x[i], small.transpose(2, 0, 1).astype(np.float32) / np.float32(255))

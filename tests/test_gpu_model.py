@@ -519,7 +519,7 @@ def test_try3_with_fused_inverted_residual_heads(try3_sd, synth, monkeypatch):
     x = opb.preprocess(frame)
     PB = M("layers").PriorBoxLayer
     outs = {}
-    for mode in ("1", "0"):
+    for mode in ("1", "0", "2"):                        # expand + depthwise fused / separate launches / whole blocks in one launch
         monkeypatch.setenv("FDT_FUSE_IR", mode)
         net = M("pyramid_mb2_try3").build_sfd_mobile('test', 640, 2)
         net.load_state_dict(try3_sd)
@@ -534,6 +534,14 @@ def test_try3_with_fused_inverted_residual_heads(try3_sd, synth, monkeypatch):
             names = [n for n, _, _ in (net.profile(True), net(x), net.profile_read())[2]]
             # every block whose staged patch leaves room for two workgroups per CU (features.2 .. features.6)
             assert sum(n.endswith(".expand_dw") for n in names) == 5
+            net.profile(False)
+        if mode == "2":
+            o = opb.try3_forward(try3_sd, x, want=TRY3_STAGES)
+            for st in TRY3_STAGES:
+                got = net.get_tensor(st)
+                assert got.shape == o[st].shape and rel_rms(got, o[st]) < STAGE_RTOL, (st, rel_rms(got, o[st]))
+            names = [n for n, _, _ in (net.profile(True), net(x), net.profile_read())[2]]
+            assert sum(n.endswith(".expand_dw_project") for n in names) >= 3, names     # the blocks with <= 32 output channels
             net.profile(False)
         net.close()
     n = int((outs["0"][0, 1, :, 0] > 0).sum())
