@@ -35,7 +35,7 @@ struct P1x1 {
   static constexpr size_t LDS_BYTES = (size_t)NBUF * STAGE * sizeof(float);
   static_assert(XSZ % 1024 == 0, "the pixel tile is staged with whole dwordx4 wave-instructions");
   static_assert(NBUF == 3, "ring of three (the host checks nst >= NBUF - 1 = 2)");
-  static_assert((NBUF - 2) * LOADS + NACC <= 63 || true, "vmcnt is 6 bits: larger counts are clamped (safe: waits for more)");
+  // (vmcnt is 6 bits: wait_vm clamps a count above 63, which is safe -- it only waits for a few more of the younger operations)
 };
 
 template <int N>
