@@ -848,8 +848,8 @@ def main():
 
     # ---- PCIe-inclusive rate: pageable host frames through the pipelined async ingest (never `value`) ---------------
     host_path = None
-    if rank == 0 and world == 1 and args.host_frames > 0 and B == 1:
-        host_path = host_frames_rate(args, lib, net, frames_h, H, W, SH, SW)
+    if rank == 0 and world == 1 and args.host_frames > 0 and max(1, args.batch) == 1:
+        host_path = host_frames_rate(args, lib, net, frames_h, H, W, SH, SW, G)
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample ---------------------------
     cpu, parity = None, None
@@ -989,10 +989,11 @@ def main():
         dist.destroy_process_group()
 
 
-def host_frames_rate(args, lib, net, frames_h, H, W, SH, SW):
+def host_frames_rate(args, lib, net, frames_h, H, W, SH, SW, G=1):
     """Frames handed over as pageable HOST buffers (what iouTracke_cal.py:119-124 has after cv2.read) -- measured by calling
-    the reference-named entry point itself: iouTracke_cal.track(frames[, size=(W, H)]) = pinned staging ring + H2D + forward
-    + device-resident tracker, three handles x two tickets in flight, no host wait per frame."""
+    the reference-named entry point itself: iouTracke_cal.track(frames[, size=(W, H)][, batch=G]) = pinned landing buffer + H2D
+    + forward + device-resident tracker, no host wait per frame; both engines of track() are timed, the module's default one
+    is `value`.  G > 1: the grouped configuration (G consecutive frames per forward, like the timed loop)."""
     import torch
     cal = importlib.import_module("face-detection-and-tracking_amd.iouTracke_cal")
     cal.net = net
@@ -1000,16 +1001,25 @@ def host_frames_rate(args, lib, net, frames_h, H, W, SH, SW):
     n = args.host_frames
     NF = int(os.environ.get("FDT_HOST_NF", "3"))   # three handles x two tickets: measured optimum of this path (four: -7 %)
     size = (W, H) if args.source else None
-    cal.track((frames_h[i % U] for i in range(2 * NF + 2)), inflight=NF, size=size)     # plans, graphs, pinned slots
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    tracks = cal.track((frames_h[i % U] for i in range(n)), inflight=NF, size=size)
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 2), "unit": "frames/s", "frames": n, "ms_per_frame": round(dt / n * 1e3, 3),
-            "tracks": len(tracks), "entry_point": "iouTracke_cal.track(frames%s, inflight=%d)" % (", size=(%d, %d)" % size if size else "", NF),
-            "what": "PCIe-inclusive, whole call timed (tracker creation, the frames, finish()): pageable host u8 frames -> "
-                    "pinned ring -> H2D -> forward -> device-resident tracker; %d handles x 2 tickets in flight "
-                    "(fdt_model_forward_async / fdt_model_async_record / fdt_model_release: no host wait per frame)" % NF}
+    out = {}
+    for engine in ("pipeline", "async"):
+        nf = NF if engine == "async" else int(os.environ.get("FDT_HOST_PIPE_NF", "4"))
+        cal.track((frames_h[i % U] for i in range((2 * nf + 2) * G)), inflight=nf, size=size, engine=engine, batch=G)   # plans, graphs, pinned slots
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tracks = cal.track((frames_h[i % U] for i in range(n)), inflight=nf, size=size, engine=engine, batch=G)
+        dt = time.perf_counter() - t0
+        out[engine] = {"value": round(n / dt, 2), "ms_per_frame": round(dt / n * 1e3, 3), "tracks": len(tracks), "inflight": nf}
+    best = cal.DEFAULT_ENGINE
+    sz = ", size=(%d, %d)" % size if size else ""
+    return {"value": out[best]["value"], "unit": "frames/s", "frames": n, "ms_per_frame": out[best]["ms_per_frame"],
+            "tracks": out[best]["tracks"],
+            "entry_point": "iouTracke_cal.track(frames%s, inflight=%d%s)" % (sz, out[best]["inflight"], ", batch=%d" % G if G > 1 else ""),
+            "engine": best, "engines": out,
+            "what": "PCIe-inclusive, whole call timed (tracker reset/creation, the frames, finish()): pageable host u8 frames -> "
+                    "pinned landing buffer -> H2D -> forward -> device-resident tracker, no host wait per frame.  'pipeline': one "
+                    "fdt_pipeline_step_host call per frame; 'async': fdt_model_forward_async / _async_record / _release tickets "
+                    "stepped from Python"}
 
 
 if __name__ == "__main__":

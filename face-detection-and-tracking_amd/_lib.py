@@ -124,6 +124,7 @@ SIGNATURES = {
     "fdt_pipeline_destroy": (None, [_vp]),
     "fdt_pipeline_prime": (C.c_int, [_vp, _vp]),
     "fdt_pipeline_step": (C.c_int, [_vp, C.c_longlong, _vp]),
+    "fdt_pipeline_step_host": (C.c_int, [_vp, C.c_longlong, _vp, C.c_int]),
     "fdt_pipeline_step_frame": (C.c_int, [_vp, C.c_longlong, _vp]),
     "fdt_pipeline_flush": (C.c_int, [_vp]),
     "fdt_pipeline_sync": (C.c_int, [_vp]),

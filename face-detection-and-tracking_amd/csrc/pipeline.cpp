@@ -25,6 +25,8 @@ struct fdt_pipeline {
   std::vector<float*> mine, gathered;      // per slot: this rank's records [B][REC]; all ranks' [world][B][REC] (== mine at world 1)
   std::vector<int*> counts;                // per slot: [B][2]
   std::vector<unsigned char*> stage;       // per slot: [B][h][w][3] u8, frames handed over one at a time (step_frame)
+  std::vector<unsigned char*> pinned;      // per slot: pinned host landing buffer of step_host (lazily allocated)
+  std::vector<hipEvent_t> h2d_done;        // per slot: the H2D copy out of `pinned` has completed
   fdt_tracker* tracker = nullptr;
   fdt_comm* comm = nullptr;                // borrowed
   long long pend_group = -1;               // step_frame: the partly filled batch
@@ -112,6 +114,8 @@ extern "C" fdt_pipeline* fdt_pipeline_create(fdt_model* m, int device, int heigh
     if (cnt) p->counts.push_back(cnt);
     p->gathered.push_back(world == 1 ? mine : all);
     p->stage.push_back(nullptr);
+    p->pinned.push_back(nullptr);
+    p->h2d_done.push_back(nullptr);
     if (ok) ok = hipMemsetAsync(mine, 0, rec_bytes, s) == hipSuccess && hipMemsetAsync(cnt, 0, (size_t)batch * 2 * 4, s) == hipSuccess;
   }
   ok = ok && hipStreamCreateWithFlags(&p->trk, hipStreamNonBlocking) == hipSuccess &&
@@ -143,6 +147,10 @@ extern "C" void fdt_pipeline_destroy(fdt_pipeline* p) {
   for (auto c : p->counts) (void)hipFree(c);
   for (auto s : p->stage)
     if (s) (void)hipFree(s);
+  for (auto s : p->pinned)
+    if (s) (void)hipHostFree(s);
+  for (auto e : p->h2d_done)
+    if (e) (void)hipEventDestroy(e);
   for (auto e : p->det_done) (void)hipEventDestroy(e);
   for (auto e : p->trk_done) (void)hipEventDestroy(e);
   for (auto e : p->mark)
@@ -171,6 +179,30 @@ extern "C" int fdt_pipeline_step(fdt_pipeline* p, long long i, const void* frame
   FDT_HIP(hipStreamWaitEvent(p->det[k], p->trk_done[k], 0));     // the slot's previous record was consumed
   FDT_TRY(forward_slot(p, k, frames_dev));
   return track_slot(p, k, p->B, false);
+}
+
+// Step i from HOST frames (what cv2's capture hands over, iouTracke_cal.py:119-124): `batch` pageable uint8 frames are copied into
+// the slot's pinned landing buffer (the caller may reuse its memory at once), the H2D copy runs on the slot's stream in front
+// of its forward (a copy stream of its own can land on another slot's hardware queue and wait behind a whole forward there:
+// DESIGN.md section 5), then as fdt_pipeline_step.  n_valid < batch: a partly filled last batch (only the first n_valid
+// frames are shown to the tracker).
+extern "C" int fdt_pipeline_step_host(fdt_pipeline* p, long long i, const void* frames_host, int n_valid) {
+  FDT_REQUIRE(p && frames_host && i >= 0 && n_valid >= 1 && n_valid <= p->B, FDT_ERR_ARG, "fdt_pipeline_step_host: bad argument");
+  const int k = (int)(i % p->NF);
+  const size_t fb = (size_t)(p->src_h > 0 ? p->src_h : p->H) * (p->src_h > 0 ? p->src_w : p->W) * 3 * p->B;
+  if (!p->pinned[k]) {
+    FDT_HIP(hipHostMalloc((void**)&p->pinned[k], fb, hipHostMallocDefault));
+    FDT_HIP(hipEventCreateWithFlags(&p->h2d_done[k], hipEventDisableTiming));
+    if (!p->stage[k]) FDT_HIP(hipMalloc((void**)&p->stage[k], fb));
+  } else {
+    FDT_HIP(hipEventSynchronize(p->h2d_done[k]));             // the previous copy out of the landing buffer (long done)
+  }
+  memcpy(p->pinned[k], frames_host, fb);
+  FDT_HIP(hipStreamWaitEvent(p->det[k], p->trk_done[k], 0));  // the slot's previous record was consumed
+  FDT_HIP(hipMemcpyAsync(p->stage[k], p->pinned[k], fb, hipMemcpyHostToDevice, p->det[k]));
+  FDT_HIP(hipEventRecord(p->h2d_done[k], p->det[k]));
+  FDT_TRY(forward_slot(p, k, p->stage[k]));
+  return track_slot(p, k, n_valid, n_valid < p->B);
 }
 
 extern "C" int fdt_pipeline_flush(fdt_pipeline* p) {

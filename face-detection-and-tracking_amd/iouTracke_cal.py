@@ -8,10 +8,11 @@ MI355X (`fdt_model_forward*`, `fdt_tracker_step*`).  Video decoding / display ar
 network resolution or -- `track(frames, size=(640, 480))` -- as raw source frames that the GPU resizes
 like the reference's `cv2.resize(image, (640, 480))` (:123).
 
-`track()` is the PIPELINED path bench.py times (`fdt_model_forward_async` / `fdt_model_async_record` /
-`fdt_model_release`): `inflight` detector handles that share one weight copy (fdt_model_clone), two tickets each,
-host frames copied into a pinned ring and uploaded in front of their forward, the Detect record handed to the
-tracker on the device, no host wait per frame.  The tracks are bit-identical to the synchronous one-handle path
+`track()` is the PIPELINED path bench.py times as `host_path`: `inflight` detector handles that share one weight copy
+(fdt_model_clone), host frames copied into a pinned landing buffer and uploaded in front of their forward, the Detect
+record handed to the tracker on the device, no host wait per frame.  Two engines: "pipeline" (default; one
+`fdt_pipeline_step_host` call per batch, the library owns the slots) and "async" (the ticket interface
+`fdt_model_forward_async` / `fdt_model_async_record` / `fdt_model_release`, two tickets per handle, stepped from here).  The tracks are bit-identical to the synchronous one-handle path
 (`pipelined=False`) and to the oracle tracker (tests/test_gpu_entry.py).
 
     python -m face-detection-and-tracking_amd.iouTracke_cal   (needs frames in `video_file + '.frames.npy'`)
@@ -38,6 +39,7 @@ display_result = False
 use_net = 'repo'
 video_file = './image_and_anno/video/video8'
 #  <<<<<<<<<<<<<<<<<<<<<<<end of config parameter>>>>>>>>>>>>>>>>>>>>>>>>>>
+DEFAULT_ENGINE = "pipeline"      # track(engine=None): see track()
 
 net = None
 _clones = {}        # id(net) -> (net, [fdt_model_clone handles]) for the frames in flight of track()
@@ -154,7 +156,7 @@ def _handles(n):
     return [net] + ent[1][:n - 1]
 
 
-def track(frames, device_resident=True, pipelined=True, inflight=3, size=None, batch=1):
+def track(frames, device_resident=True, pipelined=True, inflight=None, size=None, batch=1, engine=None):
     """Run detect + association over an iterable of uint8 BGR HWC frames; returns `tracks_finished`
     (reference :113-156 + :174-175).
 
@@ -163,9 +165,12 @@ def track(frames, device_resident=True, pipelined=True, inflight=3, size=None, b
     device_resident (default): the Detect output never leaves the GPU between detection and association (the host
                  unpack of :53-84 runs inside the tracker kernel).  False: the reference's own host flow,
                  `detect_face(image, 1)` + a host-stepped association.
-    pipelined (default, needs device_resident): `inflight` handles x 2 tickets in flight, no host wait per frame;
+    pipelined (default, needs device_resident): `inflight` handles in flight (None: 4 / 3 by engine), no host wait per frame;
                  `batch` consecutive frames per forward (the association still sees them one by one, in order).
                  False: one handle, one stream, one frame at a time.
+    engine (pipelined only): "async" -- the ticket interface, fdt_model_forward_async / _async_record / _release, stepped from
+                 here; "pipeline" -- one fdt_pipeline_step_host call per batch, the library owns slots, streams, the pinned
+                 landing buffers and the tracker (kept between calls for the same geometry).  Same tracks, bit for bit.
     `use_iou = False` selects the distance measure of :136-138 (host-stepped; the detection still runs on the GPU)."""
     if not use_iou:
         tr = _DistanceTracker(sigma_dis, sigma_h, t_min)
@@ -182,6 +187,13 @@ def track(frames, device_resident=True, pipelined=True, inflight=3, size=None, b
         tracker.close()
         return out
     if pipelined:
+        engine = engine or DEFAULT_ENGINE
+        if inflight is None:
+            inflight = 4 if engine == "pipeline" else 3        # measured optima (bench.py host_path, docs/EXPERIMENTS.md R4-11)
+        if engine == "pipeline":
+            return _track_cabi(frames, max(1, int(inflight)), size, max(1, int(batch)))
+        if engine != "async":
+            raise ValueError("track(engine=...): 'async' or 'pipeline'")
         return _track_pipelined(frames, max(1, int(inflight)), size, max(1, int(batch)))
 
     tracker = IouTracker(sigma_iou, sigma_h, t_min)
@@ -290,6 +302,61 @@ def _track_pipelined(frames, inflight, size, batch):
         if tracker is not None:
             torch.cuda.synchronize()
             tracker.close()
+
+
+_pipes = {}       # (id(net), H, W, SH, SW, inflight, batch) -> CabiPipeline, kept between track() calls
+
+
+def _track_cabi(frames, inflight, size, batch):
+    """track() on fdt_pipeline_step_host: the per-frame host work is one C call (memcpy into the slot's pinned buffer, H2D,
+    forward graph, tracker launch, all enqueued)."""
+    from .pipeline import CabiPipeline
+    pipe = None
+    shape = None
+    group = []
+    i = 0
+    try:
+        for image in frames:
+            image = np.ascontiguousarray(image, dtype=np.uint8)
+            if shape is None:
+                shape = image.shape
+                SH, SW, _ = shape
+                W, H = (int(size[0]), int(size[1])) if size is not None else (SW, SH)
+                key = (id(net), H, W, SH, SW, inflight, batch, sigma_iou, sigma_h, t_min)
+                ent = _pipes.get(key)
+                if ent is None or ent[0] is not net:
+                    for _, old in _pipes.values():
+                        old.close()
+                    _pipes.clear()
+                    pipe = CabiPipeline(net, H, W, torch.cuda.current_device(), inflight, batch,
+                                        source_hw=(SH, SW) if size is not None else None,
+                                        sigma_iou=sigma_iou, sigma_h=sigma_h, t_min=t_min, log_frames=max(256, batch),
+                                        plan_text=net.tuned_plan_text(H, W, batch))
+                    _pipes[key] = (net, pipe)
+                else:
+                    pipe = ent[1]
+                    pipe._trk.reset()
+            elif image.shape != shape:
+                raise ValueError("track(): frame shape changed from %s to %s" % (shape, image.shape))
+            if batch == 1:
+                pipe.step_host(i, image)
+                i += 1
+                continue
+            group.append(image)
+            if len(group) == batch:
+                pipe.step_host(i, np.stack(group))
+                i += 1
+                group = []
+        if group:
+            nfr = len(group)      # a last, partial batch: padded with copies of its last frame, only the real ones are tracked
+            pipe.step_host(i, np.stack(group + [group[-1]] * (batch - nfr)), nfr)
+        if pipe is None:
+            return []
+        return pipe.finish()
+    except BaseException:
+        if pipe is not None:
+            pipe.sync()
+        raise
 
 
 def save_tracks(tracks, path):

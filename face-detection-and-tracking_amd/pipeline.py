@@ -224,6 +224,10 @@ class CabiPipeline:
     def step(self, i, frames_dev):
         _lib.check(self._L.fdt_pipeline_step(self._p, int(i), self._ptr(frames_dev)))
 
+    def step_host(self, i, frames_host, n_valid=None):
+        """Step i from host frames: a C-contiguous uint8 array [batch, h, w, 3] (free for reuse on return)."""
+        _lib.check(self._L.fdt_pipeline_step_host(self._p, int(i), _lib.ptr(frames_host), int(self.B if n_valid is None else n_valid)))
+
     def step_frame(self, i, frame_dev):
         _lib.check(self._L.fdt_pipeline_step_frame(self._p, int(i), self._ptr(frame_dev)))
 

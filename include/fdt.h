@@ -335,6 +335,10 @@ void fdt_pipeline_destroy(fdt_pipeline* p);
 int fdt_pipeline_prime(fdt_pipeline* p, const void* frames_dev);
 /* enqueue step i: detection of `batch` frames on slot i % inflight, exchange, association of the step's world * batch frames */
 int fdt_pipeline_step(fdt_pipeline* p, long long i, const void* frames_dev);
+/* the same from HOST frames (`batch` pageable uint8 frames, iouTracke_cal.py:119-124): copied to a pinned landing buffer of the
+ * slot (the caller's memory is free on return), H2D on the slot's stream in front of its forward.  n_valid < batch: a partly
+ * filled last batch -- only the first n_valid frames reach the tracker.                                                    */
+int fdt_pipeline_step_host(fdt_pipeline* p, long long i, const void* frames_host, int n_valid);
 /* frames handed over ONE at a time (what a video source delivers), executed `batch` at a time: frame i of this rank is
  * copied into the staging batch of slot (i / batch) % inflight; the batch's last frame launches it (one launch per layer for
  * `batch` consecutive frames).  fdt_pipeline_flush runs a partly filled batch (end of the video).                       */

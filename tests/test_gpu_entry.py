@@ -113,6 +113,31 @@ def test_track_pipelined_equals_synchronous_and_oracle(entry, synth):
         entry.track(frames[:2] + [frames[0][:64]])                  # frame shape changes mid-sequence
 
 
+def test_track_on_the_library_pipeline_engine(entry, synth):
+    """track(engine="pipeline"): one fdt_pipeline_step_host call per batch (the library owns slots, pinned landing buffers,
+    streams and the tracker, kept between calls) -- the same tracks as the ticket engine and the oracle, for several slot
+    counts, repeated calls (tracker reset), a partial last batch and source-size frames."""
+    frames = frames_sequence(synth)
+    t_ref = _ref_tracks(entry, frames)
+    for inflight in (1, 3, 4):
+        assert entry.track(frames, inflight=inflight, engine="pipeline") == t_ref, inflight
+    assert entry.track(frames, inflight=4, engine="pipeline") == t_ref          # the cached pipeline, tracker reset
+    assert entry.track(iter(frames[:9]), inflight=4, engine="pipeline") == _ref_tracks(entry, frames[:9])
+    for batch in (2, 4):
+        assert entry.track(frames, inflight=2, batch=batch, engine="pipeline") == entry.track(frames, inflight=2, batch=batch), batch
+    rng = np.random.default_rng(5)
+    base = [rng.integers(0, 256, (270, 480, 3), dtype=np.uint8) for _ in range(3)]
+    src = [base[i // 7] for i in range(21)]
+    assert entry.track(src, size=(160, 128), engine="pipeline") == entry.track(src, size=(160, 128))
+    assert entry.track([], engine="pipeline") == []
+    with pytest.raises(ValueError):
+        entry.track(frames[:2] + [frames[0][:64]], engine="pipeline")
+    with pytest.raises(ValueError):
+        entry.track(frames, engine="nope")
+    entry.net.firstTime = True
+    entry.net(frames[0])
+
+
 def test_track_from_source_frames_resized_on_the_gpu(entry, synth):
     """reference :123: image = cv2.resize(image, (W, H)) in front of detect_face -- track(frames, size=(W, H)) does it on the
     GPU inside the pipelined ingest; same tracks as resizing with the oracle's restatement on the host first."""
