@@ -404,7 +404,9 @@ def main():
     ap.add_argument("--group", type=int, default=0,
                     help="frames are handed to the pipeline ONE AT A TIME but executed GROUP at a time (one launch per layer for "
                          "GROUP consecutive frames: pipeline.step_frame); a step stays one frame per GPU.  0 = auto: 4 for "
-                         "Res50 frames of at most 640x480 at --batch 1 (launch-bound there), else 1")
+                         "Res50 frames of at most 1024x1024 at --batch 1 when tuned/ holds the batch-4 plan, else 1")
+    ap.add_argument("--ungrouped-steps", type=int, default=64,
+                    help="with grouping on (N = 1): also time this many steps of the --group 1 form (reported as `ungrouped`); 0 = skip")
     ap.add_argument("--source", default="", help="HxW of raw source frames (e.g. 1080x1920): the frames are resized on the "
                     "GPU to --height x --width inside the timed step like iouTracke_cal.py:123 does with cv2.resize")
     ap.add_argument("--unique-frames", type=int, default=8)
@@ -467,7 +469,7 @@ def main():
     B = max(1, args.batch)
     # cross-frame grouped launches: G consecutive frames of a rank share one launch per layer (the handle runs its batch-G
     # plan); every leg below then works on batches of G, only the timed loop hands the frames over one by one
-    G = args.group if args.group > 0 else (4 if (args.arch == "res50" and B == 1 and H * W <= 640 * 480 and os.path.exists(
+    G = args.group if args.group > 0 else (4 if (args.arch == "res50" and B == 1 and H * W <= 1024 * 1024 and os.path.exists(
         os.path.join(ROOT, "face-detection-and-tracking_amd", "tuned", "res50_%dx%d_b4.plan" % (W, H)))) else 1)
     if G > 1:
         if B != 1:
@@ -752,11 +754,14 @@ def main():
         (dk, dt_), dg = max(groups.items(), key=lambda kv: kv[1][1])
         # HBM bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (PMC
         # cannot be read from inside the process); the committed summary of the current round is quoted here.
-        traffic = traffic_src = traffic_cal = traffic_classes = traffic_ratio = None
+        traffic = traffic_src = traffic_cal = traffic_classes = traffic_ratio = traffic_alg = None
         for rnd in ("r04", "r03", "r02", "r01"):
-            tj = os.path.join(ROOT, "profiles", rnd, "conv_hbm_traffic.json")
+            tj = os.path.join(ROOT, "profiles", rnd, "conv_hbm_traffic%s.json" % ("" if B == 1 else "_b%d" % B))
             if args.arch == "res50" and H == 1024 and W == 1024 and os.path.exists(tj):
                 tdata = json.load(open(tj))
+                if tdata.get("frames_per_forward", 1) != B:      # measured at another batch / group size: not this run's launches
+                    continue
+                traffic_alg = round(tdata["algorithmic_bytes_per_launch"]) if "algorithmic_bytes_per_launch" in tdata else None
                 traffic = round(tdata["hbm_bytes_per_launch"])
                 if tdata.get("hbm_bytes_per_launch_calibrated"):
                     traffic_cal = round(tdata["hbm_bytes_per_launch_calibrated"])
@@ -765,8 +770,9 @@ def main():
                     traffic_classes = [{"class": c["cls"], "launches_per_frame": c["launches_per_frame"], "ratio": c["ratio"],
                                         "bytes_per_launch": c["bytes_per_launch"],
                                         "algorithmic_bytes_per_launch": c["algorithmic_bytes_per_launch"]} for c in tdata["by_class"][:8]]
-                    traffic_src = "profiles/%s/conv_hbm_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B} / TCC_EA0_WRREQ{,_64B}: " \
-                                  "bytes by request size class, calibrated on a 1 GiB copy; per dispatch, joined with the op list)" % rnd
+                    traffic_src = "profiles/%s/%s (rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B} / TCC_EA0_WRREQ{,_64B}: bytes by " \
+                                  "request size class, calibrated on a 1 GiB copy; per dispatch of %d-frame forwards, joined with " \
+                                  "the op list)" % (rnd, os.path.basename(tj), B)
                 else:
                     traffic_src = "profiles/%s/conv_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, all conv " \
                                   "kernels, bytes/launch)" % rnd
@@ -792,8 +798,8 @@ def main():
             "traffic_note": ("QUOTED from the committed PMC summary named in traffic_source (separate rocprofv3 --pmc passes of "
                              "this command on an earlier run), NOT measured in this run: hardware counters cannot be read from "
                              "inside the process") if traffic is not None else None,
-            "algorithmic_bytes_per_launch": round((3.52e9 + 0.2688e9) / 105) if args.arch == "res50" and H == 1024 and W == 1024 else None,
-            # (fdt_model_traffic counts the residual / upsample reads too: 38.2 MB per launch in profiles/r04/conv_hbm_traffic.json)
+            # input + output (+ residual / upsample source) + weights of every conv, each once (fdt_model_traffic), / launches
+            "algorithmic_bytes_per_launch": traffic_alg,
             # all conv launches of a frame (serial profile pass on one stream)
             "conv_stack": {"launches_per_frame": n_conv, "ms_per_frame": round(conv_ms / B, 3),
                            "algorithmic_gflop_per_frame": round(alg / B / 1e9, 3),
@@ -933,6 +939,28 @@ def main():
             cpu = {"see": "cpu_baseline of the N=1 line of this bench.py (measured on rank 0 at N=1 only, as the bench contract "
                           "says): the oracle end to end on this host's cores"}
 
+    # ---- the same steps WITHOUT cross-frame grouping (one launch chain per frame, the batch-1 plan), for the record -------
+    ungrouped = None
+    if rank == 0 and world == 1 and G > 1 and use_cabi and args.ungrouped_steps > 0:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
+        pipe.close()
+        p1 = pipeline.CabiPipeline(net, H, W, local_rank, inflight=NF, batch=1, source_hw=(SH, SW) if args.source else None,
+                                   plan_text=net.tuned_plan_text(H, W, 1))
+        p1.prime(frames_d[0:1])
+        for i in range(args.warmup):
+            p1.step(i, frames_d[i % U:i % U + 1])
+        p1.sync()
+        t1 = time.perf_counter()
+        for i in range(args.ungrouped_steps):
+            p1.step(args.warmup + i, frames_d[(args.warmup + i) % U:(args.warmup + i) % U + 1])
+        p1.sync()
+        d1 = time.perf_counter() - t1
+        ungrouped = {"value": round(args.ungrouped_steps / d1, 3), "unit": "frames/s", "steps": args.ungrouped_steps,
+                     "ms_per_step": round(d1 / args.ungrouped_steps * 1e3, 4), "tracks": len(p1.finish()),
+                     "what": "--group 1: the same pipeline with one launch chain per frame (batch-1 kernel plan), same slots"}
+        p1.close()
+
     if rank == 0:
         frames = args.steps * world * (1 if G > 1 else B)
         line = {
@@ -974,6 +1002,7 @@ def main():
             "cpu_baseline": cpu,
             "parity": parity,
             "host_path": host_path,
+            "ungrouped": ungrouped,
         }
         print(json.dumps(line))
     pipe.close()

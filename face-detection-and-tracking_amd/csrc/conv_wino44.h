@@ -138,7 +138,9 @@ using W44D2 = W44T<true, 2>;
 
 #ifdef FDT_W44_STAMPS   // diagnostic build (tools/experiments/w44_stamps.sh): where does a workgroup's time go?  Constant-rate clock
 __device__ long long g_w44_time[8];   // (100 MHz), summed over workgroups: [0] prologue [1] main loop [2] epilogue round 0 [3] round 1 [4] workgroups
-#define W44_STAMP(i) if (threadIdx.x == 0) { const long long c_ = wall_clock64(); atomicAdd((unsigned long long*)&g_w44_time[i], (unsigned long long)(c_ - w44_t_)); w44_t_ = c_; }
+                                      // [5] SHADER-clock cycles (s_memtime) of the main loop: [5] / [1] x 100 MHz = the clock the CUs held
+#define W44_STAMP(i) if (threadIdx.x == 0) { const long long c_ = wall_clock64(); atomicAdd((unsigned long long*)&g_w44_time[i], (unsigned long long)(c_ - w44_t_)); w44_t_ = c_; \
+    if (i == 0) w44_c_ = clock64(); if (i == 1) atomicAdd((unsigned long long*)&g_w44_time[5], (unsigned long long)(clock64() - w44_c_)); }
 #else
 #define W44_STAMP(i)
 #endif
@@ -147,7 +149,7 @@ template <class T>
 __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef FDT_W44_STAMPS
-  long long w44_t_ = wall_clock64();
+  long long w44_t_ = wall_clock64(), w44_c_ = 0;
 #endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;

@@ -16,5 +16,7 @@ for kind, cin, h, w, cout, split in SHAPES:
     v = list(buf)
     n = max(v[4], 1)
     us = [x / 100.0 / n for x in v[:4]]
-    print("%s %4d -> %4d @ %3dx%-3d /%d: %6.1f us per launch; per workgroup (%d per launch): prologue %5.1f  main loop %6.1f  epilogue round 0 %5.1f  round 1 %5.1f us"
-          % (cb.KIND[kind], cin, cout, h, w, split, ms * 1e3, n // 22, us[0], us[1], us[2], us[3]), flush=True)
+    mhz = 100.0 * v[5] / max(v[1], 1)
+    print("%s %4d -> %4d @ %3dx%-3d /%d: %6.1f us per launch; per workgroup (%d per launch): prologue %5.1f  main loop %6.1f  epilogue round 0 %5.1f  round 1 %5.1f us;"
+          " shader clock in the main loop %4.0f MHz (s_memtime / s_memrealtime), %.0f cycles per k-step"
+          % (cb.KIND[kind], cin, cout, h, w, split, ms * 1e3, n // 22, us[0], us[1], us[2], us[3], mhz, v[5] / n / (cin / 2.0 / split)), flush=True)

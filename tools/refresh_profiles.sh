@@ -10,7 +10,7 @@ R=${1:-r04}
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT /tmp/raw
 export TMPDIR=/tmp
-PLAN=face-detection-and-tracking_amd/tuned/res50_1024x1024_b1.plan
+PLAN=face-detection-and-tracking_amd/tuned/res50_1024x1024_b4.plan     # the default bench runs four frames per launch chain (--group auto)
 # the single-kernel PMC passes below measure the (kernel class, tile, split-K) the COMMITTED plan runs for these layers
 # (read from the plan, so a re-tune cannot leave the PMC files describing a kernel that is no longer used)
 plan_of() { awk -v L="$1" '$1==L {print $2, $3, $4; f=1} END {if(!f) exit 1}' $PLAN || { echo "refresh_profiles: layer $1 not in $PLAN" >&2; exit 1; }; }
@@ -20,19 +20,26 @@ K_B=$(plan_of layer1.0.conv3)
 K_C=$(plan_of layer2.1.conv3)
 case "$K_WINO" in "14 32 "*|"14 33 "*) ;; *) echo "refresh_profiles: conv2_SSH.conv1 is no longer a Winograd F(4x4,3x3) kernel ($K_WINO)" >&2; exit 1;; esac
 K_WD2=$(plan_of conv2_SSH.conv2)       # the dilated SSH context conv: quarter-split F(2x2,3x3)
-B="python bench.py --steps 48 --warmup 8 --cpu-frames 0 --host-frames 0"
+B="python bench.py --steps 48 --warmup 8 --cpu-frames 0 --host-frames 0 --ungrouped-steps 0"
 timeout -k 10 400 python bench.py --steps 64 --warmup 8 > $OUT/bench_line_res50_1024.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt --output-format csv -- $B > $OUT/bench_under_rocprof.log 2>&1
 cp /tmp/raw/kt_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv
-# that command runs 16 priming (two per slot) + 8 warm-up + 48 timed + 56 parity (sequential re-run) + 5 per-op profiled + 2 x 5 segment-timed forwards
-python tools/rocprof_conv_summary.py $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv 143 $OUT/bench_line_res50_1024.json > $OUT/rocprof_vs_bench.txt
+# every forward of that command is a four-frame forward (priming, 56 / 4 timed + warm-up groups, the sequential parity re-run, the
+# per-op profiled and the segment-timed forwards); their number is read from the head_finalize_all_kernel calls
+python tools/rocprof_conv_summary.py $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv 60 $OUT/bench_line_res50_1024.json > $OUT/rocprof_vs_bench.txt
 # HBM traffic by request size class, per dispatch (tools/experiments/traffic_r4.sh has the calibration passes)
-P="python bench.py --steps 8 --warmup 2 --cpu-frames 0 --host-frames 0 --inflight 1 --profile-frames 1 --graph 0"
+P="python bench.py --steps 32 --warmup 8 --cpu-frames 0 --host-frames 0 --inflight 1 --profile-frames 1 --graph 0 --ungrouped-steps 0"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d /tmp/raw -o fwd_rd --output-format csv -- $P > /tmp/raw/fwd_rd.log 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -d /tmp/raw -o fwd_wr --output-format csv -- $P > /tmp/raw/fwd_wr.log 2>&1
-python tools/dump_ops.py > $OUT/ops_1024.json 2> /tmp/raw/dump_ops.err
-CAL=""; [ -d profiles/$R/traffic ] && CAL=profiles/$R/traffic
-python tools/traffic_by_class.py /tmp/raw/fwd_rd_counter_collection.csv /tmp/raw/fwd_wr_counter_collection.csv $OUT/ops_1024.json $OUT/conv_hbm_traffic.json $CAL > $OUT/conv_hbm_traffic_summary.txt
+python tools/dump_ops.py --batch 4 > $OUT/ops_1024_b4.json 2> /tmp/raw/dump_ops.err
+python tools/traffic_by_class.py /tmp/raw/fwd_rd_counter_collection.csv /tmp/raw/fwd_wr_counter_collection.csv $OUT/ops_1024_b4.json $OUT/conv_hbm_traffic_b4.json - 4 > $OUT/conv_hbm_traffic_b4_summary.txt
+# the same two passes for the one-frame-per-launch form (--group 1, the batch-1 plan; calibration passes: tools/experiments/traffic_r4.sh)
+P1="$P --group 1"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d /tmp/raw -o fwd1_rd --output-format csv -- $P1 > /tmp/raw/fwd1_rd.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -d /tmp/raw -o fwd1_wr --output-format csv -- $P1 > /tmp/raw/fwd1_wr.log 2>&1
+python tools/dump_ops.py > $OUT/ops_1024.json 2> /tmp/raw/dump_ops1.err
+CAL="-"; [ -d profiles/$R/traffic ] && CAL=profiles/$R/traffic
+python tools/traffic_by_class.py /tmp/raw/fwd1_rd_counter_collection.csv /tmp/raw/fwd1_wr_counter_collection.csv $OUT/ops_1024.json $OUT/conv_hbm_traffic.json $CAL 1 > $OUT/conv_hbm_traffic_summary.txt
 # matrix-pipe occupancy of the production kernels (one kernel per process; SQ counters + GRBM in one pass)
 #        name                       kind tile split cin  h   w  cout res
 pmc_one() {
@@ -55,6 +62,8 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VA
   python tools/summarize_pmc.py /tmp/raw/valu_head_counter_collection.csv $OUT/pmc_valu_head_512to8_256x256.csv || echo "head PMC pass failed (counters unavailable)" > $OUT/pmc_valu_head_512to8_256x256.csv
 echo "face_loc.0 $K_HEAD" >> $OUT/pmc_mfma_kernels.txt
 timeout -k 10 300 python tools/profile_layers.py > $OUT/per_layer_hip_events_res50_1024.txt
+timeout -k 10 300 python tools/profile_layers.py --batch 4 > $OUT/per_layer_hip_events_res50_1024_b4.txt
+timeout -k 10 300 python bench.py --steps 256 --warmup 32 --group 1 --cpu-frames 0 --host-frames 0 > $OUT/bench_line_res50_1024_group1.json
 timeout -k 10 300 python bench.py --steps 256 --warmup 32 --height 480 --width 640 > $OUT/bench_line_res50_640x480.json
 timeout -k 10 300 python bench.py --steps 256 --warmup 32 --height 480 --width 640 --group 1 --cpu-frames 0 --host-frames 0 > $OUT/bench_line_res50_640x480_group1.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt480 --output-format csv -- python bench.py --steps 64 --warmup 8 --height 480 --width 640 --cpu-frames 0 --host-frames 0 > $OUT/bench_640x480_under_rocprof.log 2>&1

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """profiles/<round>/conv_hbm_traffic.json, per kernel class and per layer, from rocprofv3 --pmc per-dispatch CSVs of one
 forward sequence of the committed plan (tools/experiments/traffic_r4.sh):
-    python tools/traffic_by_class.py RD_dispatches.csv WR_dispatches.csv OPS.json OUT.json [CAL_DIR]
+    python tools/traffic_by_class.py RD_dispatches.csv WR_dispatches.csv OPS.json OUT.json [CAL_DIR|-] [FRAMES_PER_FORWARD]
+("per frame" below = per FORWARD of FRAMES_PER_FORWARD frames: the grouped default of bench.py runs four frames per launch)
 Read bytes = 32 * TCC_EA0_RDREQ_32B + 64 * _64B + 128 * _128B (the TCC's memory-side read requests BY SIZE CLASS: exact on a
 1 GiB float4 copy, where FETCH_SIZE reports half -- it tallies every non-32-byte request at 64 bytes); written bytes =
 64 * TCC_EA0_WRREQ_64B + 32 * the rest.  The conv dispatches of a forward are in op order (one conv-kernel dispatch per conv op),
@@ -78,8 +79,9 @@ for lst, fn in ((rd, rd_bytes), (wr, wr_bytes)):
             k = e["name"].split("(")[0].split("::")[-1][:48]
             others[k][0] += 1
             others[k][1] += fn(e)
+FPF = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 cal = {}
-if len(sys.argv) > 5:
+if len(sys.argv) > 5 and sys.argv[5] != "-":
     def mean_of(path, names):
         agg = collections.defaultdict(float)
         n = 0
@@ -108,7 +110,7 @@ out = {
               "read bytes = 32*TCC_EA0_RDREQ_32B + 64*_64B + 128*_128B, written = 64*TCC_EA0_WRREQ_64B + 32*(WRREQ - _64B); separate "
               "rocprofv3 --pmc passes of `bench.py --steps 8 --warmup 2 --cpu-frames 0 --host-frames 0 --inflight 1 --profile-frames 1 "
               "--graph 0`; mean over the last %d of %d forwards; per dispatch, joined with the op list by launch order" % (len(use), F),
-    "forwards": F, "conv_launches_per_frame": n_ops,
+    "forwards": F, "frames_per_forward": FPF, "conv_launches_per_frame": n_ops,
     "hbm_bytes_per_frame": tot_m, "algorithmic_bytes_per_frame": tot_a, "ratio": tot_m / tot_a,
     "hbm_bytes_per_launch": tot_m / n_ops, "algorithmic_bytes_per_launch": tot_a / n_ops,
     "calibration": cal,
@@ -121,8 +123,8 @@ out = {
     "other_kernels_total_bytes_over_all_forwards": {k: {"dispatches": v[0] // 2, "bytes": round(v[1])} for k, v in sorted(others.items(), key=lambda kv: -kv[1][1])[:8]},
 }
 json.dump(out, open(sys.argv[4], "w"), indent=1)
-print("overall: %.1f MB per frame measured vs %.1f MB algorithmic = %.2fx (%.1f vs %.1f MB per launch)" % (
-    tot_m / 1e6, tot_a / 1e6, tot_m / tot_a, tot_m / n_ops / 1e6, tot_a / n_ops / 1e6))
+print("overall: %.1f MB per forward of %d frame(s) measured vs %.1f MB algorithmic = %.2fx (%.1f vs %.1f MB per launch)" % (
+    tot_m / 1e6, FPF, tot_a / 1e6, tot_m / tot_a, tot_m / n_ops / 1e6, tot_a / n_ops / 1e6))
 for c in out["by_class"][:10]:
     print("  %-28s x%-3d %8.1f MB alg %8.1f MB read %8.1f MB written  ratio %.2f" % (
         c["cls"], c["launches_per_frame"], c["algorithmic_bytes"] / 1e6, c["read_bytes"] / 1e6, c["written_bytes"] / 1e6, c["ratio"]))
