@@ -27,6 +27,12 @@ cp /tmp/raw/kt_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv
 # every forward of that command is a four-frame forward (priming, 56 / 4 timed + warm-up groups, the sequential parity re-run, the
 # per-op profiled and the segment-timed forwards); their number is read from the head_finalize_all_kernel calls
 python tools/rocprof_conv_summary.py $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv 60 $OUT/bench_line_res50_1024.json > $OUT/rocprof_vs_bench.txt
+# The default command keeps eight slots in flight: two F(4x4) launches of different slots share the CUs and each one's duration in
+# the trace above is longer than alone (their sum per frame exceeds the step time).  The SAME command with one slot (--inflight 1:
+# launches back to back on one stream) is what bench.py's per-launch figures (serial profile pass) are comparable with:
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt1 --output-format csv -- $B --inflight 1 > $OUT/bench_inflight1_under_rocprof.log 2>&1
+cp /tmp/raw/kt1_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_res50_1024_inflight1.csv
+python tools/rocprof_conv_summary.py $OUT/rocprofv3_kernel_stats_bench_res50_1024_inflight1.csv 60 $OUT/bench_line_res50_1024.json > $OUT/rocprof_vs_bench_inflight1.txt
 # HBM traffic by request size class, per dispatch (tools/experiments/traffic_r4.sh has the calibration passes)
 P="python bench.py --steps 32 --warmup 8 --cpu-frames 0 --host-frames 0 --inflight 1 --profile-frames 1 --graph 0 --ungrouped-steps 0"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d /tmp/raw -o fwd_rd --output-format csv -- $P > /tmp/raw/fwd_rd.log 2>&1
