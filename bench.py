@@ -156,18 +156,20 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
             "by_op": [{"op": r[0], "ms": round(r[1], 4), "GBps": round(gbs(r[2], r[1]), 1),
                        "algorithmic_tflops": round(r[3] / (r[1] * 1e-3) / 1e12, 1) if r[1] > 0 else 0.0}
                       for r in sorted(rows, key=lambda r: -r[1])[:8]],
-            # the two layers with real matrix work, priced as what they are: f32 MFMA work.  conv1 pads K = 3 x 49 = 147 to 196
-            # (two-channel stages) and N = 24 to 32 output channels; conv2 (48 -> 64, 5x5) pads nothing
+            # the two layers with real matrix work, priced as what they are: f32 MFMA work.  conv1 (conv_stem_s4.h, kernel class
+            # 20 / 19) pads K = 3 x 49 = 147 to 3 x 7 x 8 = 168 and N = 24 to 32 output channels (the generic class 6: K = 196);
+            # conv2 (48 -> 64, 5x5) pads nothing
             "mfma_side": {"bound": "mfma", "peak": 157.3, "unit": "TFLOP/s",
                           "kernels": [{"op": r[0].split("#")[0], "ms": round(r[1], 4),
                                        "algorithmic_tflops": round(r[3] / (r[1] * 1e-3) / 1e12, 1),
                                        "executed_tflops": round(r[3] * pad / (r[1] * 1e-3) / 1e12, 1),
                                        "frac": round(r[3] * pad / (r[1] * 1e-3) / 1e12 / 157.3, 4)}
-                                      for r in rows for nm0, pad in (("conv1", 196.0 / 147.0 * 32.0 / 24.0), ("conv2", 1.0))
+                                      for r in rows for nm0, pad in (("conv1", (196.0 if "#k6t" in r[0] else 168.0) / 147.0 * 32.0 / 24.0),
+                                                                     ("conv2", 1.0))
                                       if r[0].split("#")[0] == nm0 and r[1] > 0]},
             "note": "bytes = un-fused algorithmic lower bound (each op reads its inputs and writes its output once, f32; "
                     "weights once).  The whole net is 1.87 GFLOP and 77 MB per frame over 40 launches: launch-latency bound, "
-                    "which is why several batches are kept in flight; conv1 (3 -> 24 channels, K = 147 padded to 196, N = 24 "
+                    "which is why several batches are kept in flight; conv1 (3 -> 24 channels, K = 147 padded to 168, N = 24 "
                     "padded to 32) and conv2 are the two layers with real matrix work (algorithmic_tflops)"}
 
     cpu, parity = None, None
@@ -241,7 +243,7 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
 
 
 KIND_NAMES = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2", "3x3s1_wino", "3x3d2_wino", "1x1s1_k32",
-              "1x1s1_k64", "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44", "1x1s1_p16", "1x1s1_p32", "7x7s2_u8", "7x7s4_u8"]
+              "1x1s1_k64", "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44", "1x1s1_p16", "1x1s1_p32", "7x7s2_u8", "7x7s4_u8", "7x7s4_k168"]
 WINO_KINDS = (8, 9, 14, 15)   # conv.h: Winograd kinds execute fewer MACs than the direct form:
 WINO_RATIO = {8: 2.25, 9: 2.25, 14: 4.0, 15: 4.0}   # F(2x2,3x3) 16/36 of them, F(4x4,3x3) (CONV_3x3_{S1,D2}_WINO44) 36/144
 
@@ -254,7 +256,9 @@ def kernel_label(kind, tile):
         return "%s<%s, tile %d>" % (k, KIND_NAMES[kind], tile)
     if kind == 13:            # conv.h: CONV_3x3_S1_N8, the vector-ALU kernel of the narrow heads (conv_n8.h)
         return "conv_n8_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
-    if kind in (18, 19):      # conv.h: CONV_7x7_S2_U8 / _S4_U8, the stem conv on the raw uint8 frame (conv_stem_u8.h)
+    if kind in (19, 20):      # conv.h: CONV_7x7_S4_U8 / _K168, the stride-4 stem of FaceBoxes (conv_stem_s4.h)
+        return "conv_stem_s4_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
+    if kind == 18:            # conv.h: CONV_7x7_S2_U8, the stem conv on the raw uint8 frame (conv_stem_u8.h)
         return "conv_stem_u8_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
     if kind in (16, 17):      # conv.h: CONV_1x1_S1_P16 / _P32, the persistent-tile 1x1 kernel (conv_1x1p.h)
         return "conv1x1p_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)

@@ -31,6 +31,7 @@
 #include "conv_wino44.h"
 #include "conv_1x1p.h"
 #include "conv_stem_u8.h"
+#include "conv_stem_s4.h"
 
 namespace fdt {
 namespace {
@@ -184,7 +185,8 @@ struct Table {
     conv_fill_wino44(e[CONV_3x3_S1_WINO44]);
     conv_fill_wino44_d2(e[CONV_3x3_D2_WINO44]);
     conv_fill_1x1_p(e[CONV_1x1_S1_P16], e[CONV_1x1_S1_P32]);
-    conv_fill_stem_u8(e[CONV_7x7_S2_U8], e[CONV_7x7_S4_U8]);
+    conv_fill_stem_u8(e[CONV_7x7_S2_U8]);
+    conv_fill_stem_s4(e[CONV_7x7_S4_K168], e[CONV_7x7_S4_U8]);
   }
 };
 
@@ -198,7 +200,8 @@ const ConvGeom kGeoms[CONV_KIND_COUNT] = {
     {3, 3, 2, 1, 1, 4, 0},  {7, 7, 2, 1, 3, 2, 0},  {7, 7, 4, 1, 3, 2, 0}, {5, 5, 2, 1, 2, 2, 0},
     {3, 3, 1, 1, 1, 8, 1},  {3, 3, 1, 2, 2, 8, 1},  {1, 1, 1, 1, 0, 32, 0},  {1, 1, 1, 1, 0, 64, 0},
     {7, 7, 2, 1, 1, 2, 0},  {3, 3, 1, 1, 1, 1, 0},  {3, 3, 1, 1, 1, 2, 2},  {3, 3, 1, 2, 2, 2, 2},
-    {1, 1, 1, 1, 0, 16, 0}, {1, 1, 1, 1, 0, 32, 0}, {7, 7, 2, 1, 3, 4, 0},  {7, 7, 4, 1, 3, 4, 0},
+    {1, 1, 1, 1, 0, 16, 0}, {1, 1, 1, 1, 0, 32, 0}, {7, 7, 2, 1, 3, 4, 0},  {7, 7, 4, 1, 3, 3, 0},
+    {7, 7, 4, 1, 3, 3, 0},
 };
 const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum ConvTile)
     {128, 128, 8, 16}, {128, 64, 8, 16}, {128, 32, 8, 16}, {64, 64, 8, 8},   {64, 128, 8, 8},
@@ -237,7 +240,8 @@ ConvKind conv_base_kind(ConvKind k) {
     case CONV_1x1_S1_P16:
     case CONV_1x1_S1_P32: return CONV_1x1_S1;
     case CONV_7x7_S2_U8: return CONV_7x7_S2;
-    case CONV_7x7_S4_U8: return CONV_7x7_S4;
+    case CONV_7x7_S4_U8:
+    case CONV_7x7_S4_K168: return CONV_7x7_S4;
     default: return k;
   }
 }
@@ -271,6 +275,17 @@ void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKin
   const int nstages = (Cin + KC - 1) / KC;
   // Layout::WSZP (dwordx4 LDS-DMA granularity); the 8-channel VALU kernel stages exactly its 72 weights (N8::WSZ)
   // ... and the F(4x4,3x3) kernel exactly its 2 x 36 x 64 (W44::WSZ: 2 x 8 KB + 2 KB of LDS-DMA per k-step)
+  if (kind == CONV_7x7_S4_K168 || kind == CONV_7x7_S4_U8) {
+    // conv_stem_s4.h: [channel tile][c][ky][8 columns = taps -1 .. 6][32 couts], the first column zero (StemS4::WSZ = 5376 floats per tile)
+    out.assign((size_t)n_tiles * 3 * 7 * 8 * 32, 0.0f);
+    if (Cin != 3 || BN != 32) return;      // (conv_shape_supported keeps such a layer off these classes)
+    for (int co = 0; co < Cout; ++co)
+      for (int ci = 0; ci < 3; ++ci)
+        for (int t = 0; t < 49; ++t)
+          out[(((size_t)(co / 32) * 3 + ci) * 7 + t / 7) * 256 + (size_t)(t % 7 + 1) * 32 + co % 32] =
+              w[((size_t)co * 3 + ci) * 49 + t] * (scale ? scale[co] : 1.0f);
+    return;
+  }
   const size_t wszp = (BN == 8 || g.wino == 2) ? (size_t)KC * taps * BN : ((size_t)KC * taps * BN + 1023) / 1024 * 1024;
   out.assign((size_t)n_tiles * nstages * wszp, 0.0f);
   for (int co = 0; co < Cout; ++co) {
@@ -367,6 +382,9 @@ bool conv_shape_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
     return a.in_u8 != nullptr && a.Cin == 3 && a.ksplit <= 1 && !a.ws && !a.res && !a.up && !a.sk_count &&
            (long long)(a.Cout + 64) * a.Hout * a.Wout * 4 < (1ll << 31);
   if (a.in_u8) return false;   // every other class reads f32 NCHW
+  if (kind == CONV_7x7_S4_K168)
+    return a.Cin == 3 && a.ksplit <= 1 && !a.ws && !a.res && !a.up && !a.sk_count && (long long)3 * a.Hin * a.Win * 4 < (1ll << 31) &&
+           (long long)(a.Cout + 64) * a.Hout * a.Wout * 4 < (1ll << 31);
   if (kind_is_persistent(kind)) {
     const int nstages = ceil_div(a.Cin, conv_geom(kind).kc);
     const long long hw = (long long)a.Hin * a.Win;
@@ -455,6 +473,16 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
     FDT_LAUNCH_CHECK();
     return FDT_OK;
   }
+  if (kind == CONV_7x7_S4_K168 || kind == CONV_7x7_S4_U8) {
+    // conv_stem_s4.h: persistent over the (image, spatial tile) pairs, three workgroups per CU; grid.y = channel tile
+    const long long total = (long long)a.B * tiles;
+    FDT_REQUIRE(total <= 0x7fffffffll && n_ct <= 65535, FDT_ERR_ARG, "launch_conv: grid too large");
+    const int k = (int)ceil_div_ll(total, (long long)device_cus(dev) * 3);
+    a.tiles_per_wg = k;
+    hipLaunchKernelGGL(ke.fn, dim3((unsigned)ceil_div_ll(total, k), (unsigned)n_ct), dim3(ke.threads), ke.lds, st, a);
+    FDT_LAUNCH_CHECK();
+    return FDT_OK;
+  }
   FDT_REQUIRE(a.map_mode >= CONV_MAP_ROWS && a.map_mode < CONV_MAP_COUNT, FDT_ERR_ARG, "launch_conv: bad map mode");
   const long long gx = (a.map_mode == CONV_MAP_XCD_SPATIAL || a.map_mode == CONV_MAP_XCD_REGION)
                            ? (long long)ceil_div(tiles, 8) * 8 * n_ct
@@ -527,6 +555,7 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
   if (kind == CONV_3x3_S1_D2 && tile_is_wino((ConvTile)tile)) kind = CONV_3x3_D2_WINO;
   if (kind == CONV_3x3_S1 && tile == TILE_N8_32x64) kind = CONV_3x3_S1_N8;
   if (kind == CONV_1x1_S1 && (tile == TILE_P_128x64 || tile == TILE_P_128x128)) kind = CONV_1x1_S1_P16;
+  if (kind == CONV_7x7_S4 && tile == TILE_128x32W) kind = CONV_7x7_S4_K168;   // conv_stem_s4.h (Cin = 3 only: checked at launch)
   FDT_REQUIRE(tile >= 0 && tile < CONV_TILE_COUNT && conv_supported((ConvKind)kind, (ConvTile)tile), FDT_ERR_ARG,
               "fdt_conv2d: kernel (kind %d, tile %d) not instantiated", kind, tile);
   const bool combine = ksplit > 0 && (ksplit & FDT_SPLIT_COMBINE);   // in-kernel combine instead of the reduce pass

@@ -173,8 +173,8 @@ KernelEntry entry_stem() {
 
 //                       stride BN  WM WN
 using STEM_S2_N64 = StemU8<2, 64, 2, 2>;     // Res50: 3 -> 64, 7x7 / 2
-using STEM_S4_N32 = StemU8<4, 32, 4, 1>;     // FaceBoxes: 3 -> 24 (one 32-channel tile), 7x7 / 4
+// (FaceBoxes' 7x7 / 4 stem on the raw frame: conv_stem_s4.h)
 
 }  // namespace
-void conv_fill_stem_u8(void* row_s2, void* row_s4);
+void conv_fill_stem_u8(void* row_s2);
 }  // namespace fdt

@@ -401,6 +401,13 @@ struct Builder {
     int groups = 1;           // grouped 1x1 (pyramid_mobile_try1.py:185-186): run as the block-diagonal dense conv
   };
 
+  static bool stem_s4_enabled() {
+#ifdef FDT_EXPERIMENTS   // A/B against the generic direct kernel (tools/experiments/r4_job27.sh)
+    if (const char* e = getenv("FDT_STEM_S4")) return atoi(e) != 0;
+#endif
+    return true;
+  }
+
   int conv(const std::string& name, int in_t, int Cout, ConvKind kind, const ConvOpt& o) {
     if (rc != FDT_OK) return -1;
     const Tensor in = m->tensors[in_t];
@@ -450,6 +457,12 @@ struct Builder {
       op.tile = TILE_N8_32x64;
       const long long wgs = (long long)B * ceil_div(Ho, tile_th(op.tile)) * ceil_div(Wo, tile_tw(op.tile));
       while (wgs * ksplit < 512 && ksplit * 2 <= std::min(32, in.C / 8)) ksplit *= 2;
+    } else if (kind == CONV_7x7_S4 && in.C == 3 && o.groups == 1 && o.res_t < 0 && o.up_t < 0 &&
+               conv_supported(CONV_7x7_S4_K168, TILE_128x32W) && stem_s4_enabled()) {
+      // FaceBoxes' stem: K = 3 x 7 x 8 instead of 4 x 49, three workgroups per CU (conv_stem_s4.h)
+      kind = CONV_7x7_S4_K168;
+      op.kind = kind;
+      op.tile = TILE_128x32W;
     } else {
       choose(kind, Ctot, in.C, Ho, Wo, B, o.up_t >= 0, op.tile, ksplit);
     }

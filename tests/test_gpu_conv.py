@@ -420,3 +420,24 @@ def test_persistent_1x1_refuses_what_it_is_not_built_for():
     x = rng.standard_normal((1, 40, 20, 32)).astype(np.float32)
     rc, _ = run_conv(x, w, None, 1, 1, 0, 1, tile=16 * 100 + T_P64, split=2)   # no split-K
     assert rc != 0 and b"not instantiated" in lib().lib().fdt_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 64, 128, 24), (1, 1024, 1024, 24), (3, 45, 77, 24), (2, 130, 250, 45), (1, 7, 9, 5)])
+def test_facebox_stem_k168(shape):
+    """conv_stem_s4.h (CONV_7x7_S4_K168): 7x7 / stride 4 / pad 3 on three input channels as 84 k-pairs (3 x 7 x 8 columns, the
+    eighth column's weights zero) from a column-phase de-interleaved patch staged by LDS-DMA -- against torch, incl. odd sizes,
+    images smaller than a tile, two channel tiles, every activation."""
+    B, H, W, Cout = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    x = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, 3, 7, 7)) / np.sqrt(147)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    for act, bias in ((1, b), (0, None), (2, b)):
+        rc, got = run_conv(x, w, bias, 7, 4, 3, 1, act=act, tile=36)
+        assert rc == 0, lib().lib().fdt_last_error()
+        exp = reference(x, w, bias, 7, 4, 3, 1, act=act)
+        assert rel_err(got, exp) < 1e-5, (shape, act, rel_err(got, exp))
+    x5 = rng.standard_normal((1, 5, 32, 32)).astype(np.float32)                    # not the three-channel stem: refused
+    rc, _ = run_conv(x5, rng.standard_normal((8, 5, 7, 7)).astype(np.float32), None, 7, 4, 3, 1, tile=36)
+    assert rc != 0 and b"not instantiated" in lib().lib().fdt_last_error()
