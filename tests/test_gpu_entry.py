@@ -243,3 +243,18 @@ def test_c4_full_size_1080p_source_to_640x480(synth, res50_sd):
     finally:
         cal.net.close()
         cal.net = old_net
+
+
+@pytest.mark.parametrize("shape", [(270, 480), (133, 241), (96, 160), (301, 1024), (64, 3632)])
+def test_resize_kernels_agree_with_the_oracle(entry, shape):
+    """Both resize kernels (ops.hip): the workgroup-per-row form (source rows of a multiple of 16 bytes: 480, 160, 1024, 3632 pixels
+    wide -- the last one with a partly filled last 1 KB chunk per row) and the per-pixel form (241: rows of 723 bytes) give the
+    oracle's resized + mean-subtracted tensor bit for bit, up- and down-scaling."""
+    from oracle import ingest
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    src = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+    small = ingest.resize_linear_u8(src, 160, 128)
+    entry.net(small)
+    ref = entry.net.get_tensor("input")
+    entry.net.forward_resized(src, (160, 128))
+    assert np.array_equal(entry.net.get_tensor("input"), ref)
