@@ -248,6 +248,24 @@ WINO_KINDS = (8, 9, 14, 15)   # conv.h: Winograd kinds execute fewer MACs than t
 WINO_RATIO = {8: 2.25, 9: 2.25, 14: 4.0, 15: 4.0}   # F(2x2,3x3) 16/36 of them, F(4x4,3x3) (CONV_3x3_{S1,D2}_WINO44) 36/144
 
 
+def clock_fields(achieved_tflops, kind):
+    """QUOTED measurement (not taken in this run): shader clock inside the F(4x4,3x3) kernel's main loop on full-chip layers."""
+    if kind not in (14, 15):
+        return {}
+    for rnd in ("r04",):
+        f = os.path.join(ROOT, "profiles", rnd, "wino44_clock.json")
+        if os.path.exists(f):
+            c = json.load(open(f))
+            lo, hi = c["sustained_mhz_full_chip_layers"]
+            mid = 0.5 * (lo + hi)
+            peak = PEAK_F32_MFMA_TFLOPS * mid / c["paper_mhz"]
+            return {"sustained_clock_mhz": [lo, hi], "peak_at_sustained_clock": round(peak, 1),
+                    "frac_at_sustained_clock": round(achieved_tflops / peak, 4),
+                    "clock_source": "profiles/%s/wino44_clock.json (s_memtime / s_memrealtime inside the kernel's main loop; QUOTED, "
+                                    "not measured in this run)" % rnd}
+    return {}
+
+
 def kernel_label(kind, tile):
     """Kernel template a (kind, tile) pair of conv.h launches (names as rocprofv3 prints them)."""
     if kind in WINO_KINDS:
@@ -808,6 +826,9 @@ def main():
             "time_share_of_convs": round(dg[1] / conv_ms, 4),
             "algorithmic_gflop_per_launch": round(dg[2] / dg[0] / 1e9, 3),
             "executed_gflop_per_launch": round(dg[3] / dg[0] / 1e9, 3),
+            # the clock the chip holds under the dominant kernel (measured inside the kernel, committed under profiles/): the peak
+            # above is the 2.4 GHz paper figure; `frac` stays defined on it
+            **clock_fields(tf(dg[3], dg[1]), dk),
             "traffic": traffic, "traffic_source": traffic_src, "traffic_calibrated": traffic_cal,
             "traffic_over_algorithmic": traffic_ratio, "traffic_by_class": traffic_classes,
             "traffic_note": ("QUOTED from the committed PMC summary named in traffic_source (separate rocprofv3 --pmc passes of "
