@@ -8,7 +8,7 @@ L = cb.lib.lib()
 buf = (ctypes.c_longlong * 8)()
 SHAPES = [(14, 256, 256, 256, 256, 1), (14, 512, 128, 128, 512, 1), (14, 1024, 64, 64, 1024, 2), (14, 256, 256, 256, 128, 1), (15, 256, 256, 256, 128, 1),
           (14, 128, 128, 128, 128, 1)]
-for kind, cin, h, w, cout, split in SHAPES:
+for kind, cin, h, w, cout, split in SHAPES[:int(os.environ.get('W44_SHAPES', len(SHAPES)))]:
     cb.bench(kind, 32, split, cin, h, w, cout, iters=3)
     L.fdt_debug_w44_times(buf)                      # drop the warm-up launches
     ms = cb.bench(kind, 32, split, cin, h, w, cout, iters=20)
