@@ -425,8 +425,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (one batched forward)")
     ap.add_argument("--group", type=int, default=0,
                     help="frames are handed to the pipeline ONE AT A TIME but executed GROUP at a time (one launch per layer for "
-                         "GROUP consecutive frames: pipeline.step_frame); a step stays one frame per GPU.  0 = auto: 4 for "
-                         "Res50 frames of at most 1024x1024 at --batch 1 when tuned/ holds the batch-4 plan, else 1")
+                         "GROUP consecutive frames: pipeline.step_frame); a step stays one frame per GPU.  0 = auto for Res50 at "
+                         "--batch 1: 8 up to 640x480, 4 up to 1024x1024 (when tuned/ holds that batch's plan), else 1")
     ap.add_argument("--ungrouped-steps", type=int, default=64,
                     help="with grouping on (N = 1): also time this many steps of the --group 1 form (reported as `ungrouped`); 0 = skip")
     ap.add_argument("--source", default="", help="HxW of raw source frames (e.g. 1080x1920): the frames are resized on the "
@@ -491,8 +491,16 @@ def main():
     B = max(1, args.batch)
     # cross-frame grouped launches: G consecutive frames of a rank share one launch per layer (the handle runs its batch-G
     # plan); every leg below then works on batches of G, only the timed loop hands the frames over one by one
-    G = args.group if args.group > 0 else (4 if (args.arch == "res50" and B == 1 and H * W <= 1024 * 1024 and os.path.exists(
-        os.path.join(ROOT, "face-detection-and-tracking_amd", "tuned", "res50_%dx%d_b4.plan" % (W, H)))) else 1)
+    def has_plan(b):
+        return os.path.exists(os.path.join(ROOT, "face-detection-and-tracking_amd", "tuned", "res50_%dx%d_b%d.plan" % (W, H, b)))
+    G = args.group
+    if G <= 0:      # auto: eight per launch chain at the tracker's frame size (831 vs 788 frames/s with four), four up to 1024x1024
+        G = 1
+        if args.arch == "res50" and B == 1:
+            if H * W <= 640 * 480 and has_plan(8):
+                G = 8
+            elif H * W <= 1024 * 1024 and has_plan(4):
+                G = 4
     if G > 1:
         if B != 1:
             raise SystemExit("--group needs --batch 1 (a step is one frame per GPU)")
