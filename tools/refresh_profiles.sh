@@ -72,7 +72,7 @@ timeout -k 10 300 python tools/profile_layers.py --batch 4 > $OUT/per_layer_hip_
 timeout -k 10 300 python bench.py --steps 256 --warmup 32 --group 1 --cpu-frames 0 --host-frames 0 > $OUT/bench_line_res50_1024_group1.json
 timeout -k 10 300 python bench.py --steps 256 --warmup 32 --height 480 --width 640 > $OUT/bench_line_res50_640x480.json
 timeout -k 10 300 python bench.py --steps 256 --warmup 32 --height 480 --width 640 --group 1 --cpu-frames 0 --host-frames 0 > $OUT/bench_line_res50_640x480_group1.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt480 --output-format csv -- python bench.py --steps 64 --warmup 8 --height 480 --width 640 --cpu-frames 0 --host-frames 0 > $OUT/bench_640x480_under_rocprof.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt480 --output-format csv -- python bench.py --steps 64 --warmup 8 --height 480 --width 640 --cpu-frames 0 --host-frames 0 --ungrouped-steps 0 > $OUT/bench_640x480_under_rocprof.log 2>&1
 cp /tmp/raw/kt480_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_res50_640x480.csv
 timeout -k 10 200 python tools/profile_layers.py --height 480 --width 640 > $OUT/per_layer_hip_events_res50_640x480.txt
 timeout -k 10 300 python bench.py --steps 128 --warmup 16 --source 1080x1920 --height 480 --width 640 --host-frames 256 > $OUT/bench_line_res50_640x480_from_1080p.json
@@ -82,6 +82,8 @@ timeout -k 10 300 python bench.py --steps 32 --warmup 4 --arch try3 --batch 8 > 
 timeout -k 10 300 python bench.py --arch facebox --batch 16 --steps 100 --warmup 8 > $OUT/bench_line_facebox_4k_b16.json
 timeout -k 10 400 python bench.py --steps 32 --warmup 6 --batch 2 --cpu-frames 0 > $OUT/bench_line_res50_1024_b2.json
 timeout -k 10 300 python bench.py --steps 48 --warmup 8 --height 480 --width 640 --batch 4 --cpu-frames 0 > $OUT/bench_line_res50_640x480_b4.json
+timeout -k 10 300 python bench.py --steps 256 --warmup 32 --height 480 --width 640 --group 4 --cpu-frames 0 --host-frames 0 --ungrouped-steps 0 > $OUT/bench_line_res50_640x480_group4.json
+timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line_res50_1024_driver_style.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o ktfb --output-format csv -- python bench.py --arch facebox --batch 16 --steps 50 --warmup 5 --cpu-frames 0 > $OUT/bench_facebox_under_rocprof.log 2>&1
 cp /tmp/raw/ktfb_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_facebox_4k_b16.csv
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kttry3 --output-format csv -- python bench.py --steps 32 --warmup 4 --arch try3 --batch 8 --cpu-frames 0 --host-frames 0 > $OUT/bench_try3_b8_under_rocprof.log 2>&1
