@@ -52,6 +52,7 @@ int main(int argc, char** argv) {
   const char* wfile = argv[1];
   const char* ffile = argv[2];
   const int n_frames = atoi(argv[3]), H = atoi(argv[4]), W = atoi(argv[5]), inflight = atoi(argv[6]);
+  const int host_mode = argc > 7 && atoi(argv[7]);   /* 1: frames stay in host memory, fdt_pipeline_step_host uploads them */
   fdt_model* m = fdt_model_create(FDT_ARCH_RES50, 0);
   if (!m) { fprintf(stderr, "create: %s\n", fdt_last_error()); return 1; }
   FILE* f = fopen(wfile, "rb");
@@ -83,13 +84,19 @@ int main(int argc, char** argv) {
   if (!f || fread(host, 1, (size_t)(fb * n_frames), f) != (size_t)(fb * n_frames)) return 5;
   fclose(f);
   void* dev = NULL;
-  CHECK(fdt_dev_malloc(&dev, fb * n_frames));
-  CHECK(fdt_dev_upload(dev, host, fb * n_frames));
+  if (!host_mode) {
+    CHECK(fdt_dev_malloc(&dev, fb * n_frames));
+    CHECK(fdt_dev_upload(dev, host, fb * n_frames));
+  }
   fdt_pipeline* p = fdt_pipeline_create(m, 0, H, W, inflight, 1, NULL, NULL, 0, 1, 0, 0, 0.4f, 0.4, 0.6, 5, 8);
   if (!p) { fprintf(stderr, "pipeline: %s\n", fdt_last_error()); return 1; }
-  CHECK(fdt_pipeline_prime(p, dev));
+  if (!host_mode) CHECK(fdt_pipeline_prime(p, dev));
   CHECK(fdt_pipeline_mark(p, 0));
-  { int i; for (i = 0; i < n_frames; ++i) CHECK(fdt_pipeline_step(p, i, (unsigned char*)dev + fb * i)); }
+  { int i;
+    for (i = 0; i < n_frames; ++i) {
+      if (host_mode) CHECK(fdt_pipeline_step_host(p, i, host + fb * i, 1));
+      else CHECK(fdt_pipeline_step(p, i, (unsigned char*)dev + fb * i));
+    } }
   CHECK(fdt_pipeline_mark(p, 1));
   CHECK(fdt_pipeline_sync(p));
   { float ms = 0; CHECK(fdt_pipeline_elapsed_ms(p, &ms)); fprintf(stderr, "%d frames, %d in flight: %.3f ms\n", n_frames, inflight, ms); }
@@ -109,7 +116,7 @@ int main(int argc, char** argv) {
       free(boxes);
     } }
   fdt_pipeline_destroy(p);
-  CHECK(fdt_dev_free(dev));
+  if (dev) CHECK(fdt_dev_free(dev));
   fdt_model_destroy(m);
   free(host);
   printf("ok\n");
@@ -146,17 +153,18 @@ def test_plain_c_program_runs_two_frames_in_flight_detect_and_track(tmp_path, re
     src.write_text(C_DRIVER)
     subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", INC, str(src), "-o", str(exe), "-L", LIBDIR, "-lfdt_hip",
                     "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    r = subprocess.run([str(exe), str(wfile), str(ffile), str(N), str(H), str(W), "2"], stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-2000:])
-    got = []
-    for ln in r.stdout.splitlines():
-        p = ln.split()
-        if p and p[0] == "track":
-            sf, nb, ms = int(p[1]), int(p[2]), float(p[3])
-            v = [float(x) for x in p[4:]]
-            got.append((sf, ms, [v[4 * i:4 * i + 4] for i in range(nb)]))
-    assert got == want
+    for host_mode in ("0", "1"):      # frames uploaded once (fdt_dev_*) / frames in host memory (fdt_pipeline_step_host)
+        r = subprocess.run([str(exe), str(wfile), str(ffile), str(N), str(H), str(W), "2", host_mode], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-2000:])
+        got = []
+        for ln in r.stdout.splitlines():
+            p = ln.split()
+            if p and p[0] == "track":
+                sf, nb, ms = int(p[1]), int(p[2]), float(p[3])
+                v = [float(x) for x in p[4:]]
+                got.append((sf, ms, [v[4 * i:4 * i + 4] for i in range(nb)]))
+        assert got == want, host_mode
 
 
 @pytest.mark.parametrize("batch,inflight", [(1, 3), (2, 2)])
