@@ -33,6 +33,7 @@ namespace fdt {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ float g_ir_zero[4];   // source of every out-of-image / padding element of the staged patch (zero-initialised)
@@ -53,12 +54,12 @@ struct IrTile {
 // KS = Cin / 2 when known at compile time (the GEMM loop is then fully unrolled: all operand reads of a column tile are in
 // flight before its first MFMA), 0 = runtime loop.
 template <int S, int KS, bool PROJ = false>
-__global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict__ x, int Cin, int H, int W,
+__global__ __launch_bounds__(256, (S == 1 && KS > 0 && KS <= 12 && !PROJ) ? 3 : 1) void expand_dw_kernel(const float* __restrict__ x, int Cin, int H, int W,
                                                         const float* __restrict__ w1, const float* __restrict__ b1,
                                                         const float* __restrict__ wdw, const float* __restrict__ bdw,
                                                         int hid, float* __restrict__ out, int Ho, int Wo,
                                                         const float* __restrict__ wp = nullptr, const float* __restrict__ bp = nullptr,
-                                                        int oup = 0, int residual = 0) {
+                                                        int oup = 0, int residual = 0, int total_tiles = 0, int tiles_per_wg = 1) {
   using T = IrTile<S>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                                   // [Cin][NPOSP]
@@ -66,20 +67,74 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict_
   float* ws = hs + 32 * T::NPOSP;                     // [Cin][32]: this chunk's expand weights, k-major (A operand)
   float* wps = ws + 32 * Cin;                         // PROJ: [2][32 k][32 oup] project weights of the chunk, double buffered
   constexpr int NPX = T::TH * T::TW;                  // output pixels of the tile: 128 (stride 1) / 64 (stride 2)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tiles_x = (Wo + T::TW - 1) / T::TW, tiles_y = (Ho + T::TH - 1) / T::TH;
+  const int n_sp = tiles_x * tiles_y;
+  // PERSISTENT (round 4): the workgroup walks the (image, tile) pairs ti0 .. ti1 - 1 (launch_expand_dw sizes the grid for the
+  // workgroups a CU holds).  When Cin is a template constant and the rows are 16-byte aligned (W % 4 == 0) the patch of the NEXT
+  // tile is fetched as 16-byte pieces into registers right after this tile's patch has become visible, and written to LDS when
+  // the tile is done: the staging that one-tile workgroups exposed (features.2: 279 -> 210 us without it) runs under the chunks.
+  // The barriers of the loop wait for LDS only (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also wait for vmcnt(0),
+  // i.e. for the prefetch.
+  const int ti0 = blockIdx.x * tiles_per_wg, ti1 = min(ti0 + tiles_per_wg, total_tiles);
+  constexpr int NQ = (T::PWR + 3 + 3) / 4;              // 16-byte pieces per patch row, from the aligned column ox0 * S - 4
+  constexpr bool VEC = KS > 0 && !PROJ;              // (the whole-block form keeps its registers for the project accumulator)
+  constexpr int NPC = VEC ? 2 * KS * T::PH * NQ : 1, NITP = (NPC + 255) / 256;
+  const bool vec = VEC && (W & 3) == 0;
+  f32x4 pv[NITP];
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto fetch = [&](int ti) {
+    const int b_ = ti / n_sp, sp_ = ti - b_ * n_sp;
+    const int gy0_ = (sp_ / tiles_x) * T::TH * S - 1, gxa_ = (sp_ % tiles_x) * T::TW * S - 4;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long long)b_ * Cin * H * W), 0,
+                                                                          (int)min((long long)Cin * H * W * 4, 0x7fffffffll), 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NITP; ++k) {
+      const int i = tid + 256 * k;
+      const int r = i / NQ, q = i - r * NQ;
+      const int c = r / T::PH, py = r - c * T::PH;
+      const int gy = gy0_ + py, gx = gxa_ + 4 * q;
+      const bool ok = i < NPC && gy >= 0 && gy < H && gx >= 0 && gx < W;       // W % 4 == 0: a piece is wholly inside or outside
+      const unsigned vo = ok ? (unsigned)((c * H + gy) * W + gx) * 4u : 0x80000000u;
+      pv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0));
+    }
+  };
+  if (vec && ti0 < ti1) fetch(ti0);
+  if (VEC) {      // the pitch / tile padding of the patch is never written by the pieces: zero it once (it only feeds positions that
+                  // the expand phase zeroes again, but uninitialised LDS may hold NaNs)
+    for (int e = tid; e < Cin * T::NPOSP; e += 256) xs[e] = 0.0f;
+    lds_barrier();
+  }
+
+  for (int ti = ti0; ti < ti1; ++ti) {
+  const int b = ti / n_sp, sp = ti - b * n_sp;
+  const int oy0 = (sp / tiles_x) * T::TH, ox0 = (sp % tiles_x) * T::TW;
+  const int gy0 = oy0 * S - 1, gx0 = ox0 * S - 1;
+  const float* xb = x + (long long)b * Cin * H * W;
   f32x16 pacc;                                        // PROJ: out[oup rows][32 pixels of this wave's tile row], across the chunks
 #pragma unroll
   for (int r = 0; r < 16; ++r) pacc[r] = 0.0f;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, l31 = lane & 31;
-  const int tiles_x = (Wo + T::TW - 1) / T::TW;
-  const int oy0 = (blockIdx.x / tiles_x) * T::TH, ox0 = (blockIdx.x % tiles_x) * T::TW;
-  const int b = blockIdx.z;
-  const int gy0 = oy0 * S - 1, gx0 = ox0 * S - 1;
-  const float* xb = x + (long long)b * Cin * H * W;
 
-  // ---- stage the input patch by LDS-DMA (nothing passes through VGPRs, all loads in flight together); out-of-image and
-  // pitch-padding elements read a zero word.  Element e = 256 * k + tid lands at float e: wave-uniform base + lane * 4.
-  {
+  if (vec) {
+    // piece (row r, column group q) holds the patch columns 4 q - 3 .. 4 q of row r (the patch starts at image column ox0 * S - 1)
+#pragma unroll
+    for (int k = 0; k < NITP; ++k) {
+      const int i = tid + 256 * k;
+      if (i < NPC) {
+        const int r = i / NQ, q = i - r * NQ;
+        const int c = r / T::PH, py = r - c * T::PH;
+        float* d = xs + c * T::NPOSP + py * T::PWP + 4 * q - 3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int px = 4 * q - 3 + e;
+          if (px >= 0 && px < T::PWR) d[e] = pv[k][e];
+        }
+      }
+    }
+  } else {
+    // ---- stage the input patch by LDS-DMA (nothing passes through VGPRs, all loads in flight together); out-of-image and
+    // pitch-padding elements read a zero word.  Element e = 256 * k + tid lands at float e: wave-uniform base + lane * 4.
     const float* zpad = g_ir_zero;
     const int total = Cin * T::NPOSP;
     for (int e0 = 0; e0 < (FDT_IR_EXP == 4 ? 0 : total); e0 += 256) {
@@ -126,8 +181,9 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict_
         wq[e] = (o < oup && hw < hid) ? wp[(long long)o * hid + hw] : 0.0f;
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the patch (first chunk) has landed
-    __syncthreads();
+    if (!vec && ch == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the patch has landed
+    lds_barrier();
+    if (vec && ch == 0 && ti + 1 < ti1) fetch(ti + 1);   // the next tile's patch: in flight under this tile's chunks
     // ---- expand: hs[32][positions] = ReLU6(W1[chunk] . xs + b1), column tiles dealt round-robin to the four waves
     // A wave owns the column tiles wave, wave + 4, ...: their accumulation chains are independent, so they are advanced
     // together (one dependent MFMA chain alone leaves the matrix pipe idle 3/4 of the time at one wave per SIMD); the A
@@ -186,7 +242,7 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict_
         for (int r = 0; r < (FDT_IR_EXP == 3 ? 1 : 16); ++r) hp[(size_t)((r & 3) + 8 * (r >> 2)) * T::NPOSP] = vv[r];
       }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- depthwise 3x3: thread = (channel of the chunk, strip of 4 output columns), all TH rows of the tile
     {
@@ -257,7 +313,7 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict_
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     if constexpr (PROJ) {
       // ---- project: pacc[oup][pixels] += Wp[:, chunk] . dw[chunk][pixels]; wave w owns tile row w (32 pixels); channel
       // pairs ascending = the k order of the stand-alone 1x1 kernel.  (The padded hidden channels of a last, partly filled
@@ -297,6 +353,8 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict_
       }
     }
   }
+  lds_barrier();      // every wave is done with xs (the residual) and hs: the next tile's patch may overwrite them
+  }   // tiles of this workgroup
 }
 
 }  // namespace
@@ -308,6 +366,18 @@ size_t expand_dw_lds_bytes(int Cin, int stride, int hid) {
 }
 size_t ir_block_lds_bytes(int Cin, int stride, int hid) { return expand_dw_lds_bytes(Cin, stride, hid) + 2 * 1024 * sizeof(float); }
 
+// tiles a persistent workgroup walks: the grid fills every CU with the workgroups its LDS holds (at most four: 16 waves), and all of
+// them get the same number of tiles (+-1 at the end)
+static int ir_tiles_per_wg(long long total, size_t lds, int dev) {
+  int cus = 256;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const int resident = (int)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / lds));
+#ifdef FDT_EXPERIMENTS   // tools/experiments/ir_persistent.sh: 0 = one tile per workgroup (the round-3 launch)
+  if (const char* e = getenv("FDT_IR_TILES")) { const int v = atoi(e); if (v > 0) return v; }
+#endif
+  return (int)std::max<long long>(1, (total + (long long)cus * resident - 1) / ((long long)cus * resident));
+}
+
 int launch_expand_dw(const float* x, int B, int Cin, int H, int W, const float* w1, const float* b1, const float* wdw,
                      const float* bdw, int hid, int stride, float* out, int Ho, int Wo, hipStream_t st, int dev) {
   FDT_REQUIRE(stride == 1 || stride == 2, FDT_ERR_ARG, "expand_dw: stride %d", stride);
@@ -316,9 +386,13 @@ int launch_expand_dw(const float* x, int B, int Cin, int H, int W, const float* 
   const size_t lds = expand_dw_lds_bytes(Cin, stride, hid);
   FDT_REQUIRE(lds <= 160 * 1024, FDT_ERR_ARG, "expand_dw: %d -> %d channels do not fit LDS", Cin, hid);
   const int th = stride == 1 ? IrTile<1>::TH : IrTile<2>::TH;
-  dim3 grid((unsigned)(ceil_div(Wo, 32) * ceil_div(Ho, th)), 1, (unsigned)B);
+  if (dev < 0) FDT_HIP(hipGetDevice(&dev));
+  const long long total = (long long)ceil_div(Wo, 32) * ceil_div(Ho, th) * B;
+  FDT_REQUIRE(total <= 0x7fffffffll, FDT_ERR_ARG, "expand_dw: grid too large");
+  const int tpw = ir_tiles_per_wg(total, lds, dev);
+  dim3 grid((unsigned)((total + tpw - 1) / tpw));
   typedef void (*Kern)(const float*, int, int, int, const float*, const float*, const float*, const float*, int, float*, int,
-                       int, const float*, const float*, int, int);
+                       int, const float*, const float*, int, int, int, int);
   const int ks = Cin >> 1;
   Kern fn = nullptr;
   if (stride == 1)
@@ -338,7 +412,7 @@ int launch_expand_dw(const float* x, int B, int Cin, int H, int W, const float* 
     FDT_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, x, Cin, H, W, w1, b1, wdw, bdw, hid, out, Ho, Wo, (const float*)nullptr,
-                     (const float*)nullptr, 0, 0);
+                     (const float*)nullptr, 0, 0, (int)total, tpw);
   FDT_LAUNCH_CHECK();
   return FDT_OK;
 }
@@ -355,9 +429,13 @@ int launch_ir_block(const float* x, int B, int Cin, int H, int W, const float* w
   const size_t lds = ir_block_lds_bytes(Cin, stride, hid);
   FDT_REQUIRE(lds <= 160 * 1024, FDT_ERR_ARG, "ir_block: %d -> %d channels do not fit LDS", Cin, hid);
   const int th = stride == 1 ? IrTile<1>::TH : IrTile<2>::TH;
-  dim3 grid((unsigned)(ceil_div(Wo, 32) * ceil_div(Ho, th)), 1, (unsigned)B);
+  if (dev < 0) FDT_HIP(hipGetDevice(&dev));
+  const long long total = (long long)ceil_div(Wo, 32) * ceil_div(Ho, th) * B;
+  FDT_REQUIRE(total <= 0x7fffffffll, FDT_ERR_ARG, "ir_block: grid too large");
+  const int tpw = ir_tiles_per_wg(total, lds, dev);
+  dim3 grid((unsigned)((total + tpw - 1) / tpw));
   typedef void (*Kern)(const float*, int, int, int, const float*, const float*, const float*, const float*, int, float*, int,
-                       int, const float*, const float*, int, int);
+                       int, const float*, const float*, int, int, int, int);
   const int ks = Cin >> 1;
   Kern fn = nullptr;
   if (stride == 1)
@@ -373,7 +451,7 @@ int launch_ir_block(const float* x, int B, int Cin, int H, int W, const float* w
     FDT_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (dev < 16) seen[dev].fetch_or(1ull << slot, std::memory_order_release);
   }
-  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, x, Cin, H, W, w1, b1, wdw, bdw, hid, out, Ho, Wo, wp, bp, oup, residual);
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, x, Cin, H, W, w1, b1, wdw, bdw, hid, out, Ho, Wo, wp, bp, oup, residual, (int)total, tpw);
   FDT_LAUNCH_CHECK();
   return FDT_OK;
 }
