@@ -112,6 +112,28 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert all(torch.equal(c, counts_k[0]) for c in counts_k), "in-flight slots disagree"
+    # ---- PCIe-inclusive: the same batches handed over as pageable HOST frames (never `value`) ------------------------------
+    host_path = None
+    if rank == 0 and world == 1 and args.host_frames > 0:
+        nb = max(2, min(8, args.host_frames // B))
+        hp = ctypes.c_void_p(frames_h.ctypes.data)
+        hb = np.empty((B, 21824, 4), np.float32)
+        hpr = np.empty((B, 21824), np.float32)
+        hc = np.zeros(B, np.int32)
+
+        def host_call():      # host frames in, host boxes / probs / counts out: synchronous (the copy in front of the resize)
+            lib.check(L.fdt_model_detect_facebox_resized(net._h, hp, 0, B, SH, SW, 0.35, 0.5, lib.ptr(hb), lib.ptr(hpr), lib.ptr(hc), None))
+        host_call()
+        th = time.perf_counter()
+        for i in range(nb):
+            host_call()
+        dh = time.perf_counter() - th
+        assert [int(c) for c in hc] == [int(c) for c in counts_k[0].cpu()], "host-frame call disagrees with the device-resident one"
+        host_path = {"value": round(nb * B / dh, 1), "unit": "frames/s", "batches": nb, "ms_per_batch": round(dh / nb * 1e3, 2),
+                     "host_bytes_per_batch": int(frames_h.nbytes),
+                     "host_to_device_GBps": round(frames_h.nbytes * nb / dh / 1e9, 1),
+                     "what": "PCIe-inclusive: fdt_model_detect_facebox_resized on pageable host frames (%d x %dx%d u8 = %.0f MB per "
+                             "batch cross the bus before the resize): bound by the copy, not by the GPU" % (B, SW, SH, frames_h.nbytes / 1e6)}
     res = net.detect_frames(frames_h)          # same kernels, host round trip: what the parity leg compares
     faces = [int(c) for c in counts.cpu()]
     assert faces == [len(p) for _, p in res], (faces, [len(p) for _, p in res])
@@ -236,7 +258,7 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
                                  "batches_in_flight": NF, "hip_graph": bool(args.graph), "device": pkg.device_name(0),
                                  "parallelism": "frame-parallel replicas x%d, no data-path collective (the path has no "
                                                 "exchange step: FACEBOX/My_test_facebox.py is detection only)" % world},
-                      "roofline": roof, "cpu_baseline": cpu, "parity": parity}))
+                      "roofline": roof, "cpu_baseline": cpu, "parity": parity, "host_path": host_path}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
