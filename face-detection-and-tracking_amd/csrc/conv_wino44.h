@@ -14,7 +14,8 @@
 //    MFMA B-operand layout) and write it to a V buffer in LDS; all eight waves then read A (weights U) and B (V) from LDS.
 //  * Everything is pipelined by k-step (two input channels = one MFMA k-depth) in SUPER-STEPS of two k-steps between two
 //    barriers: at the barrier the operands of k-step s sit in registers, the weights U(s+1), U(s+2) and the raw patches
-//    R(s+3), R(s+4) have landed (LDS-DMA rings of four slots each, one vmcnt(0) per super-step = two k-steps of flight) and
+//    R(s+3), R(s+4) have landed (LDS-DMA rings: four slots of weights with one super-step = two k-steps of flight; six
+//    slots of patch with two super-steps of flight, the wait is vmcnt(<patch instructions of the last super-step>)) and
 //    V(s+1), V(s+2) are written; each half runs its nine MFMAs while it reads a window, transforms it into V two k-steps
 //    ahead, prefetches the next operands and issues the LDS-DMA of two / four k-steps ahead (super_step below).
 //  * The matrix pipe and the vector ALU of a SIMD do not co-execute on this chip (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so the
@@ -120,7 +121,12 @@ struct W44T {
   static constexpr int XSZP = VEC ? (D == 1 ? 1600 : 1776) : 1536;   // ring slot
   static constexpr int WSZ = 2 * 36 * BN;                // 4608 floats of transformed weights per k-step: 2 x (8 waves x 1 KB) + 2 KB
   static constexpr int VSZ = 36 * 64;                    // transformed input of a k-step: [position][channel][tile]
-  static constexpr int U_SLOTS = 4, R_SLOTS = 4, V_SLOTS = 4;   // four each: the loop is unrolled by four, every ring offset an immediate
+  // U and V: four slots, the loop is unrolled by four k-steps and every offset into them is an immediate.  R (the raw patch, the
+  // one stream that comes from HBM): SIX slots with a run-time slot offset (one scalar per super-step, one v_add per window) --
+  // its LDS-DMA is issued eight k-steps ahead of the MFMAs that use it and stays in flight across a whole super-step more than
+  // the weights' (round 4: with four slots and one k-step less of flight the patch stalled the k-step by 8 % on the 256^2
+  // layers at four frames per launch: tools/experiments/w44_feed_split.py)
+  static constexpr int U_SLOTS = 4, R_SLOTS = 6, V_SLOTS = 4;
   static constexpr int U0 = 0, R0 = U_SLOTS * WSZ, V0 = R0 + R_SLOTS * XSZP, RING = V0 + V_SLOTS * VSZ;
   static constexpr int EXCH = 2 * 4 * 8 * 8 * 64;        // epilogue exchange: [cout half][group][8 regs][8 values][lane]
   static constexpr size_t LDS_BYTES = (size_t)(RING > EXCH ? RING : EXCH) * sizeof(float);
@@ -243,9 +249,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
       glds4(usrc + 4096 + wave * 64 + lane, U_ + 4096 + wave * 64);
     }
   };
-  auto issue_r = [&](auto tail_c, auto extra_c, auto rs_c, int sr) {
+  auto issue_r = [&](auto tail_c, auto extra_c, int RS, int sr) {
     constexpr bool TAILW = decltype(tail_c)::value;     // waves 6, 7 stage no patch pieces (but wave 6 the last 56 at D = 2)
-    constexpr int RS = decltype(rs_c)::value;
     const int src_ = sr < nst ? sr : nst - 1;
     if constexpr (T::VEC) {
       const unsigned xb = (unsigned)(s_begin + src_) * 2u * (unsigned)HW * 4u;
@@ -336,8 +341,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     constexpr int RSTEP = (ROLE == 0 || ROLE == 5) ? 2 : 1;        // rows 0,2,4 / 1,2,3,4 / 1,3,5
     constexpr int NROW = (ROLE == 0 || ROLE == 5) ? 3 : 4;
     constexpr int NRAW = (ROLE < 6) ? (T::D == 2 ? 3 : 2) * NROW : 0;
-    auto raw_reads = [&](Raw& w, auto rs_c) {
-      constexpr int SO = decltype(rs_c)::value * T::XSZP * 4;       // byte offset of the ring slot
+    auto raw_reads = [&](Raw& w, int rs) {
+      const unsigned SO = (unsigned)(rs * T::XSZP * 4);             // byte offset of the ring slot (wave-uniform)
       if constexpr (ROLE < 6 && T::D == 2) {
         // window row i = patch row 2 i, column c = patch column 2 c: ds_read2_b32 (8-bit dword offsets, two columns = 4 dwords
         // apart per pair) from a per-k-step base = ring slot + first row (one v_add; a second one for the rows beyond 255 dwords)
@@ -359,15 +364,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
           }
         }
       } else if constexpr (ROLE < 6) {
-        w44_read_b128<SO + (R0_ + 0 * RSTEP) * T::PW * 4>(w.lo[0], xbase);
-        w44_read_b64<SO + ((R0_ + 0 * RSTEP) * T::PW + 4) * 4>(w.hi[0], xbase);
-        w44_read_b128<SO + (R0_ + 1 * RSTEP) * T::PW * 4>(w.lo[1], xbase);
-        w44_read_b64<SO + ((R0_ + 1 * RSTEP) * T::PW + 4) * 4>(w.hi[1], xbase);
-        w44_read_b128<SO + (R0_ + 2 * RSTEP) * T::PW * 4>(w.lo[2], xbase);
-        w44_read_b64<SO + ((R0_ + 2 * RSTEP) * T::PW + 4) * 4>(w.hi[2], xbase);
+        const unsigned xr = xbase + SO;                             // the one vector add of a k-step's window
+        w44_read_b128<(R0_ + 0 * RSTEP) * T::PW * 4>(w.lo[0], xr);
+        w44_read_b64<((R0_ + 0 * RSTEP) * T::PW + 4) * 4>(w.hi[0], xr);
+        w44_read_b128<(R0_ + 1 * RSTEP) * T::PW * 4>(w.lo[1], xr);
+        w44_read_b64<((R0_ + 1 * RSTEP) * T::PW + 4) * 4>(w.hi[1], xr);
+        w44_read_b128<(R0_ + 2 * RSTEP) * T::PW * 4>(w.lo[2], xr);
+        w44_read_b64<((R0_ + 2 * RSTEP) * T::PW + 4) * 4>(w.hi[2], xr);
         if constexpr (NROW == 4) {
-          w44_read_b128<SO + (R0_ + 3 * RSTEP) * T::PW * 4>(w.lo[3], xbase);
-          w44_read_b64<SO + ((R0_ + 3 * RSTEP) * T::PW + 4) * 4>(w.hi[3], xbase);
+          w44_read_b128<(R0_ + 3 * RSTEP) * T::PW * 4>(w.lo[3], xr);
+          w44_read_b64<((R0_ + 3 * RSTEP) * T::PW + 4) * 4>(w.hi[3], xr);
         }
       }
     };
@@ -459,40 +465,43 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     using S2 = std::integral_constant<int, 2>;
     using S3 = std::integral_constant<int, 3>;
 
-    // ---- prologue: U(0..2), R(0..4) landed; V(0..2) written; operands of k-step 0 in registers
+    // ---- prologue: U(0..2), R(0..5) landed; V(0..2) written; operands of k-step 0 in registers
     issue_u(TAILc{}, S0{}, 0);
     issue_u(TAILc{}, S1{}, 1);
     issue_u(TAILc{}, S2{}, 2);
-    issue_r(TAILc{}, EXTRAc{}, S0{}, 0);
-    issue_r(TAILc{}, EXTRAc{}, S1{}, 1);
-    issue_r(TAILc{}, EXTRAc{}, S2{}, 2);
-    issue_r(TAILc{}, EXTRAc{}, S3{}, 3);
+    issue_r(TAILc{}, EXTRAc{}, 0, 0);
+    issue_r(TAILc{}, EXTRAc{}, 1, 1);
+    issue_r(TAILc{}, EXTRAc{}, 2, 2);
+    issue_r(TAILc{}, EXTRAc{}, 3, 3);
+    issue_r(TAILc{}, EXTRAc{}, 4, 4);
+    issue_r(TAILc{}, EXTRAc{}, 5, 5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     {
       Raw w0, w1;
-      raw_reads(w0, S0{});
-      raw_reads(w1, S1{});
+      raw_reads(w0, 0);
+      raw_reads(w1, 1);
       wait_raw(w0, std::integral_constant<int, NRAW>{});
       transform_store(w0, S0{});
       wait_raw(w1, std::integral_constant<int, (ROLE < 6 ? 3 : 0)>{});
       transform_store(w1, S1{});
-      raw_reads(w0, S2{});
+      raw_reads(w0, 2);
       wait_raw(w0, N0{});
       transform_store(w0, S2{});
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();          // V(0..2) visible; every wave is done with R(0..2)
     __builtin_amdgcn_sched_barrier(0);
-    issue_r(TAILc{}, EXTRAc{}, S0{}, 4);   // R(4) into the slot of R(0)
+    issue_r(TAILc{}, EXTRAc{}, 0, 6);      // R(6) into the slot of R(0)
     Ops X, Y;
     load_ops(X, S0{}, S0{});
     wait_ops(X, N0{});
 
 #ifndef FDT_W44_EXP
 #define FDT_W44_EXP 0     // timing experiments (tools/experiments/w44_variants.sh), a bit mask: 1 no input transform, 2 no barrier,
-#endif                    // 4 no LDS-DMA in the loop, 8 no MFMA, 16 no operand reads -- results are wrong for every value but 0
+#endif                    // 4 no LDS-DMA in the loop (32: no patch DMA only, 64: no weight DMA only), 8 no MFMA, 16 no operand reads --
+                          // results are wrong for every value but 0
     auto mf = [&](Ops& cur, auto qc) {
       if (!(FDT_W44_EXP & 8)) mfma_q(cur, qc);
       __builtin_amdgcn_sched_barrier(0);
@@ -506,32 +515,42 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
     using I6 = std::integral_constant<int, 6>;
     using I7 = std::integral_constant<int, 7>;
     using I8 = std::integral_constant<int, 8>;
-    // ---- super-step: the k-steps s = 2 S (ring slots M) and s + 1 (slots M + 1) between TWO barriers ---------------------
-    // At its barrier: the operands of k-step s sit in `cur`; U(s+1), U(s+2), R(s+3), R(s+4) have landed (all LDS-DMA of the
-    // previous super-step: vmcnt(0), one super-step = two k-steps of flight); V(s+1), V(s+2) are written.  First half: MFMAs
-    // of s, window of s+3 -> V(s+3), operands of s+1 -> `nxt`, LDS-DMA of U(s+3) / R(s+5); second half: MFMAs of s+1, window of
-    // s+4 -> V(s+4), operands of s+2 -> `cur`, LDS-DMA of U(s+4) / R(s+6).  The first two MFMAs stand in front of the barrier
-    // (their operands are registers), four MFMAs between a window read and its wait, the operand prefetch late.
-    auto super_step = [&](auto m_c, Ops& cur, Ops& nxt, int s) {
+    // ---- super-step: the k-steps s = 2 S (U / V ring slots M) and s + 1 (slots M + 1) between TWO barriers -----------------
+    // At its barrier: the operands of k-step s sit in `cur`; U(s+1), U(s+2) (LDS-DMA of the previous super-step) and R(s+3),
+    // R(s+4) (LDS-DMA of the super-step before that) have landed, R(s+5), R(s+6) may still be in flight: the wait is
+    // vmcnt(<the patch instructions this wave issued in the previous super-step>), and the patch instructions are the LAST ones a
+    // super-step issues.  V(s+1), V(s+2) are written.  First half: MFMAs of s, window of s+3 -> V(s+3), operands of s+1 ->
+    // `nxt`, LDS-DMA of U(s+3), U(s+4) (the slots of U(s-1), U(s): every wave took its operands of k-step s before this
+    // barrier) and R(s+7) (the slot of R(s+1), read in the previous super-step); second half: MFMAs of s+1, window of s+4 ->
+    // V(s+4), operands of s+2 -> `cur`, LDS-DMA of R(s+8).  The first two MFMAs stand in front of the barrier (their operands
+    // are registers), four MFMAs between a window read and its wait, the operand prefetch late.  r6 = s mod 6.
+    constexpr int NRW = T::VEC ? ((ROLE < 6 || (ROLE == 6 && T::D == 2)) ? 1 : 0) : 3;   // patch LDS-DMA instructions per wave and k-step
+    auto super_step = [&](auto m_c, Ops& cur, Ops& nxt, int s, int r6) {
       constexpr int M = decltype(m_c)::value;
       using M0 = std::integral_constant<int, M>;
       using M1 = std::integral_constant<int, (M + 1) & 3>;
       using M2 = std::integral_constant<int, (M + 2) & 3>;
       using M3 = std::integral_constant<int, (M + 3) & 3>;
+      const int rd3 = r6 + 3 >= 6 ? r6 - 3 : r6 + 3, rd4 = r6 + 4 >= 6 ? r6 - 2 : r6 + 4;   // slots of R(s+3), R(s+4)
+      const int wr7 = r6 + 1, wr8 = r6 + 2 >= 6 ? 0 : r6 + 2;                                // slots of R(s+7), R(s+8) (r6 is even, <= 4)
       mf(cur, I0{});
       mf(cur, I1{});
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NRW) : "memory");
       if (!(FDT_W44_EXP & 2)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       Raw w;
       f32x2 Tp[3];
       float v[6];
-      if (!(FDT_W44_EXP & 1)) raw_reads(w, M3{});
+      if (!(FDT_W44_EXP & 1)) raw_reads(w, rd3);
       __builtin_amdgcn_sched_barrier(0);
       mf(cur, I2{});
       if (!(FDT_W44_EXP & 4)) {
-        issue_u(TAILc{}, M3{}, s + 3);
-        issue_r(TAILc{}, EXTRAc{}, M1{}, s + 5);
+        if (!(FDT_W44_EXP & 64)) {
+          issue_u(TAILc{}, M3{}, s + 3);
+          issue_u(TAILc{}, M0{}, s + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);     // the patch instructions stay the youngest of the super-step (see the vmcnt above)
+        if (!(FDT_W44_EXP & 32)) issue_r(TAILc{}, EXTRAc{}, wr7, s + 7);
       }
       __builtin_amdgcn_sched_barrier(0);
       mf(cur, I3{});
@@ -553,14 +572,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
       if (!(FDT_W44_EXP & 16)) wait_ops(nxt, N0{});
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       // ---- second half: k-step s + 1
-      if (!(FDT_W44_EXP & 1)) raw_reads(w, M0{});
+      if (!(FDT_W44_EXP & 1)) raw_reads(w, rd4);
       __builtin_amdgcn_sched_barrier(0);
       mf(nxt, I0{});
       mf(nxt, I1{});
       mf(nxt, I2{});
       if (!(FDT_W44_EXP & 4)) {
-        issue_u(TAILc{}, M0{}, s + 4);
-        issue_r(TAILc{}, EXTRAc{}, M2{}, s + 6);
+        if (!(FDT_W44_EXP & 32)) issue_r(TAILc{}, EXTRAc{}, wr8, s + 8);
       }
       __builtin_amdgcn_sched_barrier(0);
       mf(nxt, I3{});
@@ -583,13 +601,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     W44_STAMP(0)
-    int s = 0;
+    int s = 0, r6 = 0;
     for (; s + 3 < nst; s += 4) {
-      super_step(S0{}, X, Y, s);
-      super_step(S2{}, X, Y, s + 2);
+      super_step(S0{}, X, Y, s, r6);
+      super_step(S2{}, X, Y, s + 2, r6 + 2 >= 6 ? r6 - 4 : r6 + 2);
+      r6 = r6 + 4 >= 6 ? r6 - 2 : r6 + 4;
     }
     if (s + 1 < nst) {
-      super_step(S0{}, X, Y, s);
+      super_step(S0{}, X, Y, s, r6);
       s += 2;
     }
     if (s < nst) {                          // an odd last k-step: its operands are in X, nothing left to prefetch
