@@ -1042,10 +1042,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "PyramidBox-%s %dx%d synthetic u8 frames%s, batch=%d per GPU, decode+NMS+IoU-tracker "
+            "config": {"workload": "PyramidBox-%s %dx%d synthetic u8 frames%s, %s, decode+NMS+IoU-tracker "
                                    "on device" % ("Res50" if args.arch == "res50" else "MobileNetV2-try3", W, H,
                                                   " resized on the GPU from %dx%d sources" % (SW, SH) if args.source else "",
-                                                  1 if G > 1 else B),
+                                                  ("one frame per GPU and step, handed over singly, %d consecutive frames per launch "
+                                                   "chain (`ungrouped`: the one-chain-per-frame rate)" % G) if G > 1
+                                                  else "batch=%d per GPU" % B),
                        "frames_per_step": world * (1 if G > 1 else B),
                        "frames_grouped_per_launch": G if G > 1 else None,
                        "grouping": ("frames are handed to the pipeline one at a time (a step = one frame per GPU); %d consecutive "
