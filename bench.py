@@ -451,6 +451,9 @@ def main():
                          "--batch 1: 8 up to 640x480, 4 up to 1024x1024 (when tuned/ holds that batch's plan), else 1")
     ap.add_argument("--ungrouped-steps", type=int, default=64,
                     help="with grouping on (N = 1): also time this many steps of the --group 1 form (reported as `ungrouped`); 0 = skip")
+    ap.add_argument("--latency-frames", type=int, default=256,
+                    help="N = 1: frames of the per-frame latency leg (hand-over -> track update, frames arriving at a fixed rate); 0 = skip")
+    ap.add_argument("--latency-load", type=float, default=0.9, help="arrival rate of the latency leg as a fraction of the measured throughput")
     ap.add_argument("--source", default="", help="HxW of raw source frames (e.g. 1080x1920): the frames are resized on the "
                     "GPU to --height x --width inside the timed step like iouTracke_cal.py:123 does with cv2.resize")
     ap.add_argument("--unique-frames", type=int, default=8)
@@ -737,6 +740,31 @@ def main():
                             a["bboxes"] == b["bboxes"] for a, b in zip(seq_tracks, tracks)))
         seq.close()
 
+    # ---- GPU side of the detections-vs-CPU-oracle parity leg: the TIMED handle with the TIMED plan ---------------------
+    # Whole forwards of B (= the group size G when frames are grouped) frames through forward_dev() -- slot 0's handle, record
+    # and stream, exactly what a step of the timed loop launched; frame f of the sample is entry f % B of forward f // B.
+    # (Until round 4 this leg called net(frame) with ONE frame, which on a handle holding batch-G hints runs the analytic
+    # batch-1 plan.)  Taken here, before any later leg can touch the handle's plan; compared with the oracle further down.
+    gpu_recs, ran_plan = {}, (None, None)
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        rec_host = np.empty((B, 2, top_k, 5), np.float32)
+        rec_of_batch = {}
+        for f in range(max(args.cpu_frames, 4)):
+            b = (f % U) // B
+            if b not in rec_of_batch:
+                forward_dev(b)
+                torch.cuda.synchronize()
+                lib.check(L.fdt_dev_download(lib.ptr(rec_host), ctypes.c_void_p(mine.data_ptr()), rec_host.nbytes))
+                rec_of_batch[b] = rec_host.copy()
+            gpu_recs[f] = rec_of_batch[b][(f % U) % B][None]
+        ran = net.export_plan().strip().splitlines()
+        rows_ok = None
+        if plan_text:      # every layer ran the (kernel class, tile, split-K, map) of the plan that was timed; conv1 may run as
+            want_rows = {ln.split()[0]: ln.split() for ln in plan_text.strip().splitlines()[1:]}      # its raw-uint8 class
+            got_rows = {ln.split()[0]: ln.split() for ln in ran[1:]}
+            rows_ok = all(got_rows.get(k, [])[:len(v)] == v for k, v in want_rows.items() if k != "conv1")
+        ran_plan = (ran[0], rows_ok)
+
     # ---- per-launch timing (HIP events around every launch on the stream the kernels run on) -------------------------
     roof = None
     if rank == 0:
@@ -830,7 +858,7 @@ def main():
                     traffic_cal = round(tdata["hbm_bytes_per_launch_calibrated"])
                 if tdata.get("by_class"):       # round 4: read requests by SIZE CLASS (exact on a known-byte copy), per kernel class
                     traffic_ratio = round(tdata["ratio"], 3)
-                    traffic_classes = [{"class": c["cls"], "launches_per_frame": c["launches_per_frame"], "ratio": c["ratio"],
+                    traffic_classes = [{"class": c["cls"], "launches_per_forward": c["launches_per_frame"], "ratio": c["ratio"],
                                         "bytes_per_launch": c["bytes_per_launch"],
                                         "algorithmic_bytes_per_launch": c["algorithmic_bytes_per_launch"]} for c in tdata["by_class"][:8]]
                     traffic_src = "profiles/%s/%s (rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B} / TCC_EA0_WRREQ{,_64B}: bytes by " \
@@ -852,7 +880,7 @@ def main():
             "frac_executed": round(tf(dg[3], dg[1]) / PEAK_F32_MFMA_TFLOPS, 4),
             "achieved_algorithmic": round(tf(dg[2], dg[1]), 2),
             "frac_algorithmic": round(tf(dg[2], dg[1]) / PEAK_F32_MFMA_TFLOPS, 4),
-            "launches_per_frame": dg[0], "avg_launch_us": round(dg[1] * 1e3 / dg[0], 2),
+            "launches_per_forward": dg[0], "frames_per_forward": B, "avg_launch_us": round(dg[1] * 1e3 / dg[0], 2),
             "time_share_of_convs": round(dg[1] / conv_ms, 4),
             "algorithmic_gflop_per_launch": round(dg[2] / dg[0] / 1e9, 3),
             "executed_gflop_per_launch": round(dg[3] / dg[0] / 1e9, 3),
@@ -867,7 +895,7 @@ def main():
             # input + output (+ residual / upsample source) + weights of every conv, each once (fdt_model_traffic), / launches
             "algorithmic_bytes_per_launch": traffic_alg,
             # all conv launches of a frame (serial profile pass on one stream)
-            "conv_stack": {"launches_per_frame": n_conv, "ms_per_frame": round(conv_ms / B, 3),
+            "conv_stack": {"launches_per_forward": n_conv, "frames_per_forward": B, "ms_per_frame": round(conv_ms / B, 3),
                            "algorithmic_gflop_per_frame": round(alg / B / 1e9, 3),
                            "executed_gflop_per_frame": round(exe / B / 1e9, 3),
                            "achieved_executed": round(tf(exe, conv_ms), 2),
@@ -881,7 +909,7 @@ def main():
                                                         if "all_ops" in seg_ms else None)},
             # the scope north_star's ">= 40 % MFMA roofline for the backbone" is stated on
             "backbone": ({"ops": "conv1, layer1.* .. layer4.* (bottlenecks + downsample), layer5.*, layer6.* (pyramid.py:229-236)",
-                          "launches_per_frame": bb[0],
+                          "launches_per_forward": bb[0], "frames_per_forward": B,
                           # one HIP-event pair around the whole run of backbone launches (maxpool and the backbone's reduce
                           # passes included, nothing subtracted), one frame alone on the GPU
                           "ms_per_frame": round(seg_ms["backbone"][0] / B, 4),
@@ -963,9 +991,8 @@ def main():
             det_ref = cpu_frame(i, ref_trk)
             times.append(time.perf_counter() - t1)
             # parity of the same frames on the GPU path (checker only; not timed)
-            yg = (net.forward_resized(frames_h[i % U], (W, H)) if args.source else net(frames_h[i % U])).numpy()
             ref_dets.append(det_ref)
-            gpu_dets.append(opp.unpack_detections(yg, W, H, 0.4))
+            gpu_dets.append(opp.unpack_detections(gpu_recs[i], W, H, 0.4))
         torch.set_num_threads(default_threads)
         ap_, n_truth, n_pred = opp.ap_against_reference(gpu_dets, ref_dets, 0.5)
         iou_def = 0.0
@@ -976,6 +1003,10 @@ def main():
                                                                          g[:, :4].astype(np.float64)).max(1)).max()))
         parity = {"ap_vs_cpu_ref": round(ap_, 6), "ref_boxes": n_truth, "gpu_boxes": n_pred,
                   "max_iou_deficit": float("%.3g" % iou_def), "frames": len(ref_dets),
+                  # which kernel plan the GPU side of this comparison ran: the timed handle's, at the timed batch
+                  "plan": plan_src, "plan_shape_run": ran_plan[0], "plan_rows_as_committed": ran_plan[1], "frames_per_forward": B,
+                  "plan_pinned_by": "tests/test_gpu_timed_plans.py (the same plan through fdt_pipeline_step%s over 8-16 distinct "
+                                    "frames vs the oracle and the reference fixture)" % ("_frame" if G > 1 else ""),
                   "tracks_equal": tracks_equal,
                   "tracks_equal_note": "track list of the TIMED multi-stream loop == the same %d steps re-run one frame at a "
                                        "time, synchronously (bitwise)" % (args.warmup + args.steps)}
@@ -1027,6 +1058,51 @@ def main():
                      "what": "--group 1: the same pipeline with one launch chain per frame (batch-1 kernel plan), same slots"}
         p1.close()
 
+    # ---- per-frame latency: hand-over -> track update done, frames arriving at a fixed rate (N = 1, C ABI) ------------------
+    latency = None
+    if rank == 0 and world == 1 and use_cabi and args.latency_frames > 0 and max(1, args.batch) == 1:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
+        pipe.close()
+        latency = {"what": "ms from handing frame i to the pipeline (fdt_pipeline_step_frame / _step returns at once) to the "
+                           "completion of its association on the tracker stream (fdt_pipeline_stamps: a HIP event behind the "
+                           "group's track_step launch, iouTracke_cal.py:126-156 done for it), frames arriving at a FIXED rate = "
+                           "%.0f %% of that configuration's measured throughput (a saturated queue would measure the backlog, "
+                           "not the path); a frame of a group of G waits for the group's last frame before anything is launched"
+                           % (100 * args.latency_load)}
+        legs = [(G, plan_text, args.steps / dt)]      # a step is one frame here (--batch 1)
+        if G > 1 and ungrouped:
+            legs.append((1, net.tuned_plan_text(H, W, 1), ungrouped["value"]))
+        for g_, ptxt, fps_max in legs:
+            n = args.latency_frames // g_ * g_
+            pl = pipeline.CabiPipeline(net, H, W, local_rank, inflight=NF, batch=g_, source_hw=(SH, SW) if args.source else None,
+                                       plan_text=ptxt)
+            pl.prime(frames_d[0:g_])
+            for i in range(2 * g_):                              # one untimed round so the slots' graphs are warm
+                pl.step_frame(i, frames_d[i % U:i % U + 1]) if g_ > 1 else pl.step(i, frames_d[i % U:i % U + 1])
+            pl.sync()
+            pl.stamps_enable(n // g_)
+            rate = args.latency_load * fps_max
+            t_in = np.zeros(n)
+            pl.mark(0)
+            t0l = time.perf_counter()
+            for i in range(n):
+                while time.perf_counter() - t0l < i / rate:      # the source delivers frame i at i / rate
+                    pass
+                t_in[i] = (time.perf_counter() - t0l) * 1e3
+                j = 2 * g_ + i
+                pl.step_frame(j, frames_d[j % U:j % U + 1]) if g_ > 1 else pl.step(j, frames_d[j % U:j % U + 1])
+            pl.sync()
+            done = pl.stamps_read(n // g_)
+            lat = np.array([done[i // g_] - t_in[i] for i in range(min(n, len(done) * g_))])
+            latency["frames_per_launch_%d" % g_] = {
+                "p50_ms": round(float(np.percentile(lat, 50)), 3), "p99_ms": round(float(np.percentile(lat, 99)), 3),
+                "max_ms": round(float(lat.max()), 3), "min_ms": round(float(lat.min()), 3), "frames": int(len(lat)),
+                "arrival_rate_fps": round(rate, 1), "achieved_fps": round(n / ((time.perf_counter() - t0l)), 1),
+                "slots": NF, "frames_in_flight_capacity": NF * g_}
+            pl.finish()
+            pl.close()
+
     if rank == 0:
         frames = args.steps * world * (1 if G > 1 else B)
         line = {
@@ -1049,6 +1125,9 @@ def main():
                                                    "chain (`ungrouped`: the one-chain-per-frame rate)" % G) if G > 1
                                                   else "batch=%d per GPU" % B),
                        "frames_per_step": world * (1 if G > 1 else B),
+                       # how many frames share one kernel launch per layer (1 = BASELINE's batch=1 wording; `ungrouped` below
+                       # carries that rate whenever this is not 1)
+                       "frames_per_launch": B,
                        "frames_grouped_per_launch": G if G > 1 else None,
                        "grouping": ("frames are handed to the pipeline one at a time (a step = one frame per GPU); %d consecutive "
                                     "frames of a GPU share ONE launch per layer (pipeline.step_frame: staged into the slot's "
@@ -1071,6 +1150,7 @@ def main():
             "parity": parity,
             "host_path": host_path,
             "ungrouped": ungrouped,
+            "latency": latency,
         }
         print(json.dumps(line))
     pipe.close()

@@ -73,11 +73,13 @@ SIGNATURES = {
     "fdt_tracker_num_tracks": (C.c_int, [_vp, _c_int_p]),
     "fdt_tracker_track_info": (C.c_int, [_vp, C.c_int, _c_int_p, _c_f64_p, _c_int_p]),
     "fdt_tracker_track_boxes": (C.c_int, [_vp, C.c_int, _vp]),
+    "fdt_tracker_stats": (C.c_int, [_vp, _c_i64_p, _c_i64_p]),
     "fdt_model_create": (_vp, [C.c_int, C.c_int]),
     "fdt_model_destroy": (None, [_vp]),
     "fdt_model_clone": (_vp, [_vp]),
     "fdt_model_enable_graph": (C.c_int, [_vp, C.c_int]),
     "fdt_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "fdt_comm_unique_id_local": (C.c_int, [C.c_char_p]),
     "fdt_comm_init_rank": (_vp, [C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "fdt_comm_init_all": (_vp, [C.c_int, _c_int_p]),
     "fdt_comm_world": (C.c_int, [_vp, _c_int_p, _c_int_p]),
@@ -132,6 +134,8 @@ SIGNATURES = {
     "fdt_pipeline_slot": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "fdt_pipeline_mark": (C.c_int, [_vp, C.c_int]),
     "fdt_pipeline_elapsed_ms": (C.c_int, [_vp, _vp]),
+    "fdt_pipeline_stamps_enable": (C.c_int, [_vp, C.c_int]),
+    "fdt_pipeline_stamps_read": (C.c_int, [_vp, _vp, C.c_int, _c_int_p]),
     "fdt_dev_malloc": (C.c_int, [C.POINTER(_vp), C.c_longlong]),
     "fdt_dev_free": (C.c_int, [_vp]),
     "fdt_dev_upload": (C.c_int, [_vp, _vp, C.c_longlong]),

@@ -1,4 +1,7 @@
 // Library-level entry points: error string, device queries.
+#include <mutex>
+#include <shared_mutex>
+
 #include "common.h"
 
 namespace fdt {
@@ -45,6 +48,31 @@ hipStream_t thread_stream() {
 }
 }  // namespace fdt
 
+namespace fdt {
+static std::shared_mutex g_capture_mu;
+static thread_local int t_exclusive = 0, t_capturing = 0;
+hipError_t device_sync() {
+  if (t_capturing) return hipErrorStreamCaptureUnsupported;      // would wait for itself
+  if (t_exclusive) return hipDeviceSynchronize();
+  std::unique_lock<std::shared_mutex> lk(g_capture_mu);
+  return hipDeviceSynchronize();
+}
+void capture_lock_shared() {
+  g_capture_mu.lock_shared();
+  ++t_capturing;
+}
+void capture_unlock_shared() {
+  --t_capturing;
+  g_capture_mu.unlock_shared();
+}
+void exclusive_begin() {
+  if (t_exclusive++ == 0) g_capture_mu.lock();
+}
+void exclusive_end() {
+  if (--t_exclusive == 0) g_capture_mu.unlock();
+}
+}  // namespace fdt
+
 extern "C" int fdt_thread_stream(void** stream) {
   FDT_REQUIRE(stream, FDT_ERR_ARG, "fdt_thread_stream: null output");
   const hipStream_t st = fdt::thread_stream();
@@ -54,7 +82,7 @@ extern "C" int fdt_thread_stream(void** stream) {
 }
 
 extern "C" int fdt_device_synchronize(void) {
-  FDT_HIP(hipDeviceSynchronize());
+  FDT_HIP(fdt::device_sync());
   return FDT_OK;
 }
 

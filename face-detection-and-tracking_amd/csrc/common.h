@@ -87,6 +87,24 @@ static inline hipError_t copy_sync(void* dst, const void* src, size_t bytes, hip
 // turn that into FDT_ERR_HIP, never into legacy-stream work.
 hipStream_t thread_stream();
 
+// hipDeviceSynchronize() fails with "operation not permitted when stream is capturing" while ANY host thread has a stream
+// capture open -- also a thread-local one of another thread (ROCm 7.2) --, and distinct handles are driven from distinct
+// threads (one pipeline per rank thread in the loop-back tests, the reference-side threading contract of include/fdt.h).
+// So the library's device-wide waits and its captures exclude each other: a capture holds the lock shared (captures of
+// different threads may overlap), device_sync() takes it exclusively -- it waits for the few hundred microseconds an open
+// capture lasts (captures only enqueue) and holds new ones back while the device drains.
+hipError_t device_sync();
+void capture_lock_shared();
+void capture_unlock_shared();
+// a whole teardown (device-wide wait + hipFree / hipGraphExecDestroy, which synchronise implicitly) with captures held back;
+// re-entrant on a thread (fdt_pipeline_destroy destroys its clones)
+void exclusive_begin();
+void exclusive_end();
+struct ExclusiveDevice {
+  ExclusiveDevice() { exclusive_begin(); }
+  ~ExclusiveDevice() { exclusive_end(); }
+};
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
 

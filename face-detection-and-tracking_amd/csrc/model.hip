@@ -226,7 +226,7 @@ struct fdt_model {
     // A replay may still be executing on a CALLER's stream (fdt_model_forward_dev / the pipeline's per-slot streams), which a
     // synchronise of this handle's own stream does not cover: destroying a hipGraphExec_t under a replay in flight is a
     // use-after-free inside the runtime (an intermittent host-side crash, not a kernel fault).  Plan changes are rare.
-    if (!graphs.empty()) (void)hipDeviceSynchronize();
+    if (!graphs.empty()) (void)fdt::device_sync();
     for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
     graphs.clear();
     graph_used.clear();
@@ -1305,7 +1305,7 @@ int plan_reduces(fdt_model* m, int B);
 int make_plan(fdt_model* m, int B, int H, int W) {
   if (m->pB == B && m->pH == H && m->pW == W && !m->ops.empty()) {
     if (m->priors_dirty) {
-      FDT_HIP(hipDeviceSynchronize());
+      FDT_HIP(fdt::device_sync());
       FDT_TRY(make_priors(m, H, W));
     }
     return FDT_OK;
@@ -1522,7 +1522,7 @@ int grow_conv_workspace(fdt_model* m, long long need) {
   float* p = nullptr;
   FDT_HIP(hipMalloc((void**)&p, (size_t)need * 4));
   if (m->d_convws) {
-    FDT_HIP(hipDeviceSynchronize());
+    FDT_HIP(fdt::device_sync());
     for (auto it = m->plan_allocs.begin(); it != m->plan_allocs.end(); ++it)
       if (*it == (void*)m->d_convws) {
         m->plan_allocs.erase(it);
@@ -1791,15 +1791,22 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
         auto victim = m->graphs.begin();
         for (auto g = m->graphs.begin(); g != m->graphs.end(); ++g)
           if (m->graph_used[g->first] < m->graph_used[victim->first]) victim = g;
-        FDT_HIP(hipDeviceSynchronize());
+        FDT_HIP(fdt::device_sync());
         (void)hipGraphExecDestroy(victim->second);
         m->graph_used.erase(victim->first);
         m->graphs.erase(victim);
       }
-      FDT_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      // no device-wide wait of another thread may fall inside the capture (common.h: device_sync)
+      fdt::capture_lock_shared();
+      const hipError_t be = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+      if (be != hipSuccess) {
+        fdt::capture_unlock_shared();
+        FDT_HIP(be);
+      }
       const int rc = body();
       hipGraph_t g = nullptr;
       const hipError_t ce = hipStreamEndCapture(st, &g);
+      fdt::capture_unlock_shared();
       if (rc != FDT_OK) {
         if (g) (void)hipGraphDestroy(g);
         return rc;
@@ -1866,8 +1873,9 @@ extern "C" fdt_model* fdt_model_create(int arch, int device) {
 
 extern "C" void fdt_model_destroy(fdt_model* m) {
   if (!m) return;
+  fdt::ExclusiveDevice quiet;
   (void)hipSetDevice(m->device);
-  (void)hipDeviceSynchronize();
+  (void)fdt::device_sync();
   delete m;
 }
 
@@ -2130,7 +2138,7 @@ extern "C" int fdt_model_forward_async(fdt_model* m, const void* frames, int for
                                                        : (size_t)B * (resized ? src_h : H) * (resized ? src_w : W) * 3;
   const size_t out_floats = (size_t)B * 2 * m->top_k * 5, n_counts = (size_t)B * 2;
   if (in_bytes > s.in_bytes || out_floats != s.out_floats || n_counts != s.n_counts) {
-    FDT_HIP(hipDeviceSynchronize());   // a (rare) re-size: nothing may still read the old buffers
+    FDT_HIP(fdt::device_sync());   // a (rare) re-size: nothing may still read the old buffers
     hipEvent_t ev[4] = {s.copied, s.fwd, s.done, s.consumed};
     s.copied = s.fwd = s.done = s.consumed = nullptr;
     s.release();
@@ -2295,7 +2303,7 @@ extern "C" int fdt_model_get_tensor(fdt_model* m, const char* name, float* out, 
       // caller's device frames are; the library's own landing / resize buffers always are)
       const bool fb = m->arch == FDT_ARCH_FACEBOX;
       FDT_HIP(hipSetDevice(m->device));
-      FDT_HIP(hipDeviceSynchronize());
+      FDT_HIP(fdt::device_sync());
       FDT_TRY(launch_preprocess(m->last_u8_src, m->pB, m->pH, m->pW, fb ? 0.f : 104.f, fb ? 0.f : 117.f, fb ? 0.f : 123.f,
                                 fb ? 255.0f : 1.0f, m->tensors[0].d, m->stream));
       FDT_HIP(hipStreamSynchronize(m->stream));
@@ -2327,7 +2335,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   FDT_REQUIRE(m->pB > 0 && !m->ops.empty(), FDT_ERR_STATE, "fdt_model_autotune: run a forward first");
   FDT_HIP(hipSetDevice(m->device));
   hipStream_t st = m->stream;
-  FDT_HIP(hipDeviceSynchronize());
+  FDT_HIP(fdt::device_sync());
   hipEvent_t e0, e1;
   FDT_HIP(hipEventCreate(&e0));
   FDT_HIP(hipEventCreate(&e1));
@@ -2556,7 +2564,7 @@ extern "C" int fdt_model_enable_graph(fdt_model* m, int on) {
   FDT_REQUIRE(m, FDT_ERR_ARG, "fdt_model_enable_graph: null handle");
   m->use_graph = on != 0;
   if (!on) {
-    if (m->stream) (void)hipDeviceSynchronize();
+    if (m->stream) (void)fdt::device_sync();
     m->drop_graphs();
   }
   return FDT_OK;

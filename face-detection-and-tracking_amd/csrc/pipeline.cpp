@@ -32,6 +32,11 @@ struct fdt_pipeline {
   long long pend_group = -1;               // step_frame: the partly filled batch
   int pend_slot = 0, pend_n = 0;
   hipEvent_t mark[2] = {nullptr, nullptr};
+  // per-group completion stamps (fdt_pipeline_stamps_enable): a timing event on the tracker stream after the association of
+  // every track_slot() call, for latency measurements; off by default (no event in the product loop)
+  std::vector<hipEvent_t> stamps;
+  long long n_stamped = 0;
+  size_t frame_bytes() const { return (size_t)(src_h > 0 ? src_h : H) * (src_h > 0 ? src_w : W) * 3; }
 };
 
 namespace {
@@ -62,6 +67,27 @@ int track_slot(fdt_pipeline* p, int k, int n_valid, bool frame_major) {
                                          p->top_k, p->W, p->H, p->score_thresh, (void*)p->trk));
   }
   FDT_HIP(hipEventRecord(p->trk_done[k], p->trk));
+  if (!p->stamps.empty() && p->n_stamped < (long long)p->stamps.size()) FDT_HIP(hipEventRecord(p->stamps[p->n_stamped++], p->trk));
+  return FDT_OK;
+}
+
+// the pinned landing buffers + copy events of step_host, all slots at once on the first host step (nothing is left half
+// allocated: on a failure the slots already made stay valid and the call can be repeated)
+int ensure_host_landing(fdt_pipeline* p) {
+  const size_t fb = p->frame_bytes() * p->B;
+  for (int k = 0; k < p->NF; ++k) {
+    if (p->pinned[k]) continue;
+    unsigned char* pin = nullptr;
+    hipEvent_t ev = nullptr;
+    if (hipHostMalloc((void**)&pin, fb, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+      if (pin) (void)hipHostFree(pin);
+      set_error("fdt_pipeline_step_host: pinned landing buffer of slot %d (%zu bytes): %s", k, fb, hipGetErrorString(hipGetLastError()));
+      return FDT_ERR_HIP;
+    }
+    p->h2d_done[k] = ev;
+    p->pinned[k] = pin;              // set last: a slot is either complete or absent
+  }
   return FDT_OK;
 }
 }  // namespace
@@ -113,7 +139,10 @@ extern "C" fdt_pipeline* fdt_pipeline_create(fdt_model* m, int device, int heigh
     if (mine) p->mine.push_back(mine);
     if (cnt) p->counts.push_back(cnt);
     p->gathered.push_back(world == 1 ? mine : all);
-    p->stage.push_back(nullptr);
+    // the staging batch of step_frame / step_host is part of the pipeline, not of its first timed step
+    unsigned char* stg = nullptr;
+    if (ok) ok = hipMalloc((void**)&stg, p->frame_bytes() * batch) == hipSuccess;
+    p->stage.push_back(stg);
     p->pinned.push_back(nullptr);
     p->h2d_done.push_back(nullptr);
     if (ok) ok = hipMemsetAsync(mine, 0, rec_bytes, s) == hipSuccess && hipMemsetAsync(cnt, 0, (size_t)batch * 2 * 4, s) == hipSuccess;
@@ -125,7 +154,7 @@ extern "C" fdt_pipeline* fdt_pipeline_create(fdt_model* m, int device, int heigh
     p->tracker = fdt_tracker_create(sigma_iou, sigma_h, t_min, 2 * top_k, lf);
     ok = p->tracker != nullptr;
   }
-  if (ok) ok = hipDeviceSynchronize() == hipSuccess;
+  if (ok) ok = fdt::device_sync() == hipSuccess;
   if (!ok) {
     if (!*fdt::get_error()) set_error("fdt_pipeline_create: HIP resource creation failed: %s", hipGetErrorString(hipGetLastError()));
     fdt_pipeline_destroy(p);
@@ -136,8 +165,9 @@ extern "C" fdt_pipeline* fdt_pipeline_create(fdt_model* m, int device, int heigh
 
 extern "C" void fdt_pipeline_destroy(fdt_pipeline* p) {
   if (!p) return;
+  fdt::ExclusiveDevice quiet;
   (void)hipSetDevice(p->device);
-  (void)hipDeviceSynchronize();
+  (void)fdt::device_sync();
   if (p->tracker) fdt_tracker_destroy(p->tracker);
   for (size_t k = 1; k < p->nets.size(); ++k) fdt_model_destroy(p->nets[k]);
   for (size_t k = 0; k < p->mine.size(); ++k) {
@@ -155,6 +185,8 @@ extern "C" void fdt_pipeline_destroy(fdt_pipeline* p) {
   for (auto e : p->trk_done) (void)hipEventDestroy(e);
   for (auto e : p->mark)
     if (e) (void)hipEventDestroy(e);
+  for (auto e : p->stamps)
+    if (e) (void)hipEventDestroy(e);
   for (auto s : p->det) (void)hipStreamDestroy(s);
   if (p->trk) (void)hipStreamDestroy(p->trk);
   delete p;
@@ -169,12 +201,13 @@ extern "C" int fdt_pipeline_prime(fdt_pipeline* p, const void* frames_dev) {
     FDT_TRY(forward_slot(p, k, frames_dev));
     FDT_TRY(forward_slot(p, k, frames_dev));
   }
-  FDT_HIP(hipDeviceSynchronize());
+  FDT_HIP(fdt::device_sync());
   return FDT_OK;
 }
 
 extern "C" int fdt_pipeline_step(fdt_pipeline* p, long long i, const void* frames_dev) {
   FDT_REQUIRE(p && frames_dev && i >= 0, FDT_ERR_ARG, "fdt_pipeline_step: bad argument");
+  FDT_HIP(hipSetDevice(p->device));
   const int k = (int)(i % p->NF);
   FDT_HIP(hipStreamWaitEvent(p->det[k], p->trk_done[k], 0));     // the slot's previous record was consumed
   FDT_TRY(forward_slot(p, k, frames_dev));
@@ -188,40 +221,57 @@ extern "C" int fdt_pipeline_step(fdt_pipeline* p, long long i, const void* frame
 // frames are shown to the tracker).
 extern "C" int fdt_pipeline_step_host(fdt_pipeline* p, long long i, const void* frames_host, int n_valid) {
   FDT_REQUIRE(p && frames_host && i >= 0 && n_valid >= 1 && n_valid <= p->B, FDT_ERR_ARG, "fdt_pipeline_step_host: bad argument");
+  // ONE frame order per video: a step's frames are consumed rank-major (rank r's batch holds consecutive frames, as in
+  // fdt_pipeline_step).  A partly filled batch keeps that order at world 1 (the first n_valid frames of the one rank); at
+  // world > 1 the ranks would have to know each other's n_valid, which only the caller does: refused.
+  FDT_REQUIRE(p->world == 1 || n_valid == p->B, FDT_ERR_ARG,
+              "fdt_pipeline_step_host: a partly filled batch (%d of %d) is only defined at world 1", n_valid, p->B);
+  FDT_HIP(hipSetDevice(p->device));
   const int k = (int)(i % p->NF);
-  const size_t fb = (size_t)(p->src_h > 0 ? p->src_h : p->H) * (p->src_h > 0 ? p->src_w : p->W) * 3 * p->B;
-  if (!p->pinned[k]) {
-    FDT_HIP(hipHostMalloc((void**)&p->pinned[k], fb, hipHostMallocDefault));
-    FDT_HIP(hipEventCreateWithFlags(&p->h2d_done[k], hipEventDisableTiming));
-    if (!p->stage[k]) FDT_HIP(hipMalloc((void**)&p->stage[k], fb));
-  } else {
-    FDT_HIP(hipEventSynchronize(p->h2d_done[k]));             // the previous copy out of the landing buffer (long done)
-  }
-  memcpy(p->pinned[k], frames_host, fb);
+  const size_t fb = p->frame_bytes() * p->B;
+  if (!p->pinned[k]) FDT_TRY(ensure_host_landing(p));
+  else FDT_HIP(hipEventSynchronize(p->h2d_done[k]));          // the previous copy out of the landing buffer (long done)
+  memcpy(p->pinned[k], frames_host, p->frame_bytes() * n_valid);
   FDT_HIP(hipStreamWaitEvent(p->det[k], p->trk_done[k], 0));  // the slot's previous record was consumed
   FDT_HIP(hipMemcpyAsync(p->stage[k], p->pinned[k], fb, hipMemcpyHostToDevice, p->det[k]));
   FDT_HIP(hipEventRecord(p->h2d_done[k], p->det[k]));
   FDT_TRY(forward_slot(p, k, p->stage[k]));
-  return track_slot(p, k, n_valid, n_valid < p->B);
+  if (n_valid == p->B) return track_slot(p, k, p->B, false);
+  // world 1, partly filled: the first n_valid records of the one rank, in order (rank-major == frame-major here)
+  FDT_HIP(hipEventRecord(p->det_done[k], p->det[k]));
+  FDT_HIP(hipStreamWaitEvent(p->trk, p->det_done[k], 0));
+  FDT_TRY(fdt_tracker_step_dev_multi(p->tracker, p->gathered[k], n_valid, p->REC, 2, p->top_k, p->W, p->H, p->score_thresh,
+                                     (void*)p->trk));
+  FDT_HIP(hipEventRecord(p->trk_done[k], p->trk));
+  return FDT_OK;
 }
 
 extern "C" int fdt_pipeline_flush(fdt_pipeline* p) {
   FDT_REQUIRE(p, FDT_ERR_ARG, "fdt_pipeline_flush: null handle");
   if (p->pend_group < 0 || p->pend_n == 0) return FDT_OK;
+  FDT_HIP(hipSetDevice(p->device));
   const int k = p->pend_slot, n = p->pend_n;
-  p->pend_group = -1;
+  p->pend_group = -1;                        // the group is closed: its remaining frame indices cannot be handed over any more
   p->pend_n = 0;
   FDT_TRY(forward_slot(p, k, p->stage[k]));
   return track_slot(p, k, n, true);
 }
 
 // Frames handed over ONE AT A TIME, executed `batch` at a time (cross-frame grouped launches, see pipeline.py: step_frame).
+// The frames of a group arrive in order, starting with its first (i % batch == 0): that one waits for the slot's previous
+// association, and a group that fdt_pipeline_flush has run partly filled is closed -- continuing it would overwrite records the
+// tracker stream may still be reading and show it the flushed frames again (FDT_ERR_STATE).  World > 1: every rank hands over
+// (and flushes) the same number of frames; frame i of rank r is frame i * world + r of the video.
 extern "C" int fdt_pipeline_step_frame(fdt_pipeline* p, long long i, const void* frame_dev) {
   FDT_REQUIRE(p && frame_dev && i >= 0, FDT_ERR_ARG, "fdt_pipeline_step_frame: bad argument");
   const long long g = i / p->B;
   const int k = (int)(g % p->NF), j = (int)(i % p->B);
-  const size_t fb = (size_t)(p->src_h > 0 ? p->src_h : p->H) * (p->src_h > 0 ? p->src_w : p->W) * 3;
-  if (!p->stage[k]) FDT_HIP(hipMalloc((void**)&p->stage[k], fb * p->B));
+  FDT_REQUIRE(j == 0 ? p->pend_n == 0 : (p->pend_group == g && p->pend_n == j), FDT_ERR_STATE,
+              "fdt_pipeline_step_frame: frame %lld is entry %d of group %lld, but %s", i, j, g,
+              j == 0 ? "the previous group is still open (hand its frames over, or fdt_pipeline_flush)"
+                     : "that group is not the open one at that entry (frames of a group arrive in order; a flushed group is closed)");
+  FDT_HIP(hipSetDevice(p->device));
+  const size_t fb = p->frame_bytes();
   if (j == 0) FDT_HIP(hipStreamWaitEvent(p->det[k], p->trk_done[k], 0));
   FDT_HIP(hipMemcpyAsync(p->stage[k] + fb * j, frame_dev, fb, hipMemcpyDeviceToDevice, p->det[k]));
   p->pend_group = g;
@@ -234,7 +284,7 @@ extern "C" int fdt_pipeline_step_frame(fdt_pipeline* p, long long i, const void*
 extern "C" int fdt_pipeline_sync(fdt_pipeline* p) {
   FDT_REQUIRE(p, FDT_ERR_ARG, "fdt_pipeline_sync: null handle");
   FDT_HIP(hipSetDevice(p->device));
-  FDT_HIP(hipDeviceSynchronize());
+  FDT_HIP(fdt::device_sync());
   return FDT_OK;
 }
 
@@ -254,14 +304,46 @@ extern "C" int fdt_pipeline_slot(fdt_pipeline* p, int slot, fdt_model** model, v
 // which = 0 / 1: a timing event on the TRACKER stream (everything of the steps enqueued so far precedes it there)
 extern "C" int fdt_pipeline_mark(fdt_pipeline* p, int which) {
   FDT_REQUIRE(p && (which == 0 || which == 1), FDT_ERR_ARG, "fdt_pipeline_mark: bad argument");
+  FDT_HIP(hipSetDevice(p->device));
   FDT_HIP(hipEventRecord(p->mark[which], p->trk));
   return FDT_OK;
 }
 
 extern "C" int fdt_pipeline_elapsed_ms(fdt_pipeline* p, float* ms) {
   FDT_REQUIRE(p && ms, FDT_ERR_ARG, "fdt_pipeline_elapsed_ms: bad argument");
+  FDT_HIP(hipSetDevice(p->device));
   FDT_HIP(hipEventSynchronize(p->mark[1]));
   FDT_HIP(hipEventElapsedTime(ms, p->mark[0], p->mark[1]));
+  return FDT_OK;
+}
+
+// Completion stamps for latency measurements: from now on the next `n` exchange + association groups (one per fdt_pipeline_step
+// / _step_host call, one per launched group of _step_frame) each record a timing event on the tracker stream behind the
+// association.  n = 0 switches them off.  fdt_pipeline_stamps_read: milliseconds from mark(0) to each stamp recorded so far
+// (waits for them); *count = how many.
+extern "C" int fdt_pipeline_stamps_enable(fdt_pipeline* p, int n) {
+  FDT_REQUIRE(p && n >= 0 && n <= (1 << 20), FDT_ERR_ARG, "fdt_pipeline_stamps_enable: bad argument");
+  FDT_HIP(hipSetDevice(p->device));
+  FDT_HIP(fdt::device_sync());
+  for (auto e : p->stamps) (void)hipEventDestroy(e);
+  p->stamps.clear();
+  p->n_stamped = 0;
+  for (int i = 0; i < n; ++i) {
+    hipEvent_t e = nullptr;
+    FDT_HIP(hipEventCreate(&e));
+    p->stamps.push_back(e);
+  }
+  return FDT_OK;
+}
+extern "C" int fdt_pipeline_stamps_read(fdt_pipeline* p, float* ms_since_mark0, int max, int* count) {
+  FDT_REQUIRE(p && ms_since_mark0 && count && max >= 0, FDT_ERR_ARG, "fdt_pipeline_stamps_read: bad argument");
+  FDT_HIP(hipSetDevice(p->device));
+  const int n = (int)(p->n_stamped < max ? p->n_stamped : max);
+  for (int i = 0; i < n; ++i) {
+    FDT_HIP(hipEventSynchronize(p->stamps[i]));
+    FDT_HIP(hipEventElapsedTime(&ms_since_mark0[i], p->mark[0], p->stamps[i]));
+  }
+  *count = n;
   return FDT_OK;
 }
 

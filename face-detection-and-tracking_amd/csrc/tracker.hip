@@ -25,6 +25,9 @@ struct TrkState {       // one per tracker, device memory
   int frame_num;
   int overflow;         // log capacity exceeded (host flushes before this can happen)
   long long log_cursor; // bytes used in the log
+  // which association form each frame ran (fdt_tracker_stats): [0] candidate form, [1] exact form because a pair's IoU was
+  // NaN, [2] exact form because a track had more than TRK_CAND candidates, [3] exact form because sigma_iou < 0 (or NaN)
+  long long form_frames[4];
 };
 
 struct ActiveSet {      // structure of arrays, capacity M
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
   __shared__ int s_pi[TRK_THREADS];
   __shared__ int s_n_active, s_next_id, s_frame_num, s_nupd, s_nfin;
   __shared__ long long s_cursor;
+  __shared__ int s_form[4];                  // frames of this launch per association form (TrkState::form_frames)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = TRK_THREADS / 64;
   if (tid == 0) {
@@ -135,6 +139,7 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
     s_next_id = st->next_id;
     s_frame_num = st->frame_num;
     s_cursor = st->log_cursor;
+    s_form[0] = s_form[1] = s_form[2] = s_form[3] = 0;
   }
   __syncthreads();
 #ifdef FDT_TRK_TIMING
@@ -253,6 +258,7 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
   // of them can be the arg-max; the (few) overlapping ones are remembered and evaluated exactly in f64 afterwards.
   // ---- phase 1, candidate form ---------------------------------------------------------------------
   bool fast = sigma_iou >= 0.0;              // uniform (false for a NaN threshold too)
+  if (!fast && tid == 0) s_form[3] += 1;
   if (fast) {
     int* cnt = best_i;                       // candidates found so far per track (best_i is free until phase 2 stages results)
     for (int t = tid; t < T; t += TRK_THREADS) cnt[t] = 0;
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
     }
     const double half_sigma = 0.5 * sigma_iou;
     const float inf = __builtin_huge_valf();
-    bool bad = false;
+    int bad = 0;                               // 1: a NaN IoU, 2: more than TRK_CAND candidates for one track
     for (int w = wave; w < n_chunks * S; w += NW) {
       const int chunk = w % n_chunks, seg = w / n_chunks;
       const int t = chunk * 64 + lane;
@@ -313,11 +319,11 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
         if (inter < half_sigma * uni) return;
         const double v = inter / uni;
         if (v != v) {
-          bad = true;
+          bad |= 1;
         } else if (v > sigma_iou) {
           const int k = atomicAdd(&cnt[t], 1);
           if (k < TRK_CAND) cand[(size_t)t * TRK_CAND + k] = (unsigned short)j;
-          else bad = true;
+          else bad |= 2;
         }
       };
       int j = j_lo;
@@ -339,9 +345,10 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
         if (__ballot(m) != 0ull) { if (m) exact(j); }
       }
     }
-    if (bad) s_fallback = 1;
+    if (bad) atomicOr(&s_fallback, bad);
     __syncthreads();
     fast = s_fallback == 0;
+    if (tid == 0) s_form[fast ? 0 : ((s_fallback & 1) ? 1 : 2)] += 1;   // a frame with both causes counts as NaN
     TT(5)
 #ifdef FDT_TRK_TIMING
     if (tid == 0 && !fast) g_trk_time[6] += 1;   // frames that fell back to the exact form
@@ -770,6 +777,7 @@ __global__ __launch_bounds__(TRK_THREADS) void track_step_kernel(
     st->n_active = s_n_active;
     st->next_id = s_next_id;
     st->frame_num = s_frame_num;
+    for (int k = 0; k < 4; ++k) st->form_frames[k] += s_form[k];
   }
 }
 
@@ -1067,6 +1075,19 @@ extern "C" int fdt_tracker_track_boxes(fdt_tracker* t, int idx, double* boxes) {
   FDT_REQUIRE(idx >= 0 && idx < (int)t->finished.size(), FDT_ERR_ARG, "fdt_tracker: bad track index");
   const auto& tr = t->finished[idx];
   memcpy(boxes, tr.boxes.data(), tr.boxes.size() * 8);
+  return FDT_OK;
+}
+
+// Which association form the frames so far ran (since create / reset); synchronises with the stream of the last step.
+extern "C" int fdt_tracker_stats(fdt_tracker* t, long long* frames, long long* form_frames) {
+  FDT_REQUIRE(t, FDT_ERR_ARG, "fdt_tracker_stats: null handle");
+  hipStream_t st = t->last_stream ? t->last_stream : t->own_stream;
+  FDT_HIP(hipStreamSynchronize(st));
+  fdt::TrkState hs;
+  FDT_HIP(copy_sync(t, &hs, t->d_state, sizeof(hs), hipMemcpyDeviceToHost));
+  if (frames) *frames = hs.frame_num;
+  if (form_frames)
+    for (int k = 0; k < 4; ++k) form_frames[k] = hs.form_frames[k];
   return FDT_OK;
 }
 

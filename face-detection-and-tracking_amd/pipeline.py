@@ -130,6 +130,11 @@ class DetectTrackPipeline:
         association exactly like step().  flush() runs a partly filled batch (end of the video)."""
         G = self.B
         k, j = (i // G) % self.NF, i % G
+        pend = getattr(self, "_pending", None)
+        if (pend is not None) if j == 0 else (pend is None or pend[0] != i // G or pend[2] != j):
+            # same rule as fdt_pipeline_step_frame: in order from the group's first frame; a flushed group is closed
+            raise _lib.FdtError(_lib.FDT_ERR_STATE, "step_frame: frame %d is entry %d of group %d, which is not the open group "
+                                                    "at that entry (or another group is still open)" % (i, j, i // G))
         st = self.det_streams[k]
         if getattr(self, "_stage", None) is None:
             h, w = self.source_hw if self.source_hw else (self.H, self.W)
@@ -146,7 +151,7 @@ class DetectTrackPipeline:
         """Run the partly filled batch, if any: the unused entries of the staging batch hold older frames whose records
         the tracker is not shown."""
         pend = getattr(self, "_pending", None)
-        if pend and pend[2] < self.B:
+        if pend:
             self._launch_group(*pend)
         self._pending = None
 
@@ -244,6 +249,18 @@ class CabiPipeline:
         ms = ctypes.c_float(0)
         _lib.check(self._L.fdt_pipeline_elapsed_ms(self._p, ctypes.byref(ms)))
         return float(ms.value)
+
+    def stamps_enable(self, n):
+        """Record a timing event behind the association of each of the next n groups (latency measurements); 0 = off."""
+        _lib.check(self._L.fdt_pipeline_stamps_enable(self._p, int(n)))
+
+    def stamps_read(self, n):
+        """ms from mark(0) to the completion of every group stamped so far (numpy f32 array)."""
+        import numpy as np
+        out = np.zeros(int(n), np.float32)
+        cnt = ctypes.c_int(0)
+        _lib.check(self._L.fdt_pipeline_stamps_read(self._p, _lib.ptr(out), int(n), ctypes.byref(cnt)))
+        return out[:cnt.value]
 
     def slot(self, k):
         """(model handle, stream, record ptr, gathered-records ptr, counts ptr) of slot k, as c_void_p."""

@@ -55,6 +55,15 @@ class IouTracker:
                                                          num_classes, top_k, int(width), int(height),
                                                          float(score_thresh), stream))
 
+    def stats(self):
+        """Which association form the frames so far ran (fdt_tracker_stats): {'frames', 'candidate', 'exact_nan',
+        'exact_overflow', 'exact_sigma'} -- both forms reproduce iouTracke_cal.py:129-148 bit for bit."""
+        fr = C.c_longlong(0)
+        form = (C.c_longlong * 4)()
+        _lib.check(_lib.lib().fdt_tracker_stats(self._h, C.byref(fr), form))
+        return {"frames": int(fr.value), "candidate": int(form[0]), "exact_nan": int(form[1]),
+                "exact_overflow": int(form[2]), "exact_sigma": int(form[3])}
+
     def finish(self):
         L = _lib.lib()
         _lib.check(L.fdt_tracker_finish(self._h))

@@ -178,6 +178,12 @@ int fdt_tracker_num_tracks(fdt_tracker* t, int* n);
 int fdt_tracker_track_info(fdt_tracker* t, int idx, int* n_boxes, double* max_score,
                            int* start_frame);
 int fdt_tracker_track_boxes(fdt_tracker* t, int idx, double* boxes /* [n_boxes,4] */);
+/* Which of the kernel's two association forms the frames since create / reset ran (both make the decisions of the loop at
+ * iouTracke_cal.py:129-148 bit for bit; this makes the switch observable): *frames = frames stepped; form_frames[0] = candidate
+ * form (<= 6 detections above sigma_iou per track), [1] = exact form because some pair's IoU was NaN (0/0: a zero-area box against
+ * a zero-area box, :73-74's dummy row), [2] = exact form because a track had more than 6 candidates, [3] = exact form because
+ * sigma_iou < 0.  Waits for the steps enqueued so far.  Either output may be NULL.                                          */
+int fdt_tracker_stats(fdt_tracker* t, long long* frames, long long* form_frames /* [4] */);
 
 /* ------------------------------------------------------------------ detector model
  * build_sfd('test',640,2) / build_sfd_mobile('test',640,2) / FaceBox()                       */
@@ -305,6 +311,12 @@ int fdt_model_flops(fdt_model* m, double* flops);
 #define FDT_COMM_ID_BYTES 128
 int fdt_comm_unique_id(char* id_out /* [FDT_COMM_ID_BYTES] */);
 fdt_comm* fdt_comm_init_rank(int world, int rank, const char* id /* [FDT_COMM_ID_BYTES] */, int device);
+/* LOOP-BACK id: the `world` ranks are host THREADS of one process that share one GPU (RCCL refuses two ranks on a device).
+ * Every thread passes the same id to fdt_comm_init_rank (which returns when all have joined) and then uses the communicator
+ * exactly like an RCCL one: fdt_allgather_dets is a collective -- a host rendezvous of the ranks, then `world` device-to-device
+ * copies on the rank's own stream, ordered by events; a rank missing for 120 s fails the call on all ranks.  It exists so that
+ * the world > 1 branch of fdt_pipeline_* runs on a one-GPU box (tests/test_gpu_cabi_pipeline.py); it is not a transport.     */
+int fdt_comm_unique_id_local(char* id_out /* [FDT_COMM_ID_BYTES] */);
 fdt_comm* fdt_comm_init_all(int n_dev, const int* dev_ids);
 int fdt_comm_world(fdt_comm* c, int* world, int* n_local);
 int fdt_comm_group_begin(void);
@@ -335,13 +347,19 @@ void fdt_pipeline_destroy(fdt_pipeline* p);
 int fdt_pipeline_prime(fdt_pipeline* p, const void* frames_dev);
 /* enqueue step i: detection of `batch` frames on slot i % inflight, exchange, association of the step's world * batch frames */
 int fdt_pipeline_step(fdt_pipeline* p, long long i, const void* frames_dev);
-/* the same from HOST frames (`batch` pageable uint8 frames, iouTracke_cal.py:119-124): copied to a pinned landing buffer of the
- * slot (the caller's memory is free on return), H2D on the slot's stream in front of its forward.  n_valid < batch: a partly
- * filled last batch -- only the first n_valid frames reach the tracker.                                                    */
+/* the same from HOST frames (iouTracke_cal.py:119-124): n_valid pageable uint8 frames are copied to a pinned landing buffer of
+ * the slot (the caller's memory is free on return; the landing buffers of all slots are allocated by the first call), H2D on
+ * the slot's stream in front of its forward.  Frame order is that of fdt_pipeline_step (a rank's batch = consecutive frames).
+ * n_valid < batch: a partly filled last batch -- only the first n_valid frames reach the tracker; defined at world 1 only
+ * (FDT_ERR_ARG otherwise: the ranks would have to know each other's n_valid).                                              */
 int fdt_pipeline_step_host(fdt_pipeline* p, long long i, const void* frames_host, int n_valid);
 /* frames handed over ONE at a time (what a video source delivers), executed `batch` at a time: frame i of this rank is
- * copied into the staging batch of slot (i / batch) % inflight; the batch's last frame launches it (one launch per layer for
- * `batch` consecutive frames).  fdt_pipeline_flush runs a partly filled batch (end of the video).                       */
+ * copied into the staging batch (allocated by fdt_pipeline_create) of slot (i / batch) % inflight; the batch's last frame
+ * launches it (one launch per layer for `batch` consecutive frames).  fdt_pipeline_flush runs a partly filled batch (end of
+ * the video) and CLOSES it.  The frames of a group arrive in order starting with i % batch == 0; a frame that would continue
+ * a closed group, skip an entry or open a group while another is open is refused with FDT_ERR_STATE.  World > 1: frame i of
+ * rank r is frame i * world + r of the video (the tracker sees (group, entry, rank) order), and every rank hands over and
+ * flushes the same number of frames.                                                                                    */
 int fdt_pipeline_step_frame(fdt_pipeline* p, long long i, const void* frame_dev);
 int fdt_pipeline_flush(fdt_pipeline* p);
 int fdt_pipeline_sync(fdt_pipeline* p);
@@ -353,6 +371,12 @@ int fdt_pipeline_slot(fdt_pipeline* p, int slot, fdt_model** model, void** det_s
 /* timing events on the tracker stream: mark(0) ... steps ... mark(1); elapsed_ms waits for mark 1 */
 int fdt_pipeline_mark(fdt_pipeline* p, int which);
 int fdt_pipeline_elapsed_ms(fdt_pipeline* p, float* ms);
+/* Completion stamps for latency measurements (off by default): the next n exchange + association groups -- one per
+ * fdt_pipeline_step / _step_host call, one per launched group of _step_frame -- each record a timing event on the tracker
+ * stream behind the association (iouTracke_cal.py:126-156 done for those frames).  stamps_read: milliseconds from mark(0) to
+ * every stamp recorded so far (waits for them).  n = 0: off.                                                            */
+int fdt_pipeline_stamps_enable(fdt_pipeline* p, int n);
+int fdt_pipeline_stamps_read(fdt_pipeline* p, float* ms_since_mark0, int max, int* count);
 /* plain device buffers (hipMalloc / hipFree / blocking copies on the calling thread's private stream) for callers that
  * link no GPU runtime of their own                                                                                  */
 int fdt_dev_malloc(void** ptr, long long bytes);

@@ -679,7 +679,75 @@ def gen_tp_fp_fixture():
     save("tp_fp", **out)
 
 
-GENS = {"facebox": gen_facebox, "priors": gen_priors, "detect": gen_detect, "iou": gen_iou, "tracker": gen_tracker, "nets": gen_nets,
+def gen_tracker_r5():
+    """Round 5: sequences that force the device tracker's EXACT association form (csrc/tracker.hip falls back to it per frame),
+    expected tracks from the reference's own inline tracker lines (iouTracke_cal.py:127-155,174-175) as in gen_tracker():
+      stack      -- every face is reported 8..10 times per frame (near-identical boxes, as an un-suppressed detector would):
+                    each track has more than six detections above sigma_iou, frames of plain walking in between;
+      zero_mid   -- (0,0,0,0) rows among real detections on consecutive frames: a zero-box track meets a zero-box detection,
+                    0/0 = NaN IoU (utils/calc_performance.py:54-74 has no epsilon), numpy's arg-max returns the NaN;
+      neg_sigma  -- the loop with sigma_iou = -0.5 (every remaining detection matches, also the zero-IoU ones)."""
+    from utils.calc_performance import calculate_iou, calculate_distance
+    body, final = _tracker_sources()
+    rng = np.random.default_rng(505)
+
+    def stack_seq(n_frames, n_faces, w=640, h=480):
+        faces = [[rng.uniform(80, w - 80), rng.uniform(80, h - 80), rng.uniform(40, 90), rng.uniform(0.5, 0.99)]
+                 for _ in range(n_faces)]
+        frames = []
+        for f in range(n_frames):
+            dets = []
+            dup = 1 if f % 5 == 4 else int(rng.integers(8, 11))      # every fifth frame: one detection per face
+            for fc in faces:
+                fc[0] += rng.normal(0, 2.0); fc[1] += rng.normal(0, 2.0)
+                for _ in range(dup):
+                    jx, jy, js = rng.normal(0, 0.6, 3)
+                    sz = fc[2] * (1 + 0.01 * js)
+                    sc = float(np.clip(fc[3] + rng.normal(0, 0.03), 0.4, 1.0))
+                    dets.append([fc[0] + jx - sz / 2, fc[1] + jy - sz / 2, fc[0] + jx + sz / 2, fc[1] + jy + sz / 2, sc])
+            rng.shuffle(dets)
+            frames.append(np.array(dets, dtype=np.float32))
+        return frames
+
+    def zero_mid_seq():
+        frames = make_track_sequence(rng, 40, 5, p_drop=0.1)
+        for f in (6, 7, 8, 20, 21):                                   # a zero box among the real ones, consecutive frames
+            fr = frames[f]
+            if fr.shape[0] and fr[0, 2] > 0:
+                at = int(rng.integers(0, fr.shape[0] + 1))
+                frames[f] = np.insert(fr, at, np.array([0, 0, 0, 0, 0.55], fr.dtype), axis=0)
+        frames[30] = np.array([[0, 0, 0, 0, 0.4]])                    # the dummy row (:73-74) twice in a row as well
+        frames[31] = np.array([[0, 0, 0, 0, 0.4]])
+        return frames
+
+    seqs = {"stack": (stack_seq(30, 4), 0.4), "zero_mid": (zero_mid_seq(), 0.4),
+            "neg_sigma": (make_track_sequence(rng, 30, 5, p_drop=0.2), -0.5)}
+    result = {}
+    for name, (frames, sigma) in seqs.items():
+        ns = dict(np=np, calculate_iou=calculate_iou, calculate_distance=calculate_distance,
+                  use_iou=True, sigma_iou=sigma, sigma_dis=8, sigma_h=0.6, t_min=5,
+                  tracks_active=[], tracks_finished=[], frame_num=0)
+        for det0 in frames:
+            ns["frame_num"] += 1
+            ns["det0"] = det0
+            with np.errstate(all="ignore"):
+                exec(body, ns)
+        exec(final, ns)
+        result[name] = {
+            "sigma_iou": sigma,
+            "frames": [f.tolist() for f in frames],
+            "frame_dtypes": [str(f.dtype) for f in frames],
+            "tracks": [{"bboxes": [list(map(float, b)) for b in t["bboxes"]],
+                        "max_score": float(t["max_score"]), "start_frame": int(t["start_frame"])}
+                       for t in ns["tracks_finished"]],
+        }
+        print("tracker_r5", name, "frames", len(frames), "dets/frame", [len(f) for f in frames][:8], "tracks", len(result[name]["tracks"]))
+    with open(os.path.join(HERE, "tracker_r5.json"), "w") as f:
+        json.dump({"sequences": result}, f)
+    print("wrote tracker_r5.json", os.path.getsize(os.path.join(HERE, "tracker_r5.json")))
+
+
+GENS = {"tracker_r5": gen_tracker_r5, "facebox": gen_facebox, "priors": gen_priors, "detect": gen_detect, "iou": gen_iou, "tracker": gen_tracker, "nets": gen_nets,
         "nets45": gen_nets45, "nets12": gen_nets12, "nets_r2": gen_nets_r2, "nets_r3": gen_nets_r3,
         "facebox_r2": gen_facebox_r2, "tp_fp": gen_tp_fp_fixture, "distance": gen_distance}
 

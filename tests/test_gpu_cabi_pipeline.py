@@ -206,3 +206,163 @@ def test_cabi_pipeline_equals_the_python_pipeline(res50_sd, synth, batch, inflig
     py.close()
     assert got2 == want2
     net.close()
+
+
+# ------------------------------------------------------------------ world > 1 behind the C ABI (loop-back communicator)
+def _run_ranks(world, fn):
+    """fn(rank) on one host thread per rank (ctypes releases the GIL inside the library); re-raises the first failure."""
+    import threading
+    out, err = [None] * world, []
+
+    def work(r):
+        try:
+            out[r] = fn(r)
+        except BaseException as e:      # noqa: BLE001 -- handed to the main thread
+            err.append((r, e))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    assert not any(t.is_alive() for t in th), "a rank thread did not finish"
+    if err:
+        raise err[0][1]
+    return out
+
+
+def _local_id():
+    import ctypes
+    lib = M("_lib")
+    buf = ctypes.create_string_buffer(128)
+    lib.check(lib.lib().fdt_comm_unique_id_local(buf))
+    return buf
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("mode,batch,inflight", [("step", 1, 3), ("step", 2, 2), ("step_frame", 2, 2), ("step_frame", 4, 3)])
+def test_cabi_pipeline_at_world_gt_1_through_the_loopback_communicator(res50_sd, synth, world, mode, batch, inflight):
+    """fdt_pipeline_create(comm, rank, world > 1): `world` ranks = host threads sharing the one GPU, the exchange through
+    fdt_allgather_dets on a loop-back communicator (fdt_comm_unique_id_local + fdt_comm_init_rank) -- the gathered-record
+    indexing of track_slot (rank-major for step, (group, entry, rank) for step_frame incl. a partly filled last group), the
+    collective on the tracker stream beside the detector streams, the event chain.  Every rank must end with the track list of
+    ONE process that saw the same frames in video order (bit-equal), which is itself the oracle tracker's list on those
+    detections (reference iouTracke_cal.py:117-156,174-177)."""
+    lib = M("_lib")
+    L = lib.lib()
+    H, W = 128, 160
+    per_rank = 9 if mode == "step_frame" else 4             # step_frame: 9 frames per rank = a partly filled last group
+    n_items = per_rank if mode == "step_frame" else per_rank * batch
+    N = n_items * world
+    frames = moving_frames(synth, N, H, W, seed=11)
+    dev = torch.device("cuda", 0)
+    fd = torch.from_numpy(frames).to(dev)
+    torch.cuda.synchronize()
+    net = M("pyramid").build_sfd('test', 640, 2)
+    net.load_state_dict(res50_sd)
+    net.priorbox = M("layers").PriorBoxLayer(W, H)
+    net.detect = M("layers").Detect(2, 0, 750, 0.05, 0.35)
+
+    # one process, video order, same batch size (the same kernel plan): the list every rank must reproduce
+    one = M("pipeline").CabiPipeline(net, H, W, 0, inflight=inflight, batch=batch, log_frames=8)
+    one.prime(fd[:batch])
+    if mode == "step":
+        for i in range(N // batch):
+            one.step(i, fd[i * batch:(i + 1) * batch])
+    else:
+        for i in range(N):
+            one.step_frame(i, fd[i:i + 1])
+    recs = None
+    want = tracks_key(one.finish())
+    one.close()
+    assert len(want) >= 1
+    # ... which is the oracle tracker's list on the detections of the sequential path (batch 1 only: same plan, same bits)
+    if batch == 1:
+        ref = opp.IouTracker(0.4, 0.6, 5)
+        for f in frames:
+            with np.errstate(all="ignore"):
+                ref.step(opp.unpack_detections(net(f).numpy(), W, H, 0.4))
+        assert tracks_key(ref.finish()) == want
+
+    nets = [net.clone() for _ in range(world)]
+    uid = _local_id()
+
+    def rank_main(r):
+        comm = L.fdt_comm_init_rank(world, r, uid, 0)
+        assert comm, (L.fdt_last_error() or b"").decode()
+        try:
+            p = M("pipeline").CabiPipeline(nets[r], H, W, 0, inflight=inflight, batch=batch, comm=comm, world=world, rank=r,
+                                           log_frames=8)
+            try:
+                p.prime(fd[:batch])
+                if mode == "step":
+                    for s in range(per_rank):
+                        o = (s * world + r) * batch                      # rank r's batch of step s: consecutive frames
+                        p.step(s, fd[o:o + batch])
+                else:
+                    for i in range(per_rank):
+                        p.step_frame(i, fd[i * world + r:i * world + r + 1])     # frame i of rank r = frame i * world + r
+                return tracks_key(p.finish())
+            finally:
+                p.close()
+        finally:
+            L.fdt_comm_destroy(comm)
+
+    got = _run_ranks(world, rank_main)
+    for c in nets:
+        c.close()
+    net.close()
+    for r in range(world):
+        assert got[r] == want, "rank %d of %d" % (r, world)
+
+
+def test_step_frame_refuses_to_continue_a_flushed_group_and_step_host_a_partial_batch_at_world_2(res50_sd, synth):
+    lib = M("_lib")
+    L = lib.lib()
+    H, W = 128, 160
+    frames = moving_frames(synth, 8, H, W, seed=3)
+    fd = torch.from_numpy(frames).to(torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    net = M("pyramid").build_sfd('test', 640, 2)
+    net.load_state_dict(res50_sd)
+    net.priorbox = M("layers").PriorBoxLayer(W, H)
+    net.detect = M("layers").Detect(2, 0, 750, 0.05, 0.35)
+    for cls in ("CabiPipeline", "DetectTrackPipeline"):
+        p = (M("pipeline").CabiPipeline(net, H, W, 0, inflight=2, batch=4, log_frames=8) if cls == "CabiPipeline" else
+             M("pipeline").DetectTrackPipeline(net, H, W, torch.device("cuda", 0), inflight=2, batch=4, log_frames=8))
+        p.step_frame(0, fd[0:1])
+        p.step_frame(1, fd[1:2])
+        with pytest.raises(lib.FdtError) as e:
+            p.step_frame(3, fd[3:4])                          # skips entry 2
+        assert e.value.code == lib.FDT_ERR_STATE
+        with pytest.raises(lib.FdtError):
+            p.step_frame(4, fd[4:5])                          # opens group 1 while group 0 is open
+        p.flush()                                             # group 0 runs with two frames and is closed
+        with pytest.raises(lib.FdtError) as e:
+            p.step_frame(2, fd[2:3])                          # would continue the flushed group
+        assert e.value.code == lib.FDT_ERR_STATE
+        p.step_frame(4, fd[4:5])                              # the next group is fine
+        assert len(p.finish()) >= 0
+        p.close()
+    # step_host: a partly filled batch is defined at world 1 only
+    nets = [net.clone() for _ in range(2)]
+    uid = _local_id()
+
+    def rank_main(r):
+        comm = L.fdt_comm_init_rank(2, r, uid, 0)
+        assert comm
+        p = M("pipeline").CabiPipeline(nets[r], H, W, 0, inflight=2, batch=2, comm=comm, world=2, rank=r, log_frames=8)
+        with pytest.raises(lib.FdtError) as e:
+            p.step_host(0, frames[0:2], n_valid=1)
+        code = e.value.code
+        p.step_host(0, frames[2 * r:2 * r + 2])               # a full batch is fine (collective: both ranks call it)
+        n = len(p.finish())
+        p.close()
+        L.fdt_comm_destroy(comm)
+        return code, n
+
+    out = _run_ranks(2, rank_main)
+    assert [o[0] for o in out] == [lib.FDT_ERR_ARG] * 2 and out[0][1] == out[1][1]
+    for c in nets:
+        c.close()
+    net.close()

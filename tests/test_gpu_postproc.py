@@ -235,6 +235,60 @@ def test_tracker_bit_exact_vs_reference(nm, log_frames):
         assert got["bboxes"] == exp["bboxes"]
 
 
+@pytest.mark.parametrize("nm,forms", [("stack", ("candidate", "exact_overflow")), ("zero_mid", ("candidate", "exact_nan")),
+                                      ("neg_sigma", ("exact_sigma",))])
+@pytest.mark.parametrize("log_frames", [64, 7])
+def test_tracker_both_association_forms_run_and_match_the_reference(nm, forms, log_frames):
+    """The kernel's candidate form (<= 6 detections above sigma_iou per track) and its per-frame exact fallback are now
+    observable (fdt_tracker_stats): on reference-generated sequences built to leave the candidate form -- 8..10 stacked
+    detections per face, zero boxes against zero boxes (NaN IoU), sigma_iou < 0 -- the named forms really ran, every frame is
+    accounted for, and the tracks are the reference's (iouTracke_cal.py:127-155,174-175), bit for bit."""
+    with open(os.path.join(GOLDEN, "tracker_r5.json")) as f:
+        s = json.load(f)["sequences"][nm]
+    tr = M("tracker").IouTracker(s["sigma_iou"], 0.6, 5, max_dets=1500, log_frames=log_frames)
+    for fr, dt in zip(s["frames"], s["frame_dtypes"]):
+        tr.step(np.array(fr, dtype=dt))
+    st = tr.stats()
+    tracks = tr.finish()
+    assert st["frames"] == len(s["frames"])
+    assert st["candidate"] + st["exact_nan"] + st["exact_overflow"] + st["exact_sigma"] == st["frames"], st
+    for k in ("candidate", "exact_nan", "exact_overflow", "exact_sigma"):
+        assert (st[k] > 0) == (k in forms), (nm, st)
+    assert len(tracks) == len(s["tracks"]) and len(tracks) >= 4
+    for got, exp in zip(tracks, s["tracks"]):
+        assert got["start_frame"] == exp["start_frame"]
+        assert got["max_score"] == exp["max_score"]
+        assert got["bboxes"] == exp["bboxes"]
+    tr.reset()
+    assert tr.stats() == {"frames": 0, "candidate": 0, "exact_nan": 0, "exact_overflow": 0, "exact_sigma": 0}
+
+
+def test_tracker_degenerate_and_stacked_cases_vs_oracle():
+    """Hand-made frames (oracle tracker as the checker): seven near-identical detections over one track (the seventh candidate
+    is the trigger), a (0,0,0,0) track against a (0,0,0,0) detection, and the same with the dummy row of iouTracke_cal.py:73-74."""
+    base = np.array([100, 100, 180, 180], np.float32)
+    seven = np.stack([np.concatenate([base + np.float32(0.5 * k), [np.float32(0.9 - 0.01 * k)]]) for k in range(7)]).astype(np.float32)
+    frames = [np.concatenate([base, [0.95]])[None].astype(np.float32),      # one track
+              seven,                                                        # 7 candidates for it -> exact form
+              seven[:6],                                                    # 6 candidates per track at most... (7 tracks)
+              np.array([[0, 0, 0, 0, 0.7], [100, 100, 180, 180, 0.9]], np.float32),
+              np.array([[100, 100, 180, 180, 0.9], [0, 0, 0, 0, 0.7]], np.float32),   # zero track x zero det: NaN
+              np.array([[0, 0, 0, 0, 0.4]]), np.array([[0, 0, 0, 0, 0.4]])] + [seven[:3]] * 6
+    tr = M("tracker").IouTracker(0.4, 0.6, 2, max_dets=64, log_frames=4)
+    ref = opp.IouTracker(0.4, 0.6, 2)
+    for f in frames:
+        tr.step(f)
+        with np.errstate(all="ignore"):
+            ref.step(f)
+    st = tr.stats()
+    got, exp = tr.finish(), ref.finish()
+    assert st["exact_overflow"] >= 1 and st["exact_nan"] >= 2 and st["candidate"] >= 6, st
+    assert len(got) == len(exp) and len(exp) >= 1
+    for g, e in zip(got, exp):
+        assert g["start_frame"] == e["start_frame"] and g["max_score"] == float(e["max_score"])
+        assert g["bboxes"] == [list(map(float, b)) for b in e["bboxes"]]
+
+
 def test_tracker_long_random_vs_oracle():
     """500 frames, up to 300 detections per frame: ids/boxes identical to the oracle."""
     rng = np.random.default_rng(2024)
