@@ -73,8 +73,23 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
             dist.barrier()
     frames_d = torch.from_numpy(frames_h).to(dev)
     L = lib.lib()
-    res = net.detect_frames(frames_h)          # plan (+ the GPU results of these frames for the parity leg)
-    net.autotune(args.tune_iters)
+    # kernel plan: the committed autotuner result for this batch (tuned/facebox_1024x1024_b<B>.plan) when there is one -- the
+    # run then launches the same kernels every time and no candidate kernel appears in a profile of it --, else autotune here
+    plan_file = os.path.join(ROOT, "face-detection-and-tracking_amd", "tuned", "facebox_1024x1024_b%d.plan" % B)
+    if args.autotune == 1 and os.path.exists(plan_file):
+        net.import_plan(open(plan_file).read())
+        plan_src = "tuned/" + os.path.basename(plan_file)
+        res = net.detect_frames(frames_h)      # plan (+ the GPU results of these frames for the parity leg)
+    else:
+        res = net.detect_frames(frames_h)
+        if args.autotune:
+            net.autotune(args.tune_iters)
+            plan_src = "autotuned at start-up"
+            if args.save_plan and rank == 0:
+                with open(plan_file, "w") as f:
+                    f.write(net.export_plan())
+        else:
+            plan_src = "analytic model"
     # `inflight` batches in flight, each on its own handle (fdt_model_clone: shared weights) and stream: the net is a
     # chain of ~40 short launches, so consecutive batches overlap almost completely
     NF = args.inflight if args.inflight > 0 else 4
@@ -173,8 +188,13 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
                         "algorithmic_bytes_per_frame": round(tot_b / B),
                         "achieved": round(gbs(tot_b, tot_ms), 1), "frac": round(gbs(tot_b, tot_ms) / 8000.0, 4),
                         "avg_launch_us": round(tot_ms * 1e3 / len(rows), 2)},
-            "timed_step": {"ms_per_step": round(step_ms, 4), "achieved": round(gbs(tot_b, step_ms), 1),
-                           "frac": round(gbs(tot_b, step_ms) / 8000.0, 4)},
+            # the timed region against the UN-FUSED lower bound of the reference's own graph (FACEBOX/networks.py:87-116 one launch
+            # per layer: 77 320 262 B per frame, fdt_model_traffic of the FDT_FB_FUSE=0 graph + the ingest) -- a fused launch list
+            # has fewer algorithmic bytes of its own, which must not lower the bar the step is measured against
+            "timed_step": {"ms_per_step": round(step_ms, 4), "achieved": round(gbs(77320262.0 * B, step_ms), 1),
+                           "frac": round(gbs(77320262.0 * B, step_ms) / 8000.0, 4),
+                           "algorithmic_bytes_per_frame": 77320262,
+                           "achieved_on_this_launch_list": round(gbs(tot_b, step_ms), 1)},
             "by_op": [{"op": r[0], "ms": round(r[1], 4), "GBps": round(gbs(r[2], r[1]), 1),
                        "algorithmic_tflops": round(r[3] / (r[1] * 1e-3) / 1e12, 1) if r[1] > 0 else 0.0}
                       for r in sorted(rows, key=lambda r: -r[1])[:8]],
@@ -256,6 +276,7 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
                                              "decode_np+nms_np on device" % (SW, SH, B),
                                  "weights": "reference FACEBOX/faceboxes.pt", "faces_per_image": faces[:6],
                                  "batches_in_flight": NF, "hip_graph": bool(args.graph), "device": pkg.device_name(0),
+                                 "kernel_plan": plan_src, "frames_per_launch": B,
                                  "parallelism": "frame-parallel replicas x%d, no data-path collective (the path has no "
                                                 "exchange step: FACEBOX/My_test_facebox.py is detection only)" % world},
                       "roofline": roof, "cpu_baseline": cpu, "parity": parity, "host_path": host_path}))

@@ -120,7 +120,19 @@ struct ConvArgs {
   float u8_mean[3];             // u8_mean[c]) / u8_scale, the arithmetic of the ingest kernel (ops.hip: preprocess_kernel)
   float u8_scale;
   int tiles_per_wg;       // persistent-tile kernels (conv_1x1p.h): consecutive output tiles one workgroup walks; filled in by launch_conv
+  // Input as a channel slice of a wider tensor: `in` points at the slice's first channel of image 0 and consecutive images are
+  // in_bstride floats apart (0 = Cin * Hin * Win, a tensor of its own).  Every class honours it.
+  long long in_bstride;
+  // Second destination (FaceBoxes' Inception, FACEBOX/networks.py:43-57: the 1x1 branches that read the same x run as ONE
+  // launch): output channels [out2_from, Cout) go to out2 [B][out2_ctot][Hout][Wout] at channel out2_coff + (co - out2_from),
+  // channels below out2_from to `out` as usual.  Direct classes only (conv_kernel.h), no split-K (conv_shape_supported).
+  float* out2;
+  int out2_from, out2_ctot, out2_coff;
 };
+// floats between consecutive images of the input
+__host__ __device__ inline long long conv_in_bstride(const ConvArgs& a) {
+  return a.in_bstride ? a.in_bstride : (long long)a.Cin * a.Hin * a.Win;
+}
 
 enum { CONV_MAP_ROWS = 0, CONV_MAP_XCD_SPATIAL = 1, CONV_MAP_XCD_CHANNEL = 2, CONV_MAP_XCD_REGION = 3, CONV_MAP_COUNT = 4 };
 

@@ -375,8 +375,16 @@ bool conv_combine_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
 }
 
 // Shape limits of a kernel class beyond the (kind, tile) table: the autotuner and fdt_conv2d ask before they launch.
+// the direct implicit-GEMM classes of conv_kernel.h (one epilogue: the only one that knows ConvArgs.out2)
+static bool kind_is_direct(ConvKind k) {
+  return k == CONV_1x1_S1 || k == CONV_1x1_S2 || k == CONV_3x3_S1 || k == CONV_3x3_S1_D2 || k == CONV_3x3_S2 || k == CONV_7x7_S2 ||
+         k == CONV_7x7_S4 || k == CONV_5x5_S2 || k == CONV_1x1_S1_K32 || k == CONV_1x1_S1_K64 || k == CONV_7x7_S2_P1;
+}
+
 bool conv_shape_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
   if (!conv_supported(kind, tile)) return false;
+  if (a.out2 && (!kind_is_direct(kind) || a.ksplit > 1 || a.ws || a.res || a.up || a.sk_count)) return false;
+  if (a.in_bstride && (kind_is_u8_stem(kind) || kind == CONV_7x7_S4_K168)) return false;
   if (kind == CONV_3x3_D2_WINO44 && (a.Win & 3)) return false;
   if (kind_is_u8_stem(kind))   // the raw-frame stem: three input channels, one stage, plain epilogue, one channel tile per 32 / 64 couts
     return a.in_u8 != nullptr && a.Cin == 3 && a.ksplit <= 1 && !a.ws && !a.res && !a.up && !a.sk_count &&
@@ -413,6 +421,13 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
   FDT_REQUIRE(a.B >= 1 && a.Cin >= 1 && a.Cout >= 1 && a.out_coff >= 0 &&
                   a.out_coff + a.Cout <= a.out_ctot && (a.in || a.in_u8) && a.w && a.out,
               FDT_ERR_ARG, "launch_conv: bad channel/pointer arguments");
+  FDT_REQUIRE(!a.out2 || (a.out2_from > 0 && a.out2_from < a.Cout && a.out2_coff >= 0 &&
+                          a.out2_coff + (a.Cout - a.out2_from) <= a.out2_ctot && a.out_coff + a.out2_from <= a.out_ctot),
+              FDT_ERR_ARG, "launch_conv: bad second destination (out2_from %d of Cout %d)", a.out2_from, a.Cout);
+  FDT_REQUIRE(a.in_bstride == 0 || a.in_bstride >= (long long)a.Cin * a.Hin * a.Win, FDT_ERR_ARG,
+              "launch_conv: in_bstride %lld smaller than one image of the slice", a.in_bstride);
+  FDT_REQUIRE(!(a.out2 || a.in_bstride) || conv_shape_supported(kind, tile, a), FDT_ERR_ARG,
+              "launch_conv: kernel class %d does not take a second destination / a channel-slice input for this layer", (int)kind);
   FDT_REQUIRE(kind_is_persistent(kind) || conv_shape_supported(kind, tile, a), FDT_ERR_ARG,
               "launch_conv: kernel class %d is not instantiated for this layer (raw-frame stem needs ConvArgs.in_u8 and Cin = 3; every "
               "other class reads f32)", (int)kind);

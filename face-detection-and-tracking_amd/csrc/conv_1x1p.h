@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, P::RESIDENT) void conv1x1p_kernel(const ConvAr
     b = q / a.n_sp;
     oy0 = (sp / tiles_x) * P::TH;
     ox0 = (sp % tiles_x) * P::TW;
-    xrs = buf_rsrc(a.in + (long long)b * a.Cin * HW, (long long)a.Cin * HW * 4);   // channels past Cin read as zeros
+    xrs = buf_rsrc(a.in + (long long)b * conv_in_bstride(a), (long long)a.Cin * HW * 4);   // channels past Cin read as zeros
 #pragma unroll
     for (int k = 0; k < P::NXV; ++k) {
       // float4 v = 256*k + tid covers 4 consecutive pixels of one tile row of one channel of the stage

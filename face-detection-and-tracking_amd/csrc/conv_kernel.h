@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
 
   const int HWin = a.Hin * a.Win;
   const int HWout = a.Hout * a.Wout;
-  const float* in_b = a.in + (long long)b * a.Cin * HWin;
+  const float* in_b = a.in + (long long)b * conv_in_bstride(a);
   const int nstages = (a.Cin + G::KC - 1) / G::KC;
   const float* w_t = a.w + (long long)n_tile * nstages * L::WSZP;
   // this workgroup's share of the reduction (split-K over input-channel stages)
@@ -352,7 +352,10 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
                 v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
               }
             }
-            slab_store4(dst_b + off, v.x, v.y, v.z, v.w, raw && a.sk_count);
+            float* dst = dst_b + off;
+            if (a.out2 && co >= a.out2_from)      // second destination (conv.h: ConvArgs.out2; never with split-K / residual)
+              dst = a.out2 + ((long long)b * a.out2_ctot + a.out2_coff + (co - a.out2_from)) * HWout + (long long)oy * a.Wout + ox;
+            slab_store4(dst, v.x, v.y, v.z, v.w, raw && a.sk_count);
           }
         }
       }
@@ -401,7 +404,12 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void conv_kernel(const ConvArgs 
         if (res_b) v += res_b[(long long)coc * HWout + pix];
         if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
         else if (a.act == ACT_RELU6) v = fminf(fmaxf(v, 0.0f), 6.0f);
-        if (pix_ok && co < a.Cout) out_b[(long long)co * HWout + pix] = v;
+        if (pix_ok && co < a.Cout) {
+          if (a.out2 && co >= a.out2_from)
+            a.out2[((long long)b * a.out2_ctot + a.out2_coff + (co - a.out2_from)) * HWout + pix] = v;
+          else
+            out_b[(long long)co * HWout + pix] = v;
+        }
       }
     }
   }

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256, 4) void conv_n8_kernel(const ConvArgs a) {
   const int b = blockIdx.z / a.ksplit;
   const int ks = blockIdx.z - b * a.ksplit;
   const int HW = a.Hin * a.Win;                          // == Hout * Wout (stride 1, pad 1)
-  const float* in_b = a.in + (long long)b * a.Cin * HW;
+  const float* in_b = a.in + (long long)b * conv_in_bstride(a);
   const float* w_t = a.w + (long long)n_tile * a.Cin * L::WSZ;
   const int s_begin = (int)((long long)a.Cin * ks / a.ksplit);
   const int s_end = (int)((long long)a.Cin * (ks + 1) / a.ksplit);

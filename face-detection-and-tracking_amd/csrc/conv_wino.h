@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
   const int ks = blockIdx.z - b * a.ksplit;
 
   const int HW = a.Hin * a.Win;                             // stride 1, pad 1: Hout == Hin
-  const float* in_b = a.in + (long long)b * a.Cin * HW;
+  const float* in_b = a.in + (long long)b * conv_in_bstride(a);
   const int nstages = (a.Cin + T::KC - 1) / T::KC;
   const float* w_t = a.w + (long long)n_tile * nstages * T::WSZP;
   const int s_begin = (int)((long long)nstages * ks / a.ksplit);
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
   const int ks = blockIdx.z - b * a.ksplit;
 
   const int HW = a.Hin * a.Win;
-  const float* in_b = a.in + (long long)b * a.Cin * HW;
+  const float* in_b = a.in + (long long)b * conv_in_bstride(a);
   const int nstages = (a.Cin + T::KC - 1) / T::KC;
   const float* w_t = a.w + (long long)n_tile * nstages * T::WSZP;
   const int s_begin = (int)((long long)nstages * ks / a.ksplit);
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const ConvArgs a) {
   const int ks = blockIdx.z - b * a.ksplit;
 
   const int HW = a.Hin * a.Win;
-  const float* in_b = a.in + (long long)b * a.Cin * HW;
+  const float* in_b = a.in + (long long)b * conv_in_bstride(a);
   const int nstages = (a.Cin + T::KC - 1) / T::KC;
   const float* w_t = a.w + (long long)n_tile * nstages * T::WSZP;
   const int s_begin = (int)((long long)nstages * ks / a.ksplit);

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ConvArgs a) {
   const int ks = blockIdx.z - b * a.ksplit;
 
   const int HW = a.Hin * a.Win;                            // stride 1, pad 1: Hout == Hin
-  const float* in_b = a.in + (long long)b * a.Cin * HW;
+  const float* in_b = a.in + (long long)b * conv_in_bstride(a);
   const int nstages = (a.Cin + 1) / 2;
   const float* w_t = a.w + (long long)n_tile * nstages * T::WSZ;
   const int s_begin = (int)((long long)nstages * ks / a.ksplit);
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(768, 3) void conv_wino44b_kernel(const ConvArgs a) 
   const int ks = blockIdx.z - b * a.ksplit;
 
   const int HW = a.Hin * a.Win;
-  const float* in_b = a.in + (long long)b * a.Cin * HW;
+  const float* in_b = a.in + (long long)b * conv_in_bstride(a);
   const int nstages = (a.Cin + 1) / 2;
   const float* w_t = a.w + (long long)n_tile * nstages * T::WSZ;
   const int s_begin = (int)((long long)nstages * ks / a.ksplit);

@@ -48,7 +48,7 @@ struct Op {
   ConvTile tile;
   ConvArgs ca;
   // pool / dw / finalize
-  int in_t = -1, in2_t = -1, out_t = -1, stride = 1, crelu = 0, act = 0;
+  int in_t = -1, in2_t = -1, out_t = -1, out2_t = -1, stride = 1, crelu = 0, act = 0;
   int ksize = 3, pad = 1, dil = 1;   // depthwise geometry
   const float* w = nullptr;
   const float* bias = nullptr;
@@ -172,6 +172,7 @@ struct fdt_model {
   unsigned long long graph_clock = 0;
   int plan_runs = 0;          // eager forwards since the plan was (re)built; capture starts at the second
   bool use_graph = true;
+  int fb_fuse = 2;            // FaceBoxes' Inception: 0 eight launches per block, 1 the three 1x1 branches on x as one, 2 also conv4 | conv6 (Builder::inception)
   struct Hint { int kind, tile, split, map, combine; };   // combine: in-kernel split-K combine (conv.h) instead of the reduce pass
   std::map<std::string, Hint> hints;                        // autotuned (kernel class, tile, split) per layer
   int hB = 0, hH = 0, hW = 0;                               // shape the hints were tuned for
@@ -399,6 +400,20 @@ struct Builder {
     std::string name2;        // second conv concatenated along Cout (fused loc+conf heads)
     int cout2 = 0;
     int groups = 1;           // grouped 1x1 (pyramid_mobile_try1.py:185-186): run as the block-diagonal dense conv
+    // More convolutions of the same geometry in the SAME launch, concatenated along Cout behind the layer itself (FaceBoxes'
+    // Inception, FACEBOX/networks.py:43-57).  Each keeps its own bias and BatchNorm fold; a part may read only the input
+    // channels [in_off, in_off + in_c) of the launch's input (its weights are zero elsewhere: the zeros add an exact 0.0f to
+    // every fmaf chain, like the grouped 1x1 above).  w_in_c > 0 restricts the layer's own weights the same way.
+    struct Part {
+      std::string name, bn;
+      int cout = 0, in_off = 0, in_c = 0;
+    };
+    std::vector<Part> more;
+    int w_in_off = 0, w_in_c = 0;
+    // output channels from out2_from on go to tensor out2_t at channel out2_coff (ConvArgs.out2)
+    int out2_t = -1, out2_from = 0, out2_coff = 0;
+    // the input is the channel slice [in_coff, in_coff + in_c) of tensor in_t (ConvArgs.in_bstride)
+    int in_coff = 0, in_c = 0;
   };
 
   static bool stem_s4_enabled() {
@@ -410,11 +425,22 @@ struct Builder {
 
   int conv(const std::string& name, int in_t, int Cout, ConvKind kind, const ConvOpt& o) {
     if (rc != FDT_OK) return -1;
-    const Tensor in = m->tensors[in_t];
+    Tensor in = m->tensors[in_t];
+    const int in_ctot = in.C;
+    if (o.in_c > 0) {                         // a channel slice of the tensor is this launch's input
+      if (o.in_coff < 0 || o.in_coff + o.in_c > in.C) {
+        set_error("input slice out of range at %s", name.c_str());
+        return fail(FDT_ERR_STATE);
+      }
+      in.C = o.in_c;
+      if (!m->dry) in.d += (size_t)o.in_coff * in.H * in.W;
+    }
     const ConvGeom g = conv_geom(kind);
     const int Ho = (in.H + 2 * g.pad - g.dil * (g.kh - 1) - 1) / g.stride + 1;
     const int Wo = (in.W + 2 * g.pad - g.dil * (g.kw - 1) - 1) / g.stride + 1;
-    const int Ctot = Cout + o.cout2;
+    int Ctot = Cout + o.cout2;
+    for (const auto& pt : o.more) Ctot += pt.cout;
+    const bool special = !o.more.empty() || o.out2_t >= 0 || o.in_c > 0 || o.w_in_c > 0;   // direct classes, no split-K
     if (Ho < 1 || Wo < 1) {
       set_error("input too small: layer %s would have a %dx%d output", name.c_str(), Ho, Wo);
       return fail(FDT_ERR_ARG);
@@ -428,6 +454,12 @@ struct Builder {
       for (const char* sfx : {".weight", ".bias", ".running_mean", ".running_var"}) (void)get(o.bn + sfx);
     const HostT* w2 = o.cout2 ? get(o.name2 + ".weight") : nullptr;
     const HostT* b2 = o.cout2 ? get(o.name2 + ".bias") : nullptr;
+    for (const auto& pt : o.more) {           // the parts' keys belong to the state dict whether or not weights are loaded yet
+      (void)get(pt.name + ".weight");
+      (void)get(pt.name + ".bias");
+      if (!pt.bn.empty())
+        for (const char* sfx : {".weight", ".bias", ".running_mean", ".running_var"}) (void)get(pt.bn + sfx);
+    }
     Op op;
     op.type = OP_CONV;
     op.name = name;
@@ -437,6 +469,8 @@ struct Builder {
     auto hint = m->hints.find(name);
     if (hint != m->hints.end() && m->hB == B && m->hH == m->tensors[0].H && m->hW == m->tensors[0].W &&
         conv_base_kind((ConvKind)hint->second.kind) == kind &&
+        (o.out2_t < 0 || ((ConvKind)hint->second.kind == kind || (ConvKind)hint->second.kind == CONV_1x1_S1_K32 ||
+                          (ConvKind)hint->second.kind == CONV_1x1_S1_K64)) &&
         conv_supported((ConvKind)hint->second.kind, (ConvTile)hint->second.tile) &&
         // the persistent 1x1 class has shape limits of its own (conv.hip: conv_shape_supported); a plan entry that does not
         // fit this layer is ignored like one for another shape
@@ -466,6 +500,7 @@ struct Builder {
     } else {
       choose(kind, Ctot, in.C, Ho, Wo, B, o.up_t >= 0, op.tile, ksplit);
     }
+    if (o.out2_t >= 0) ksplit = 1;            // the reduce passes know one destination
     ConvArgs& a = op.ca;
     memset(&a, 0, sizeof(a));
     a.ksplit = ksplit;
@@ -480,7 +515,26 @@ struct Builder {
     a.out_ctot = m->tensors[out_t].C;
     a.out_coff = o.out_coff;
     a.act = o.act;
+    if (o.in_c > 0) a.in_bstride = (long long)in_ctot * in.H * in.W;
+    if (o.out2_t >= 0) {
+      const Tensor& t2 = m->tensors[o.out2_t];
+      if (t2.H != Ho || t2.W != Wo || o.out2_from <= 0 || o.out2_from >= Ctot || o.out2_coff + (Ctot - o.out2_from) > t2.C ||
+          o.out_coff + o.out2_from > m->tensors[out_t].C || o.res_t >= 0 || o.up_t >= 0) {
+        set_error("bad second destination at %s", name.c_str());
+        return fail(FDT_ERR_STATE);
+      }
+      a.out2 = t2.d;
+      a.out2_from = o.out2_from;
+      a.out2_ctot = t2.C;
+      a.out2_coff = o.out2_coff;
+      op.out2_t = o.out2_t;
+    }
     op.flops = conv_flops(a, kind);
+    {                                         // algorithmic FLOPs: the zero blocks of a block-diagonal launch are not work
+      double macs = (double)Cout * (o.w_in_c > 0 ? o.w_in_c : in.C) / std::max(1, o.groups) + (double)o.cout2 * in.C;
+      for (const auto& pt : o.more) macs += (double)pt.cout * (pt.in_c > 0 ? pt.in_c : in.C);
+      op.flops = 2.0 * B * (double)Ho * Wo * g.kh * g.kw * macs;
+    }
     op.out_t = out_t;
     op.needs_ws = ksplit > 1;
     if (op.needs_ws) m->ws_floats = std::max(m->ws_floats, conv_ws_floats(a));
@@ -497,8 +551,10 @@ struct Builder {
     if (!m->dry) {
       if (rc != FDT_OK) return -1;
       const size_t per = (size_t)in.C * g.kh * g.kw;
-      if (w->v.size() * o.groups != per * Cout || (b && (int)b->v.size() != Cout) ||
-          (w2 && w2->v.size() != per * o.cout2) || in.C % o.groups || Cout % o.groups || (o.groups > 1 && o.cout2)) {
+      const size_t per_own = (size_t)(o.w_in_c > 0 ? o.w_in_c : in.C) * g.kh * g.kw;      // the layer's own weights: [Cout][w_in_c][kh][kw]
+      if (w->v.size() * o.groups != per_own * Cout || (b && (int)b->v.size() != Cout) ||
+          (w2 && w2->v.size() != per * o.cout2) || in.C % o.groups || Cout % o.groups || (o.groups > 1 && o.cout2) ||
+          ((o.w_in_c > 0 || !o.more.empty()) && (o.groups > 1 || o.cout2)) || o.w_in_off + (o.w_in_c > 0 ? o.w_in_c : in.C) > in.C) {
         set_error("weight shape mismatch for layer %s", name.c_str());
         return fail(FDT_ERR_STATE);
       }
@@ -506,6 +562,36 @@ struct Builder {
       fold(o.bn, b, Cout, scale, bias);
       if (rc != FDT_OK) return -1;
       const std::vector<float>* wsrc = &w->v;
+      if (o.w_in_c > 0 || !o.more.empty()) {
+        // [Ctot][in.C][kh][kw]: the layer's rows, then every part's, each over its own input channels (zeros elsewhere)
+        const size_t kk = (size_t)g.kh * g.kw;
+        wcat.assign(per * Ctot, 0.0f);
+        auto place = [&](const std::vector<float>& src, int co0, int cout, int in_off, int in_c) {
+          for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < in_c; ++ci)
+              for (size_t k = 0; k < kk; ++k)
+                wcat[(size_t)(co0 + co) * per + (size_t)(in_off + ci) * kk + k] = src[((size_t)co * in_c + ci) * kk + k];
+        };
+        place(w->v, 0, Cout, o.w_in_off, o.w_in_c > 0 ? o.w_in_c : in.C);
+        int co0 = Cout;
+        for (const auto& pt : o.more) {
+          const HostT* pw = get(pt.name + ".weight");
+          const HostT* pb = get(pt.name + ".bias");
+          const int pin = pt.in_c > 0 ? pt.in_c : in.C;
+          if (!pw || !pb || pw->v.size() != (size_t)pt.cout * pin * kk || (int)pb->v.size() != pt.cout || pt.in_off + pin > in.C) {
+            set_error("weight shape mismatch for part %s of layer %s", pt.name.c_str(), name.c_str());
+            return fail(FDT_ERR_STATE);
+          }
+          std::vector<float> ps, pbias;
+          fold(pt.bn, pb, pt.cout, ps, pbias);
+          if (rc != FDT_OK) return -1;
+          place(pw->v, co0, pt.cout, pt.in_off, pin);
+          scale.insert(scale.end(), ps.begin(), ps.end());
+          bias.insert(bias.end(), pbias.begin(), pbias.end());
+          co0 += pt.cout;
+        }
+        wsrc = &wcat;
+      }
       if (o.groups > 1) {   // zeros outside the diagonal blocks add exact 0.0f to every fmaf chain
         const size_t cig = in.C / o.groups, cog = Cout / o.groups, kk = (size_t)g.kh * g.kw;
         wcat.assign(per * Cout, 0.0f);
@@ -1172,18 +1258,78 @@ struct Builder {
     return conv(n + ".0", x, cout, kind, o);
   }
 
-  int inception(const std::string& n, int x) {   // networks.py:43-57
+  // Inception (networks.py:43-57).  The three 1x1 branches that read x itself -- conv1 (-> out[0:32]), conv3 and conv5 (24 channels
+  // each, the inputs of the two 3x3 branches) -- are ONE launch with two destinations (ConvArgs.out2): 80 output channels over
+  // the same staged input instead of three passes over it; conv4 (on conv3's output, -> out[64:96]) and conv6 (on conv5's) are
+  // one block-diagonal 3x3 launch over the 48-channel pair.  Five launches per block instead of eight, the same sums per
+  // output channel (a part's weights are zero over the other part's input channels: exact +0.0f).  FDT_FB_FUSE=0 / 1 (create
+  // time): the un-fused form / only the 1x1 launch, for A/B runs and the bit-equality test.
+  int inception(const std::string& n, int x) {
     if (rc != FDT_OK) return -1;
     const Tensor xin = m->tensors[x];
     int out = new_tensor(n, 128, xin.H, xin.W);
     if (out < 0) return -1;
-    cbr(n + ".conv1", x, 32, CONV_1x1_S1, out, 0);
+    const int fuse = m->fb_fuse;
+    if (fuse == 0) {
+      cbr(n + ".conv1", x, 32, CONV_1x1_S1, out, 0);
+      int xp = pool(n + ".pool", x, 1, 0);
+      cbr(n + ".conv2", xp, 32, CONV_1x1_S1, out, 32);
+      int t3 = cbr(n + ".conv3", x, 24, CONV_1x1_S1);
+      cbr(n + ".conv4", t3, 32, CONV_3x3_S1, out, 64);
+      int t5 = cbr(n + ".conv5", x, 24, CONV_1x1_S1);
+      int t6 = cbr(n + ".conv6", t5, 32, CONV_3x3_S1);
+      cbr(n + ".conv7", t6, 32, CONV_3x3_S1, out, 96);
+      return out;
+    }
+    int t35 = new_tensor(n + ".conv3_5", 48, xin.H, xin.W);     // [conv3 | conv5]
+    if (t35 < 0) return -1;
+    {
+      ConvOpt o;                                                  // conv1 | conv3 | conv5 on x
+      o.bn = n + ".conv1.1";
+      o.act = ACT_RELU;
+      o.out_t = out;
+      o.out_coff = 0;
+      o.more.push_back({n + ".conv3.0", n + ".conv3.1", 24, 0, 0});
+      o.more.push_back({n + ".conv5.0", n + ".conv5.1", 24, 0, 0});
+      o.out2_t = t35;
+      o.out2_from = 32;
+      o.out2_coff = 0;
+      conv(n + ".conv1.0", x, 32, CONV_1x1_S1, o);
+    }
     int xp = pool(n + ".pool", x, 1, 0);
     cbr(n + ".conv2", xp, 32, CONV_1x1_S1, out, 32);
-    int t3 = cbr(n + ".conv3", x, 24, CONV_1x1_S1);
-    cbr(n + ".conv4", t3, 32, CONV_3x3_S1, out, 64);
-    int t5 = cbr(n + ".conv5", x, 24, CONV_1x1_S1);
-    int t6 = cbr(n + ".conv6", t5, 32, CONV_3x3_S1);
+    int t6 = new_tensor(n + ".conv6.0", 32, xin.H, xin.W);
+    if (t6 < 0) return -1;
+    if (fuse >= 2) {
+      ConvOpt o;                                                  // conv4 on t35[0:24] | conv6 on t35[24:48]
+      o.bn = n + ".conv4.1";
+      o.act = ACT_RELU;
+      o.out_t = out;
+      o.out_coff = 64;
+      o.w_in_off = 0;
+      o.w_in_c = 24;
+      o.more.push_back({n + ".conv6.0", n + ".conv6.1", 32, 24, 24});
+      o.out2_t = t6;
+      o.out2_from = 32;
+      o.out2_coff = 0;
+      conv(n + ".conv4.0", t35, 32, CONV_3x3_S1, o);
+    } else {
+      ConvOpt o4;
+      o4.bn = n + ".conv4.1";
+      o4.act = ACT_RELU;
+      o4.out_t = out;
+      o4.out_coff = 64;
+      o4.in_coff = 0;
+      o4.in_c = 24;
+      conv(n + ".conv4.0", t35, 32, CONV_3x3_S1, o4);
+      ConvOpt o6;
+      o6.bn = n + ".conv6.1";
+      o6.act = ACT_RELU;
+      o6.out_t = t6;
+      o6.in_coff = 24;
+      o6.in_c = 24;
+      conv(n + ".conv6.0", t35, 32, CONV_3x3_S1, o6);
+    }
     cbr(n + ".conv7", t6, 32, CONV_3x3_S1, out, 96);
     return out;
   }
@@ -1494,13 +1640,15 @@ ByteRange tensor_range(const fdt_model* m, int t, int B) {
 }
 struct OpAccess {
   ByteRange rd[3], wr;   // wr of a conv: its channel slice when the batch is 1 (contiguous), else the whole tensor
+  ByteRange wr2;         // ConvArgs.out2: the whole second tensor
 };
 OpAccess op_access(const fdt_model* m, const Op& op, int B) {
-  OpAccess x{{{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}}, {nullptr, nullptr}};
+  OpAccess x{{{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}}, {nullptr, nullptr}, {nullptr, nullptr}};
   if (op.type == OP_CONV) {
     const ConvArgs& a = op.ca;
     const size_t hwo = (size_t)a.Hout * a.Wout;
-    x.rd[0] = {(const char*)a.in, (const char*)a.in + (size_t)a.B * a.Cin * a.Hin * a.Win * 4};
+    x.rd[0] = {(const char*)a.in, (const char*)a.in + (size_t)a.B * conv_in_bstride(a) * 4};
+    if (a.out2) x.wr2 = {(const char*)a.out2, (const char*)a.out2 + (size_t)a.B * a.out2_ctot * hwo * 4};
     if (a.res) x.rd[1] = {(const char*)a.res, (const char*)a.res + (size_t)a.B * a.res_ctot * hwo * 4};
     if (a.up) x.rd[2] = {(const char*)a.up, (const char*)a.up + (size_t)a.B * a.Cout * a.up_h * a.up_w * 4};
     if (a.B == 1)
@@ -1551,8 +1699,8 @@ int plan_reduces(fdt_model* m, int B) {
     bool conflict = false;
     for (const auto& p : pend) {
       for (const auto& r : x.rd) conflict |= r.overlaps(p.wr);                    // reads what a pending pass will write
-      conflict |= x.wr.overlaps(p.wr);                                              // writes it
-      for (const auto& r : p.rd) conflict |= x.wr.overlaps(r);                      // rewrites what a pending pass will read
+      conflict |= x.wr.overlaps(p.wr) || x.wr2.overlaps(p.wr);                     // writes it
+      for (const auto& r : p.rd) conflict |= x.wr.overlaps(r) || x.wr2.overlaps(r); // rewrites what a pending pass will read
     }
     // the heads' finalize and Detect read through tables / other paths: nothing may be pending behind them
     if (op.type == OP_HEADFIN || op.type == OP_MBOXFIN) conflict |= !pend.empty();
@@ -1847,6 +1995,7 @@ extern "C" fdt_model* fdt_model_create(int arch, int device) {
     return nullptr;
   }
   if (const char* g = getenv("FDT_GRAPH")) m->use_graph = atoi(g) != 0;
+  if (const char* g = getenv("FDT_FB_FUSE")) m->fb_fuse = atoi(g);
   if (const char* g = getenv("FDT_FUSE_INGEST")) m->fuse_stem = atoi(g);   // A/B: 0 = ingest kernel + planar stem conv, 2 = also FaceBoxes
   if (arch == FDT_ARCH_TRY3 || arch == FDT_ARCH_TRY4 || arch == FDT_ARCH_TRY5) {   // pyramid_mb2_try3.py:216
     m->conf_t = 0.2f;
@@ -1917,6 +2066,7 @@ extern "C" fdt_model* fdt_model_clone(fdt_model* src) {
   m->hW = src->hW;
   m->use_graph = src->use_graph;
   m->fuse_stem = src->fuse_stem;
+  m->fb_fuse = src->fb_fuse;
   return m.release();
 }
 

@@ -239,6 +239,39 @@ def test_fused_ingest_facebox_bits(fb_sd):
     assert np.array_equal(res[0][2], res[1][2])
 
 
+@pytest.mark.parametrize("B", [1, 16])
+def test_inception_branches_in_one_launch_equal_the_eight_launch_form(fb_sd, monkeypatch, B):
+    """FACEBOX/networks.py:43-57 with the branches that share an input as single launches (conv1 | conv3 | conv5 on x: one
+    1x1 launch with two destinations; conv4 | conv6: one block-diagonal 3x3 launch) against the one-launch-per-layer form
+    (FDT_FB_FUSE=0 at create time) and the 1x1-only form (1): the same sums per output channel -- bit-equal wherever neither
+    form splits a reduction, else to f32 rounding --, the same faces, and fewer launches."""
+    d, _ = load_npz("facebox_r2")
+    frames = np.stack([d["img%d_frame" % (i % 6)] for i in range(B)])
+    out = {}
+    for fuse in ("0", "1", "2"):
+        monkeypatch.setenv("FDT_FB_FUSE", fuse)
+        n = M("FACEBOX.networks").FaceBox()
+        n.load_state_dict(fb_sd)
+        loc, conf = n(frames)
+        res = n.detect_frames(frames)
+        n.profile(True)
+        n.detect_frames(frames)
+        launches = len(n.profile_read())
+        n.profile(False)
+        stages = {st: n.get_tensor(st) for st in ("inception1", "inception2", "hs0", "hs1", "hs2")}
+        out[fuse] = (loc.numpy(), conf.numpy(), res, launches, stages)
+        n.close()
+    monkeypatch.delenv("FDT_FB_FUSE")
+    assert out["0"][3] - out["1"][3] == 6 and out["1"][3] - out["2"][3] == 3, [out[k][3] for k in "012"]
+    assert out["2"][3] <= 33                                    # ops + "detect" + "ingest" entries
+    for fuse in ("1", "2"):
+        for st, g in out[fuse][4].items():
+            assert g.shape == out["0"][4][st].shape and rel_rms(g, out["0"][4][st]) < 2e-6, (fuse, st)
+        assert rel_rms(out[fuse][0], out["0"][0]) < 2e-6 and rel_rms(out[fuse][1], out["0"][1]) < 2e-6
+        for (bx, pr), (bx0, pr0) in zip(out[fuse][2], out["0"][2]):
+            assert len(pr) == len(pr0) >= 3 and np.allclose(pr, pr0, atol=1e-6) and np.allclose(bx, bx0, atol=1e-6)
+
+
 def test_config5_as_baseline_words_it_4k_sources_and_batch_16_in_one_call(net, fb_sd):
     """BASELINE.json configs[4] in ONE call: sixteen 2160x3840 uint8 sources (the six multi-face images, pixel-replicated like
     bench.py builds its frames) resized on the GPU and detected as one batch.  Equal images of the batch give equal bits, every image
@@ -251,7 +284,12 @@ def test_config5_as_baseline_words_it_4k_sources_and_batch_16_in_one_call(net, f
     xi = (np.arange(SW) * 1024) // SW
     uniq = [np.ascontiguousarray(d["img%d_frame" % i][yi][:, xi]) for i in range(6)]
     frames = np.stack([uniq[b % 6] for b in range(B)])                 # 398 MB of sources
+    plan = net.tuned_plan_text(1024, 1024, B)                          # tuned/facebox_1024x1024_b16.plan: what bench.py --arch facebox runs
+    assert plan is not None and plan.split()[:4] == ["shape", "16", "1024", "1024"]
+    net.import_plan(plan)
     res = net.detect_frames(frames)
+    ran = {ln.split()[0]: ln.split() for ln in net.export_plan().strip().splitlines()[1:]}
+    assert all(ran[ln.split()[0]][:len(ln.split())] == ln.split() for ln in plan.strip().splitlines()[1:]), "the batch did not run the committed plan"
     x = net.get_tensor("input")
     assert x.shape == (B, 3, 1024, 1024)
     singles = [net.detect_frames(u[None])[0] for u in uniq]

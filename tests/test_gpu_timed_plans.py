@@ -48,7 +48,7 @@ PINNED_ELSEWHERE = {
     "res50_1920x1080_b1.plan": "tests/test_gpu_model.py::test_res50_native_1080p_vs_reference_fixture",
     "try3_1024x1024_b8.plan": "tests/test_gpu_model.py::test_try3_1024_batch8_vs_reference_fixture",
     "try3_1024x1024_b1.plan": "tests/test_gpu_timed_plans.py::test_try3_batch1_plan_vs_reference_fixture",
-    "facebox_1024x1024_b16.plan": "tests/test_gpu_facebox.py::test_config5_as_baseline_words_it_4k_sources_batch16_distinct_images",
+    "facebox_1024x1024_b16.plan": "tests/test_gpu_facebox.py::test_config5_as_baseline_words_it_4k_sources_and_batch_16_in_one_call",
 }
 
 
