@@ -37,7 +37,7 @@ struct Tensor {
   float* d = nullptr;
 };
 
-enum OpType { OP_CONV, OP_POOL, OP_DW, OP_HEADFIN, OP_MBOXFIN, OP_PAD, OP_EXPDW };
+enum OpType { OP_CONV, OP_POOL, OP_DW, OP_HEADFIN, OP_MBOXFIN, OP_PAD, OP_EXPDW, OP_DWPROJ };
 
 struct Op {
   OpType type;
@@ -72,6 +72,8 @@ struct Op {
   ConvKind u8_kind = CONV_7x7_S2_U8;
   ConvTile u8_tile = TILE_128x64W;
   const float* u8_w = nullptr;
+  // ... and the 3x3 / 2 stem of the MobileNetV2 detectors as a streaming vector-ALU kernel (stream_ir.hip): u8_w = [27][Cout]
+  bool u8_stream = false;
 };
 
 struct DevW {
@@ -172,6 +174,7 @@ struct fdt_model {
   unsigned long long graph_clock = 0;
   int plan_runs = 0;          // eager forwards since the plan was (re)built; capture starts at the second
   bool use_graph = true;
+  bool stream_ir = true;      // try3 / try4 / try5: the streaming vector-ALU kernels of stream_ir.hip (FDT_STREAM_IR=0 at create time: off)
   int fb_fuse = 2;            // FaceBoxes' Inception: 0 eight launches per block, 1 the three 1x1 branches on x as one, 2 also conv4 | conv6 (Builder::inception)
   struct Hint { int kind, tile, split, map, combine; };   // combine: in-kernel split-K combine (conv.h) instead of the reduce pass
   std::map<std::string, Hint> hints;                        // autotuned (kernel class, tile, split) per layer
@@ -643,6 +646,33 @@ struct Builder {
           op.u8_stem = true;
         }
       }
+      // the 3x3 / 2 stem of try3 / try5 (3 -> 32) on raw uint8 frames: a streaming kernel (stream_ir.hip), weights [27][32]
+      if (in_t == 0 && in.C == 3 && o.groups == 1 && !o.cout2 && !special && o.res_t < 0 && o.up_t < 0 && m->stream_ir &&
+          conv_base_kind(kind) == CONV_3x3_S2 && stem3x3s2_u8_supported(in.H, in.W, Ctot) && out_t >= 0 && o.out_coff == 0 &&
+          m->tensors[out_t].C == Ctot) {
+        std::lock_guard<std::mutex> lk(m->W->mu);
+        const std::string ck = name + "|s3u8";
+        auto it = m->W->wcache.find(ck);
+        DevW d;
+        if (it == m->W->wcache.end()) {
+          const WeightStore::HostW& hw = m->W->host_w[name];          // [Cout][3][3][3], BN folded
+          std::vector<float> wt((size_t)27 * Ctot);
+          for (int co = 0; co < Ctot; ++co)
+            for (int k = 0; k < 27; ++k) wt[(size_t)k * Ctot + co] = hw.w[(size_t)co * 27 + k];
+          if (hipMalloc((void**)&d.w, wt.size() * 4) != hipSuccess) {
+            set_error("hipMalloc failed for %s", ck.c_str());
+            return fail(FDT_ERR_HIP);
+          }
+          (void)copy_sync(d.w, wt.data(), wt.size() * 4, hipMemcpyHostToDevice, m->stream);
+          d.bias = nullptr;      // the kernel takes the layer's own bias (ConvArgs.bias); the cache frees every pointer it holds once
+          m->W->wcache[ck] = d;
+        } else {
+          d = it->second;
+        }
+        op.u8_w = d.w;
+        op.u8_stem = true;
+        op.u8_stream = true;
+      }
       a.in = in.d;
       a.w = dw.w;
       a.bias = dw.bias;
@@ -861,6 +891,70 @@ struct Builder {
     return out_t;
   }
 
+  // depthwise 3x3 (stride 1) + BN + ReLU6 and the block's 1x1 project + BN (+ residual) as ONE streaming kernel
+  // (stream_ir.hip): conv[i..i+2] and conv[i+3..i+4] of an InvertedResidual, pyramid_mb2_try3.py:84-94,96-134
+  int dw_project(const std::string& p, int i, int in_t, int oup, int res_t) {
+    if (rc != FDT_OK) return -1;
+    const Tensor in = m->tensors[in_t];
+    const std::string ndw = p + ".conv." + std::to_string(i), bdw = p + ".conv." + std::to_string(i + 1),
+                      npr = p + ".conv." + std::to_string(i + 3), bpr = p + ".conv." + std::to_string(i + 4);
+    int out_t = new_tensor(npr, oup, in.H, in.W);
+    if (out_t < 0) return -1;
+    const HostT* wd = get(ndw + ".weight");
+    const HostT* wp = get(npr + ".weight");
+    std::vector<float> s1, b1, s2, b2;
+    fold(bdw, nullptr, in.C, s1, b1);
+    fold(bpr, nullptr, oup, s2, b2);
+    Op op;
+    op.type = OP_DWPROJ;
+    op.name = p + ".dw_project";
+    op.in_t = in_t;
+    op.in2_t = res_t;
+    op.out_t = out_t;
+    op.hid = in.C;
+    op.oup = oup;
+    op.flops = 2.0 * B * (double)in.H * in.W * in.C * (9 + oup);
+    memset(&op.ca, 0, sizeof(op.ca));
+    if (!m->dry) {
+      if (rc != FDT_OK) return -1;
+      if ((int)wd->v.size() != in.C * 9 || (int)wp->v.size() != oup * in.C) {
+        set_error("weight shape mismatch for the fused depthwise + project of %s", p.c_str());
+        return fail(FDT_ERR_STATE);
+      }
+      std::lock_guard<std::mutex> lk(m->W->mu);
+      DevW d1, d2;
+      auto it = m->W->wcache.find(p + "|dwproj1");
+      if (it == m->W->wcache.end()) {
+        std::vector<float> a(wd->v), t((size_t)in.C * oup);
+        for (int c = 0; c < in.C; ++c)
+          for (int k = 0; k < 9; ++k) a[(size_t)c * 9 + k] *= s1[c];                       // the folding dwconv() applies
+        for (int o = 0; o < oup; ++o)
+          for (int c = 0; c < in.C; ++c) t[(size_t)c * oup + o] = wp->v[(size_t)o * in.C + c] * s2[o];   // ... and conv(); transposed
+        if (hipMalloc((void**)&d1.w, a.size() * 4) != hipSuccess || hipMalloc((void**)&d1.bias, (size_t)in.C * 4) != hipSuccess ||
+            hipMalloc((void**)&d2.w, t.size() * 4) != hipSuccess || hipMalloc((void**)&d2.bias, (size_t)oup * 4) != hipSuccess) {
+          set_error("hipMalloc failed for %s", p.c_str());
+          return fail(FDT_ERR_HIP);
+        }
+        (void)copy_sync(d1.w, a.data(), a.size() * 4, hipMemcpyHostToDevice, m->stream);
+        (void)copy_sync(d1.bias, b1.data(), (size_t)in.C * 4, hipMemcpyHostToDevice, m->stream);
+        (void)copy_sync(d2.w, t.data(), t.size() * 4, hipMemcpyHostToDevice, m->stream);
+        (void)copy_sync(d2.bias, b2.data(), (size_t)oup * 4, hipMemcpyHostToDevice, m->stream);
+        m->W->wcache[p + "|dwproj1"] = d1;
+        m->W->wcache[p + "|dwproj2"] = d2;
+      } else {
+        d1 = it->second;
+        d2 = m->W->wcache[p + "|dwproj2"];
+      }
+      op.w = d1.w;
+      op.bias = d1.bias;
+      op.w2 = d2.w;
+      op.bias2 = d2.bias;
+    }
+    m->ops.push_back(op);
+    m->flops_per_frame += op.flops / B;
+    return out_t;
+  }
+
   void mboxfin(int map_t, int anchors) {   // FACEBOX/multibox_layer.py:34-48
     if (rc != FDT_OK) return;
     Op op;
@@ -1051,6 +1145,12 @@ struct Builder {
         h = conv(p + ".conv." + std::to_string(i), h, hid, CONV_1x1_S1, o);
         i += 3;
       }
+      // On the large maps the depthwise output (as big as its input) is the block's traffic: depthwise + project as one
+      // streaming kernel (stream_ir.hip) -- features.1 of try3 at batch 8: 235 us as two launches.  Below 256^2 the grid of
+      // 4-pixel strips no longer fills the chip and the two launches stay.
+      const Tensor hin = m->tensors[h];
+      if (m->stream_ir && stride == 1 && dw_project_supported(hid, hin.H, hin.W, oup) && (long long)hin.H * hin.W >= 256ll * 256)
+        return dw_project(p, i, h, oup, inp == oup ? x : -1);
       h = dwconv(p + ".conv." + std::to_string(i), p + ".conv." + std::to_string(i + 1), h, stride, ACT_RELU6);
       i += 3;
     }
@@ -1459,11 +1559,13 @@ int make_plan(fdt_model* m, int B, int H, int W) {
   FDT_HIP(hipStreamSynchronize(m->stream));
   m->free_plan();
   m->dry = false;
+  FDT_HIP(hipGetLastError());      // a stale error of an earlier, unchecked runtime call would otherwise surface at the first launch check below
   int rc = build_graph(m, B, H, W);
   if (rc != FDT_OK) {
     m->free_plan();
     return rc;
   }
+  FDT_HIP(hipGetLastError());      // ... and one left behind by the plan's own allocations / uploads
   // detection levels -> prior offsets
   int P = 0;
   size_t li = 0;
@@ -1500,7 +1602,9 @@ int make_plan(fdt_model* m, int B, int H, int W) {
       if (op.type == OP_CONV && op.combine) op.ca.sk_count = m->d_skcnt;
   }
   FDT_TRY(setup_heads(m));
+  FDT_HIP(hipGetLastError());
   FDT_TRY(plan_reduces(m, B));
+  FDT_HIP(hipGetLastError());
   FDT_TRY(make_priors(m, H, W));
   m->pB = B;
   m->pH = H;
@@ -1732,6 +1836,9 @@ int plan_reduces(fdt_model* m, int B) {
 
 // The raw-frame stem of op (conv_stem_u8.h) on the uint8 frames of the forward being enqueued.
 int launch_u8_stem(fdt_model* m, const Op& op, hipStream_t st) {
+  if (op.u8_stream)
+    return launch_stem3x3s2_u8(m->u8_src, op.ca.B, op.ca.Hin, op.ca.Win, m->u8_mean, op.u8_w, op.ca.bias, op.ca.Cout, op.ca.act,
+                               op.ca.out, st);
   ConvArgs a = op.ca;
   a.in = nullptr;
   a.in_u8 = m->u8_src;
@@ -1814,6 +1921,13 @@ int run_ops(fdt_model* m, int B, hipStream_t st, size_t first_op = 0) {
                                    out.W, st, m->device));
         break;
       }
+      case OP_DWPROJ: {
+        const Tensor& in = m->tensors[op.in_t];
+        const Tensor& out = m->tensors[op.out_t];
+        FDT_TRY(launch_dw_project(in.d, B, in.C, in.H, in.W, op.w, op.bias, op.w2, op.bias2, op.oup,
+                                  op.in2_t >= 0 ? m->tensors[op.in2_t].d : nullptr, out.d, st));
+        break;
+      }
       case OP_HEADFIN:
         if (op.last_head) FDT_TRY(launch_head_finalize_all(m->headfin, B, st));   // all levels at once (setup_heads)
         break;
@@ -1855,7 +1969,7 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
   // iouTracke_cal.py:40-46 / My_test_facebox.py:14-15 happens in the stem conv's staging -- the f32 NCHW frame is never
   // written.  The stem then reads the caller's device frames in place, the H2D landing buffer, or the resized uint8 image.
   const bool fused = m->fuse_stem && format == FDT_FRAME_U8_HWC_BGR && !m->ops.empty() && m->ops[0].u8_stem &&
-                     (m->fuse_stem >= 2 || m->ops[0].u8_kind == CONV_7x7_S2_U8);
+                     (m->fuse_stem >= 2 || m->ops[0].u8_stream || m->ops[0].u8_kind == CONV_7x7_S2_U8);
   m->u8_src = nullptr;
   if (fused) {
     const bool fb = m->arch == FDT_ARCH_FACEBOX;
@@ -1996,6 +2110,7 @@ extern "C" fdt_model* fdt_model_create(int arch, int device) {
   }
   if (const char* g = getenv("FDT_GRAPH")) m->use_graph = atoi(g) != 0;
   if (const char* g = getenv("FDT_FB_FUSE")) m->fb_fuse = atoi(g);
+  if (const char* g = getenv("FDT_STREAM_IR")) m->stream_ir = atoi(g) != 0;
   if (const char* g = getenv("FDT_FUSE_INGEST")) m->fuse_stem = atoi(g);   // A/B: 0 = ingest kernel + planar stem conv, 2 = also FaceBoxes
   if (arch == FDT_ARCH_TRY3 || arch == FDT_ARCH_TRY4 || arch == FDT_ARCH_TRY5) {   // pyramid_mb2_try3.py:216
     m->conf_t = 0.2f;
@@ -2067,6 +2182,7 @@ extern "C" fdt_model* fdt_model_clone(fdt_model* src) {
   m->use_graph = src->use_graph;
   m->fuse_stem = src->fuse_stem;
   m->fb_fuse = src->fb_fuse;
+  m->stream_ir = src->stream_ir;
   return m.release();
 }
 
@@ -2777,8 +2893,11 @@ extern "C" int fdt_model_profile_read(fdt_model* m, int max, char* names, float*
       if (i < (int)m->ops.size() && m->ops[i].type == OP_CONV) {
         const Op& o_ = m->ops[i];
         const bool u8 = o_.u8_stem && m->last_fused;      // the raw-frame stem ran in its place
-        nm += "#k" + std::to_string((int)(u8 ? o_.u8_kind : o_.kind)) + "t" + std::to_string((int)(u8 ? o_.u8_tile : o_.tile)) + "s" +
-              std::to_string(u8 ? 1 : o_.ca.ksplit);
+        if (u8 && o_.u8_stream)
+          nm += ".u8_stream";                               // stream_ir.hip: not a conv class (no "#k" suffix: a vector-ALU kernel)
+        else
+          nm += "#k" + std::to_string((int)(u8 ? o_.u8_kind : o_.kind)) + "t" + std::to_string((int)(u8 ? o_.u8_tile : o_.tile)) + "s" +
+                std::to_string(u8 ? 1 : o_.ca.ksplit);
       }
       snprintf(names + (size_t)i * 48, 48, "%s", nm.c_str());
     }
@@ -2808,6 +2927,9 @@ extern "C" int fdt_model_traffic(fdt_model* m, double* act_bytes, double* weight
     } else if (op.type == OP_EXPDW) {
       b = tb(op.in_t) + tb(op.out_t);        // (the residual of a whole-block launch is the staged input itself)
       w = 4.0 * op.hid * (m->tensors[op.in_t].C + 1 + 9 + 1) + 4.0 * op.oup * (op.hid + 1);
+    } else if (op.type == OP_DWPROJ) {
+      b = tb(op.in_t) + tb(op.out_t) + tb(op.in2_t);
+      w = 4.0 * m->tensors[op.in_t].C * (9 + 1 + op.oup) + 4.0 * op.oup;
     } else if (op.type == OP_HEADFIN || op.type == OP_MBOXFIN) {
       b = 2.0 * tb(op.in_t);
     } else {

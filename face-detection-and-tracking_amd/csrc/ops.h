@@ -73,4 +73,16 @@ int launch_ir_block(const float* x, int B, int Cin, int H, int W, const float* w
                     int Ho, int Wo, hipStream_t st, int dev);
 size_t ir_block_lds_bytes(int Cin, int stride, int hid);
 
+// Streaming vector-ALU kernels of the MobileNetV2 detectors' HBM-bound front (stream_ir.hip).
+// depthwise 3x3 (stride 1, pad 1) + bias + ReLU6, then the 1x1 project + bias (+ residual [B][oup][H][W]) in one pass: in
+// [B][hid][H][W] -> out [B][oup][H][W]; w9 [hid][9], bdw [hid], wpt [hid][oup] (transposed), bp [oup]; oup in {16, 24, 32}.
+bool dw_project_supported(int hid, int H, int W, int oup);
+int launch_dw_project(const float* in, int B, int hid, int H, int W, const float* w9, const float* bdw, const float* wpt,
+                      const float* bp, int oup, const float* res, float* out, hipStream_t st);
+// Conv2d(3, 32, 3, stride 2, pad 1) + bias + act on raw uint8 HWC BGR frames ((float)u8 - mean in registers):
+// frames [B][H][W][3] -> out [B][32][Ho][Wo]; wt [27][32] ((c, dy, dx) major); W % 8 == 0.
+bool stem3x3s2_u8_supported(int H, int W, int Cout);
+int launch_stem3x3s2_u8(const unsigned char* frames, int B, int H, int W, const float mean[3], const float* wt, const float* bias,
+                        int Cout, int act, float* out, hipStream_t st);
+
 }  // namespace fdt

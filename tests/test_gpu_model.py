@@ -510,6 +510,39 @@ def test_try3_1024_heads_on_the_vector_alu_kernel_without_a_plan(try3_sd, synth)
     net.close()
 
 
+@pytest.mark.parametrize("H,W,B", [(512, 512, 2), (522, 520, 1)])
+def test_try3_streaming_stem_and_depthwise_project_kernels(try3_sd, synth, monkeypatch, H, W, B):
+    """csrc/stream_ir.hip: features.0 (3x3 / 2 stem, pyramid_mb2_try3.py:162) on the raw uint8 frame and features.1 (the t = 1
+    InvertedResidual, :84-94) as depthwise + project in one pass, both on the vector ALU, against the MFMA / two-launch forms
+    (FDT_STREAM_IR=0 at create time) and against the oracle's stages; an odd row count exercises the two-row strips' tail."""
+    frames = synth.make_frames(B, H, W, seed=31)
+    PB = M("layers").PriorBoxLayer
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FDT_STREAM_IR", mode)
+        net = M("pyramid_mb2_try3").build_sfd_mobile('test', 640, 2)
+        net.load_state_dict(try3_sd)
+        net.priorbox = PB(W, H, stride=[4, 8, 16, 32, 64], box=(16, 32, 64, 128, 256))
+        net.detect = M("layers").Detect(2, 0, 750, 0.02, 0.35)
+        y = net(frames).numpy()
+        names = [n for n, _, _ in (net.profile(True), net(frames), net.profile_read())[2]]
+        net.profile(False)
+        res[mode] = (y, net.get_tensor("stem"), net.get_tensor("features.1.conv.3"), names)
+        net.close()
+    monkeypatch.delenv("FDT_STREAM_IR")
+    assert any(n == "features.0.0.u8_stream" for n in res["1"][3]) and any(n == "features.1.dw_project" for n in res["1"][3])
+    assert not any(n.endswith((".u8_stream", ".dw_project")) for n in res["0"][3])
+    assert len(res["0"][3]) - len(res["1"][3]) == 1                      # depthwise + project: one launch instead of two
+    o = opb.try3_forward(try3_sd, opb.preprocess(frames[0]), want=["stem", "c2"])
+    for mode in ("1", "0"):
+        assert rel_rms(res[mode][1][0], o["stem"][0]) < STAGE_RTOL, mode
+    assert rel_rms(res["1"][1], res["0"][1]) < 2e-6 and rel_rms(res["1"][2], res["0"][2]) < 2e-6
+    for b in range(B):
+        n = int((res["0"][0][b, 1, :, 0] > 0).sum())
+        d_iou, d_sc = match_detections(res["1"][0][b, 1], res["0"][0][b, 1], n)
+        assert n > 5 and d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
+
+
 def test_try3_with_fused_inverted_residual_heads(try3_sd, synth, monkeypatch):
     """The fused expand + depthwise kernel (csrc/fused_ir.hip) normally takes over only on maps of 256^2 and more; forced on
     for every block that fits (FDT_FUSE_IR=1), the try3 stages at a small odd size still match the oracle, and the forced-off
