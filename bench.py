@@ -30,6 +30,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 (v_mfma_f32_32x32x16_bf16: 1024 FLOP/clk/SIMD at 2.4 GHz)
+B3_KIND = 21                      # conv.h: CONV_1x1_S1_B3 -- split-bf16 products, SIX bf16 MFMA FLOPs per algorithmic f32 FLOP
 
 
 def facebox_main(args, rank=0, local_rank=0, world=1):
@@ -286,7 +288,7 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
 
 
 KIND_NAMES = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2", "3x3s1_wino", "3x3d2_wino", "1x1s1_k32",
-              "1x1s1_k64", "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44", "1x1s1_p16", "1x1s1_p32", "7x7s2_u8", "7x7s4_u8", "7x7s4_k168"]
+              "1x1s1_k64", "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44", "1x1s1_p16", "1x1s1_p32", "7x7s2_u8", "7x7s4_u8", "7x7s4_k168", "1x1s1_b3"]
 WINO_KINDS = (8, 9, 14, 15)   # conv.h: Winograd kinds execute fewer MACs than the direct form:
 WINO_RATIO = {8: 2.25, 9: 2.25, 14: 4.0, 15: 4.0}   # F(2x2,3x3) 16/36 of them, F(4x4,3x3) (CONV_3x3_{S1,D2}_WINO44) 36/144
 
@@ -321,6 +323,8 @@ def kernel_label(kind, tile):
         return "conv_stem_s4_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
     if kind == 18:            # conv.h: CONV_7x7_S2_U8, the stem conv on the raw uint8 frame (conv_stem_u8.h)
         return "conv_stem_u8_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
+    if kind == 21:            # conv.h: CONV_1x1_S1_B3, split-bf16 products on the bf16 matrix pipe (conv_b3.h)
+        return "conv_b3_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
     if kind in (16, 17):      # conv.h: CONV_1x1_S1_P16 / _P32, the persistent-tile 1x1 kernel (conv_1x1p.h)
         return "conv1x1p_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
     return "conv_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
@@ -833,6 +837,7 @@ def main():
         # incl. the downsample convs) and the extra stages layer5 / layer6 (pyramid.py:120-131) -- everything in front of
         # the LFPN.  [launches, ms, algorithmic flops, executed flops], same serial profile pass as conv_stack.
         bb = [0, 0.0, 0.0, 0.0]
+        b3 = [0, 0.0, 0.0]                    # split-bf16 1x1 layers: launches, ms, algorithmic flops
         bb_pool_ms = 0.0
         is_backbone = lambda layer: args.arch == "res50" and (layer == "conv1" or layer.split(".")[0] in (
             "layer1", "layer2", "layer3", "layer4", "layer5", "layer6"))
@@ -858,6 +863,13 @@ def main():
                     conv_ms += ms; alg += fl; exe += fl; n_conv += 1
                 continue
             ex = fl / WINO_RATIO[kind] if kind in WINO_KINDS else fl
+            # a split-bf16 layer executes 6 x its algorithmic FLOPs, on the bf16 pipe.  Every aggregate below prices a kernel
+            # against the peak of the pipe it runs on: `ex` is kept in f32-pipe equivalents (executed FLOPs x f32 peak / that
+            # pipe's peak), so that ex / time / 157.3 stays what it was -- the fraction of the time the matrix pipe is busy at
+            # its paper rate -- whatever mix of the two pipes a set of kernels uses
+            if kind == B3_KIND:
+                b3[0] += 1; b3[1] += ms; b3[2] += fl
+                ex = 6.0 * fl * PEAK_F32_MFMA_TFLOPS / PEAK_BF16_MFMA_TFLOPS
             g = groups.setdefault((kind, tile), [0, 0.0, 0.0, 0.0])
             g[0] += 1; g[1] += ms; g[2] += fl; g[3] += ex
             conv_ms += ms; alg += fl; exe += ex; n_conv += 1
@@ -958,9 +970,27 @@ def main():
                            "achieved_algorithmic": round(tf(alg / max(G, 1), step_ms), 2),
                            "frac_algorithmic": round(tf(alg / max(G, 1), step_ms) / PEAK_F32_MFMA_TFLOPS, 4)},
             "by_kernel": [{"kernel": kernel_label(k, t), "launches": g[0], "ms": round(g[1], 4),
-                           "executed_tflops": round(tf(g[3], g[1]), 1), "algorithmic_tflops": round(tf(g[2], g[1]), 1)}
+                           "executed_tflops": round(tf(g[2] * 6.0 if k == B3_KIND else g[3], g[1]), 1),
+                           "pipe": "bf16" if k == B3_KIND else "f32",
+                           "frac_of_pipe_peak": round(tf(g[3], g[1]) / PEAK_F32_MFMA_TFLOPS, 4),
+                           "algorithmic_tflops": round(tf(g[2], g[1]), 1)}
                           for (k, t), g in sorted(groups.items(), key=lambda kv: -kv[1][1])[:6]],
+            # the layers that run as split-bf16 products (conv_b3.h): f32 operands split exactly into three bf16 planes, the six
+            # largest plane products on v_mfma_f32_32x32x16_bf16, f32 accumulate -- error against f64 equal to the f32 MFMA's
+            # (tests/test_gpu_conv.py::test_split_bf16_1x1), priced against the bf16 peak
+            "split_bf16": ({"launches_per_forward": b3[0], "ms_per_forward": round(b3[1], 4),
+                            "f32_equivalent_tflops": round(tf(b3[2], b3[1]), 1),
+                            "bf16_tflops_executed": round(tf(6.0 * b3[2], b3[1]), 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+                            "frac_of_bf16_peak": round(tf(6.0 * b3[2], b3[1]) / PEAK_BF16_MFMA_TFLOPS, 4),
+                            "share_of_algorithmic_flops": round(b3[2] / alg, 4) if alg else None,
+                            "note": "in the aggregate `frac*_executed` fields these launches count with their bf16 FLOPs against "
+                                    "the bf16 peak (as f32-pipe equivalents), the others with their f32 FLOPs against the f32 peak"}
+                           if b3[0] else None),
         }
+        if dk == B3_KIND:      # the dominant kernel itself runs on the bf16 pipe: quote it against that peak
+            roof.update({"achieved": round(tf(6.0 * dg[2], dg[1]), 2), "peak": PEAK_BF16_MFMA_TFLOPS,
+                         "frac": round(tf(6.0 * dg[2], dg[1]) / PEAK_BF16_MFMA_TFLOPS, 4),
+                         "frac_executed": round(tf(6.0 * dg[2], dg[1]) / PEAK_BF16_MFMA_TFLOPS, 4)})
         if dwm > 0:      # config 3: state the HBM side too
             roof["hbm_side"] = {"bound": "hbm", "kernel": " + ".join(sorted(dw_kernels)),
                                 "achieved": round(dwb / (dwm * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
@@ -1137,7 +1167,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": ("f32" if not (roof and roof.get("split_bf16")) else
+                      "f32 (f32 in / f32 out everywhere; 3x3, stem and head convolutions on the f32 MFMA; %d of the forward's 1x1 "
+                      "launches as split-bf16 products -- three bf16 planes per f32 operand, six plane products, f32 accumulate: "
+                      "the f32 MFMA's error against f64)" % roof["split_bf16"]["launches_per_forward"]),
             "data": "synthetic",
             "config": {"workload": "PyramidBox-%s %dx%d synthetic u8 frames%s, %s, decode+NMS+IoU-tracker "
                                    "on device" % ("Res50" if args.arch == "res50" else "MobileNetV2-try3", W, H,

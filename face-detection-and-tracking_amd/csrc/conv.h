@@ -30,6 +30,8 @@ enum ConvKind {
   CONV_7x7_S2_U8,      // CONV_7x7_S2 / _S4 reading the raw uint8 HWC BGR frame: the (float)u8 - mean (/ scale) of the ingest
   CONV_7x7_S4_U8,      // happens in the conv's own staging (conv_stem_u8.h / conv_stem_s4.h); ConvArgs.in_u8 instead of ConvArgs.in
   CONV_7x7_S4_K168,    // CONV_7x7_S4 for Cin = 3 (f32 NCHW input) as 3 x 7 x 8 k-columns instead of 4 x 49, three workgroups per CU (conv_stem_s4.h)
+  CONV_1x1_S1_B3,      // CONV_1x1_S1 with split-bf16 products on v_mfma_f32_32x32x16_bf16 (three bf16 planes per operand, six plane
+                       // products, f32 accumulate: conv_b3.h).  Same tolerance as the f32 classes, not the same bits.
   CONV_KIND_COUNT
 };
 

@@ -1,0 +1,326 @@
+// conv_b3.h -- 1x1 / stride-1 convolution with SPLIT-bf16 products on the bf16 matrix pipe (class CONV_1x1_S1_B3, round 5).
+//
+// Why.  v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate (64 FLOP/clk/SIMD); v_mfma_f32_32x32x16_bf16
+// does 16x the work per cycle.  An f32 value is EXACTLY the sum of three bf16 values x = x0 + x1 + x2 (8 + 8 + 8 significant
+// bits, each the round-to-nearest bf16 of the remainder), so a product x*y is the sum of nine plane products, and the six
+// largest -- x0y0, x0y1, x1y0, x0y2, x2y0, x1y1 -- leave out terms of at most 3 * 2^-24 relative: the size of ONE f32
+// rounding.  Each plane product is exact in the bf16 MFMA (8 x 8 significant bits) and is accumulated in f32 like the f32
+// MFMA accumulates.  Measured (tools/microbench/bf16x3_mfma.hip, docs/EXPERIMENTS.md R5-4): a [32 x 1024] x [1024 x 32] product
+// has 5.5e-7 relative RMS error against f64 in this form, 6.3e-7 with the f32 MFMA; six bf16 MFMAs (192 cycles) replace eight
+// f32 MFMAs (512 cycles) per 16 input channels.  The result is NOT bit-identical to the f32 classes (another summation order
+// inside the instruction); it passes the same tolerances (tests/test_gpu_conv.py: test_split_bf16_1x1*, the stage and end-to-end
+// tests with the plans that use it).
+//
+// How.  GEMM view and tile shapes of conv_kernel.h (weights = A operand, 128-pixel tile = B operand, four waves, LDS ring by
+// LDS-DMA with counted vmcnt), one stage = 16 input channels = ONE bf16 MFMA k-step:
+//   * weights are split into their three planes on the HOST (tile_weights) and stored per stage as
+//     [plane][k-half][BN couts][8 k] bf16 -- a lane's A operand of a plane is one ds_read_b128;
+//   * the activations arrive as f32 [16 channels][128 pixels] exactly like in the f32 class; a lane reads the eight channels
+//     of its pixel (8 x ds_read_b32), splits them in registers (v_cvt_pk_bf16_f32 + two subtractions per value) -- vector-ALU
+//     work that CO-EXECUTES with the bf16 MFMAs of the SIMD's other waves (SQ_VALU_MFMA_COEXEC_CYCLES = 50 % of the busy
+//     cycles in the microbenchmark; it is 0 for f32 MFMAs, R4-4) -- and feeds three B planes;
+//   * per (cout tile, pixel tile): six MFMAs, smallest plane products first;
+//   * epilogue: the f32 class's (bias, fused bilinear x2 upsample-add, residual, ReLU / ReLU6, second destination, split-K slabs).
+// Needs Win % 4 == 0 (16-byte activation staging).  Channels past Cin read as zeros (buffer bounds), weights are zero there.
+#pragma once
+#include "conv_kernel.h"
+
+namespace fdt {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <class T>
+struct LayoutB3 {
+  static constexpr int KC = 16;
+  static constexpr int XSZ = KC * T::BM;                       // floats: [16][BM]
+  static constexpr int NXV = XSZ / 1024;                       // dwordx4 LDS-DMA instructions per wave and stage
+  static constexpr int WSZ = 24 * T::BN;                       // floats holding [3][2][BN][8] bf16
+  static constexpr int WSZP = (WSZ + 1023) / 1024 * 1024;
+  static constexpr int NW = WSZP / 1024;
+  static constexpr int STAGE = XSZ + WSZP;
+  static constexpr int LOADS = NXV + NW;
+  static constexpr int EROW = T::BM + 4;
+  static constexpr int EPI = T::WN * 32 * EROW;
+  static constexpr int RING = T::NBUF * STAGE;
+  static constexpr size_t LDS_BYTES = (size_t)(RING > EPI ? RING : EPI) * sizeof(float);
+  static_assert(XSZ % 1024 == 0, "whole dwordx4 LDS-DMA rounds");
+  static_assert(T::NBUF == 3, "ring of three stages");
+};
+
+// x = p0 + p1 + p2 exactly (each conversion rounds to nearest even; the remainders are exact in f32)
+__device__ __forceinline__ void split3_bf16(float x, __bf16& p0, __bf16& p1, __bf16& p2) {
+  p0 = (__bf16)x;
+  const float r1 = x - (float)p0;
+  p1 = (__bf16)r1;
+  const float r2 = r1 - (float)p1;
+  p2 = (__bf16)r2;
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(bf16x8& v, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+
+template <class T>
+__global__ __launch_bounds__(256, (T::MI * T::NI >= 4) ? 2 : 3) void conv_b3_kernel(const ConvArgs a) {
+  using L = LayoutB3<T>;
+  using G = Geom<1, 1, 1, 1, 0, 16>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / T::WN, wn = wave % T::WN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int tiles_x = (a.Wout + T::TW - 1) / T::TW;
+  FDT_BLOCK_MAP(a, tile_id, n_tile);
+  const int oy0 = (tile_id / tiles_x) * T::TH;
+  const int ox0 = (tile_id % tiles_x) * T::TW;
+  const int b = blockIdx.z / a.ksplit;
+  const int ks = blockIdx.z - b * a.ksplit;
+
+  const int HWin = a.Hin * a.Win;
+  const int HWout = a.Hout * a.Wout;
+  const float* in_b = a.in + (long long)b * conv_in_bstride(a);
+  const int nstages = (a.Cin + L::KC - 1) / L::KC;
+  const float* w_t = a.w + (long long)n_tile * nstages * L::WSZP;
+  const int s_begin = (int)((long long)nstages * ks / a.ksplit);
+  const int s_end = (int)((long long)nstages * (ks + 1) / a.ksplit);
+
+  // staging plan: float4 v = 256 * k + tid covers 4 consecutive pixels of one tile row of one channel of the stage
+  const __amdgpu_buffer_rsrc_t xrs = buf_rsrc(in_b, (long long)a.Cin * HWin * 4);
+  const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(w_t, 0x7fffffffll);
+  unsigned xoff[L::NXV];
+#pragma unroll
+  for (int k = 0; k < L::NXV; ++k) {
+    const int v = tid + 256 * k;
+    const int c = v / (T::BM / 4);
+    const int p = (v - c * (T::BM / 4)) * 4;
+    const int gy = oy0 + p / T::TW, gx = ox0 + p % T::TW;
+    const bool ok = gy < a.Hin && gx < a.Win;
+    xoff[k] = ok ? (unsigned)(c * HWin + gy * a.Win + gx) * 4u : kOob;
+  }
+#define FDT_B3_STAGE(s_, buf_)                                                                            \
+  {                                                                                                       \
+    const unsigned xso_ = (unsigned)((s_) * L::KC) * (unsigned)HWin * 4u;                                 \
+    float* X_ = smem + (buf_) * L::STAGE + wave * 256;                                                    \
+    _Pragma("unroll") for (int k = 0; k < L::NXV; ++k) bglds16(xrs, X_ + 1024 * k, xoff[k], xso_);        \
+    const unsigned wso_ = (unsigned)((s_) * L::WSZP) * 4u;                                                \
+    float* W_ = smem + (buf_) * L::STAGE + L::XSZ + wave * 256;                                           \
+    _Pragma("unroll") for (int k = 0; k < L::NW; ++k) bglds16(wrs, W_ + 1024 * k, (unsigned)tid * 16u, wso_ + 4096u * k); \
+  }
+
+  // per-lane LDS read byte offsets inside a stage
+  unsigned xo[T::MI], wo[T::NI];
+#pragma unroll
+  for (int i = 0; i < T::MI; ++i) xo[i] = (unsigned)((half * 8) * T::BM + wm * (T::MI * 32) + i * 32 + l31) * 4u;
+#pragma unroll
+  for (int j = 0; j < T::NI; ++j) wo[j] = (unsigned)L::XSZ * 4u + (unsigned)(half * T::BN + wn * (T::NI * 32) + j * 32 + l31) * 16u;
+
+  f32x16 acc[T::NI][T::MI];
+#pragma unroll
+  for (int j = 0; j < T::NI; ++j)
+#pragma unroll
+    for (int i = 0; i < T::MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
+
+  const int nst = s_end - s_begin;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+
+  // One stage's operands of this wave: A planes straight from LDS, the eight f32 channels of the lane's pixels
+  struct Ops {
+    bf16x8 A[T::NI][3];
+    float xv[T::MI][8];
+    bf16x8 Bp[T::MI][3];
+  };
+  auto issue_reads = [&](Ops& o, int buf) {
+    const unsigned sb = lds0 + (unsigned)(buf * L::STAGE) * 4u;
+#pragma unroll
+    for (int j = 0; j < T::NI; ++j) {
+      const unsigned ad = sb + wo[j];      // [plane][half][BN][8 k] bf16: plane stride 2 * BN * 16 bytes
+      lds_read_b128<0>(o.A[j][0], ad);
+      lds_read_b128<2 * T::BN * 16>(o.A[j][1], ad);
+      lds_read_b128<4 * T::BN * 16>(o.A[j][2], ad);
+    }
+#pragma unroll
+    for (int i = 0; i < T::MI; ++i) {
+      const unsigned ad = sb + xo[i];      // channel k = 8 * half + q of this lane's pixel
+      lds_read_b32<0 * T::BM * 4>(o.xv[i][0], ad);
+      lds_read_b32<1 * T::BM * 4>(o.xv[i][1], ad);
+      lds_read_b32<2 * T::BM * 4>(o.xv[i][2], ad);
+      lds_read_b32<3 * T::BM * 4>(o.xv[i][3], ad);
+      lds_read_b32<4 * T::BM * 4>(o.xv[i][4], ad);
+      lds_read_b32<5 * T::BM * 4>(o.xv[i][5], ad);
+      lds_read_b32<6 * T::BM * 4>(o.xv[i][6], ad);
+      lds_read_b32<7 * T::BM * 4>(o.xv[i][7], ad);
+    }
+  };
+  auto wait_reads = [&](Ops& o) {          // every read issued so far has landed (the asm ties the registers to the wait)
+#pragma unroll
+    for (int i = 0; i < T::MI; ++i)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(o.xv[i][0]), "+v"(o.xv[i][1]), "+v"(o.xv[i][2]), "+v"(o.xv[i][3]), "+v"(o.xv[i][4]), "+v"(o.xv[i][5]),
+                     "+v"(o.xv[i][6]), "+v"(o.xv[i][7]));
+#pragma unroll
+    for (int j = 0; j < T::NI; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.A[j][0]), "+v"(o.A[j][1]), "+v"(o.A[j][2]));
+  };
+  auto split_one = [&](Ops& o, int i, int q) {
+    __bf16 p0, p1, p2;
+    split3_bf16(o.xv[i][q], p0, p1, p2);
+    o.Bp[i][0][q] = p0;
+    o.Bp[i][1][q] = p1;
+    o.Bp[i][2][q] = p2;
+  };
+  // The six plane products of every (cout tile, pixel tile) of stage `c`, smallest first (a-plane, b-plane): 11 20 02 10 01 00;
+  // the reads of stage `n` were issued in front of this call: they are waited for after the first third of the MFMAs and the
+  // f32 -> 3 x bf16 split of `n` is spread over the rest -- vector-ALU work in the shadow of this wave's own bf16 MFMAs.
+  auto mfmas = [&](Ops& c, Ops& n, bool have_next) {
+    constexpr int pa[6] = {1, 2, 0, 1, 0, 0}, pb[6] = {1, 0, 2, 0, 1, 0};
+    constexpr int NM = T::NI * T::MI * 6, NS = T::MI * 8;
+    constexpr int FIRST = NM / 3;                          // MFMAs in front of the wait
+    constexpr int PER = (NS + (NM - FIRST) - 1) / (NM - FIRST);   // values split per MFMA behind it
+    static_for<0, NM>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int t = m / 6, p = m % 6, j = t / T::MI, i = t % T::MI;
+      acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.A[j][pa[p]], c.Bp[i][pb[p]], acc[j][i], 0, 0, 0);
+      if constexpr (m + 1 >= FIRST) {
+        if (have_next) {
+          if constexpr (m + 1 == FIRST) wait_reads(n);
+          static_for<0, PER>([&](auto ec) {
+            constexpr int idx = (m + 1 - FIRST) * PER + decltype(ec)::value;      // compile-time: no dynamic register indexing
+            if constexpr (idx < NS) split_one(n, idx / 8, idx % 8);
+          });
+        }
+      }
+    });
+  };
+
+  // ring: buffer of stage s = s % 3.  Prologue: stages 0 and 1 requested, stage 0 waited for, read and split.
+#pragma unroll
+  for (int p = 0; p < T::NBUF - 1; ++p)
+    if (p < nst) FDT_B3_STAGE(s_begin + p, p);
+  Ops O[2];
+  if (nst > 0) {
+    if (nst > 1)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::LOADS) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (2 < nst) FDT_B3_STAGE(s_begin + 2, 2);
+    issue_reads(O[0], 0);
+    wait_reads(O[0]);
+#pragma unroll
+    for (int i = 0; i < T::MI; ++i)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) split_one(O[0], i, q);
+  }
+  // steady state, two stages per trip (the operand sets swap roles): at the top of step `it` the operands of stage `it` sit in
+  // registers; stage it + 1 is waited for (stage it + 2 stays in flight), the barrier also says every wave has finished READING
+  // stage it -- so stage it + 3 may be requested into its buffer --, stage it + 1 is read, and the MFMAs of stage `it` run.
+  int buf_next = 1;                                        // buffer of stage it + 1
+  auto step = [&](int it, Ops& c, Ops& n) {
+    const bool have_next = it + 1 < nst;
+    if (have_next) {
+      if (it + 2 < nst)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::LOADS) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (it + 3 < nst) FDT_B3_STAGE(s_begin + it + 3, (buf_next + 2) % 3);
+      issue_reads(n, buf_next);
+    }
+    mfmas(c, n, have_next);
+    buf_next = buf_next == 2 ? 0 : buf_next + 1;
+  };
+  for (int it = 0; it < nst; it += 2) {
+    step(it, O[0], O[1]);
+    if (it + 1 < nst) step(it + 1, O[1], O[0]);
+  }
+#undef FDT_B3_STAGE
+
+  // ---- epilogue: conv_kernel.h's, operation for operation (Wout % 4 == 0 is a precondition of this class) -------------------
+  float* E = smem;
+  float* dst_b;
+  const bool raw = a.ws != nullptr;
+  if (raw)
+    dst_b = a.ws + ((long long)(b * a.ksplit + ks) * a.Cout) * HWout;
+  else
+    dst_b = a.out + ((long long)b * a.out_ctot + a.out_coff) * HWout;
+  const float* res_b = (!raw && a.res) ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWout : nullptr;
+  constexpr int ROWS = T::WN * 32;
+  constexpr int C4 = T::BM / 4;
+  constexpr int PER = (ROWS * C4 + 255) / 256;
+#pragma unroll
+  for (int j = 0; j < T::NI; ++j) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < T::MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        E[row * L::EROW + wm * (T::MI * 32) + i * 32 + l31] = acc[j][i][r];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int idx = tid + 256 * q;
+      if (idx < ROWS * C4) {
+        const int row = idx / C4, c4 = idx - row * C4;
+        const int p = c4 * 4;
+        const int oy = oy0 + p / T::TW, ox = ox0 + p % T::TW;
+        const int co = n_tile * T::BN + (row >> 5) * (T::NI * 32) + j * 32 + (row & 31);
+        if (oy < a.Hout && ox < a.Wout && co < a.Cout) {
+          float4 v = *reinterpret_cast<const float4*>(E + row * L::EROW + p);
+          const long long off = (long long)co * HWout + (long long)oy * a.Wout + ox;
+          if (!raw) {
+            if (a.bias) {
+              const float bv = a.bias[co];
+              v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+            }
+            if (a.up) {   // ContextTexture: + bilinear x2 of the coarser map, before the residual like the reduce pass
+              float u4[4] = {v.x, v.y, v.z, v.w};
+              add_upsampled_x2<4>(a.up + ((long long)b * a.Cout + co) * a.up_h * a.up_w, a.up_h, a.up_w, oy, ox, u4);
+              v = make_float4(u4[0], u4[1], u4[2], u4[3]);
+            }
+            if (res_b) {
+              const float4 rv = *reinterpret_cast<const float4*>(res_b + off);
+              v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
+            if (a.act == ACT_RELU) {
+              v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            } else if (a.act == ACT_RELU6) {
+              v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
+              v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+            }
+          }
+          float* dst = dst_b + off;
+          if (a.out2 && co >= a.out2_from)
+            dst = a.out2 + ((long long)b * a.out2_ctot + a.out2_coff + (co - a.out2_from)) * HWout + (long long)oy * a.Wout + ox;
+          slab_store4(dst, v.x, v.y, v.z, v.w, raw && a.sk_count);
+        }
+      }
+    }
+  }
+  if (a.sk_count)
+    splitk_combine_tile<256>(a, b, tile_id + a.n_sp * n_tile, n_tile * T::BN, T::BN, oy0, ox0, T::TH, T::TW, (unsigned*)smem);
+}
+
+using TB3_128x128 = Tile<8, 16, 128, 2, 2, 3>;
+using TB3_128x64 = Tile<8, 16, 64, 2, 2, 3>;
+using TB3_128x128W = Tile<4, 32, 128, 2, 2, 3>;
+using TB3_128x64W = Tile<4, 32, 64, 2, 2, 3>;
+
+template <class T>
+KernelEntry entry_b3() {
+  return KernelEntry{conv_b3_kernel<T>, LayoutB3<T>::LDS_BYTES, 256};
+}
+
+}  // namespace
+}  // namespace fdt

@@ -521,7 +521,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_kernel(const ConvArgs a) {
       for (int k = 0; k < 4; ++k) E[(r * 4 + k) * 64 + lane] = yp[r][k];
   }
   __syncthreads();
-  if (th) return;
+  // The waves of the second half have handed their part over.  Without an in-kernel combine they are done; with one they stay:
+  // splitk_combine_tile<512> strides its elements over all 512 threads of the workgroup (round 5: they used to return here, and
+  // the last-arriving workgroup then finished only every other 256-element run of its tile -- unnoticed while the parity test's
+  // output buffer happened to be reallocated over the two-pass result it is compared with)
+  if (th && !wt) return;
+  if (!th)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int co = n_tile * T::BN + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;

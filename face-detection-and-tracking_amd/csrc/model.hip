@@ -473,7 +473,8 @@ struct Builder {
     if (hint != m->hints.end() && m->hB == B && m->hH == m->tensors[0].H && m->hW == m->tensors[0].W &&
         conv_base_kind((ConvKind)hint->second.kind) == kind &&
         (o.out2_t < 0 || ((ConvKind)hint->second.kind == kind || (ConvKind)hint->second.kind == CONV_1x1_S1_K32 ||
-                          (ConvKind)hint->second.kind == CONV_1x1_S1_K64)) &&
+                          (ConvKind)hint->second.kind == CONV_1x1_S1_K64 || (ConvKind)hint->second.kind == CONV_1x1_S1_B3)) &&
+        ((ConvKind)hint->second.kind != CONV_1x1_S1_B3 || (in.W & 3) == 0) &&
         conv_supported((ConvKind)hint->second.kind, (ConvTile)hint->second.tile) &&
         // the persistent 1x1 class has shape limits of its own (conv.hip: conv_shape_supported); a plan entry that does not
         // fit this layer is ignored like one for another shape

@@ -411,6 +411,42 @@ def test_persistent_1x1_walks_tiles(variant, shape):
     assert rc == 0 and rel_err(got, reference(x, w, None, 1, 1, 0, 1)) < 1e-5
 
 
+@pytest.mark.parametrize("tile", [7, 8, 11, 12])          # the ring-of-three tiles of class 21 (conv.h: CONV_1x1_S1_B3, conv_b3.h)
+@pytest.mark.parametrize("shape", [(1, 64, 64, 64, 256), (2, 40, 36, 48, 72), (1, 19, 27, 36, 45), (1, 1024, 32, 32, 256)])
+def test_split_bf16_1x1(tile, shape):
+    """conv_b3.h: 1x1 convolution as split-bf16 products on v_mfma_f32_32x32x16_bf16 (three bf16 planes per operand, six plane
+    products, f32 accumulate).  Same tolerance against torch's f32 convolution as the f32-MFMA classes (1e-5 of the output's
+    maximum), with bias / residual / fused bilinear upsample-add / ReLU6, split-K, channels past Cin (Cin % 16 != 0), couts past
+    Cout -- and an error against an f64 convolution that is no larger than the f32 class's (x1.5 + 1e-7 slack)."""
+    B, Cin, H, W, Cout = shape
+    rng = np.random.default_rng(tile * 1000 + Cin)
+    x = np.maximum(rng.standard_normal((B, Cin, H, W)), 0).astype(np.float32) * np.exp(rng.standard_normal((B, Cin, 1, 1))).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((B, Cout, H, W)).astype(np.float32)
+    up = rng.standard_normal((B, Cout, (H + 1) // 2, (W + 1) // 2)).astype(np.float32)
+    v = 21 * 100 + tile
+    for kw in (dict(res=res, act=1), dict(act=0), dict(up=up, act=2)):
+        exp = reference(x, w, b, 1, 1, 0, 1, **kw)
+        for split in (1, 2):
+            if split > (Cin + 15) // 16:
+                continue
+            rc, got = run_conv(x, w, b, 1, 1, 0, 1, tile=v, split=split, **kw)
+            assert rc == 0, lib().lib().fdt_last_error()
+            assert rel_err(got, exp) < 1e-5, (tile, shape, list(kw), split, rel_err(got, exp))
+    # against f64: not worse than the f32-MFMA class on the same data
+    ref64 = np.einsum("oc,bchw->bohw", w[:, :, 0, 0].astype(np.float64), x.astype(np.float64)) + b[None, :, None, None]
+    rc, got = run_conv(x, w, b, 1, 1, 0, 1, tile=v)
+    rc2, f32 = run_conv(x, w, b, 1, 1, 0, 1, tile=6)
+    assert rc == 0 and rc2 == 0
+    e_b3 = float(np.sqrt(((got - ref64) ** 2).mean()) / np.sqrt((ref64 ** 2).mean()))
+    e_f32 = float(np.sqrt(((f32 - ref64) ** 2).mean()) / np.sqrt((ref64 ** 2).mean()))
+    print("split-bf16 vs f64: %.3e   f32 MFMA vs f64: %.3e   (tile %d, %s)" % (e_b3, e_f32, tile, shape))
+    assert e_b3 <= 1.5 * e_f32 + 1e-7, (e_b3, e_f32)
+    rc, _ = run_conv(x[:, :, :, :W - 1].copy(), w, b, 1, 1, 0, 1, tile=v)     # Win % 4 != 0: not this class
+    assert rc != 0
+
+
 def test_persistent_1x1_refuses_what_it_is_not_built_for():
     rng = np.random.default_rng(5)
     x = rng.standard_normal((1, 40, 20, 30)).astype(np.float32)           # W % 4 != 0
