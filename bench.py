@@ -181,6 +181,21 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
     dom = max(rows, key=lambda r: r[1])
     step_ms = dt / args.steps * 1e3
     gbs = lambda by, ms: by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    def mfma_row(r):
+        """conv1 / conv2 priced as matrix work on the pipe they run on.  conv1 pads K = 147 to 168 (class 20 / 19), 196 (class 6) or
+        176 (class 22: split-bf16, six bf16 MFMA FLOPs per padded f32 FLOP, against the bf16 peak) and N = 24 to 32; conv2 pads nothing."""
+        op = r[0].split("#")[0]
+        b3 = "#k22t" in r[0] or "#k21t" in r[0]
+        pad = 1.0
+        if op == "conv1":
+            pad = (196.0 if "#k6t" in r[0] else 176.0 if "#k22t" in r[0] else 168.0) / 147.0 * 32.0 / 24.0
+        alg = r[3] / (r[1] * 1e-3) / 1e12
+        ex = alg * pad * (6.0 if b3 else 1.0)
+        peak = PEAK_BF16_MFMA_TFLOPS if b3 else PEAK_F32_MFMA_TFLOPS
+        return {"op": op, "ms": round(r[1], 4), "algorithmic_tflops": round(alg, 1), "executed_tflops": round(ex, 1),
+                "pipe": "bf16 (split-bf16 products: 6 plane products per f32 product)" if b3 else "f32", "peak": peak,
+                "frac": round(ex / peak, 4)}
+
     roof = {"bound": "hbm", "kernel": dom[0] + (" (resize_preprocess_kernel: cv2.resize + /255 fused)" if dom[0] == "ingest" else ""),
             "achieved": round(gbs(dom[2], dom[1]), 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(gbs(dom[2], dom[1]) / 8000.0, 4), "traffic": None,
@@ -204,13 +219,7 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
             # 20 / 19) pads K = 3 x 49 = 147 to 3 x 7 x 8 = 168 and N = 24 to 32 output channels (the generic class 6: K = 196);
             # conv2 (48 -> 64, 5x5) pads nothing
             "mfma_side": {"bound": "mfma", "peak": 157.3, "unit": "TFLOP/s",
-                          "kernels": [{"op": r[0].split("#")[0], "ms": round(r[1], 4),
-                                       "algorithmic_tflops": round(r[3] / (r[1] * 1e-3) / 1e12, 1),
-                                       "executed_tflops": round(r[3] * pad / (r[1] * 1e-3) / 1e12, 1),
-                                       "frac": round(r[3] * pad / (r[1] * 1e-3) / 1e12 / 157.3, 4)}
-                                      for r in rows for nm0, pad in (("conv1", (196.0 if "#k6t" in r[0] else 168.0) / 147.0 * 32.0 / 24.0),
-                                                                     ("conv2", 1.0))
-                                      if r[0].split("#")[0] == nm0 and r[1] > 0]},
+                          "kernels": [mfma_row(r) for r in rows if r[0].split("#")[0] in ("conv1", "conv2") and r[1] > 0]},
             "note": "bytes = un-fused algorithmic lower bound (each op reads its inputs and writes its output once, f32; "
                     "weights once).  The whole net is 1.87 GFLOP and 77 MB per frame over 40 launches: launch-latency bound, "
                     "which is why several batches are kept in flight; conv1 (3 -> 24 channels, K = 147 padded to 168, N = 24 "
@@ -288,7 +297,7 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
 
 
 KIND_NAMES = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2", "3x3s1_wino", "3x3d2_wino", "1x1s1_k32",
-              "1x1s1_k64", "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44", "1x1s1_p16", "1x1s1_p32", "7x7s2_u8", "7x7s4_u8", "7x7s4_k168", "1x1s1_b3"]
+              "1x1s1_k64", "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44", "1x1s1_p16", "1x1s1_p32", "7x7s2_u8", "7x7s4_u8", "7x7s4_k168", "1x1s1_b3", "7x7s4_b3"]
 WINO_KINDS = (8, 9, 14, 15)   # conv.h: Winograd kinds execute fewer MACs than the direct form:
 WINO_RATIO = {8: 2.25, 9: 2.25, 14: 4.0, 15: 4.0}   # F(2x2,3x3) 16/36 of them, F(4x4,3x3) (CONV_3x3_{S1,D2}_WINO44) 36/144
 
@@ -319,6 +328,8 @@ def kernel_label(kind, tile):
         return "%s<%s, tile %d>" % (k, KIND_NAMES[kind], tile)
     if kind == 13:            # conv.h: CONV_3x3_S1_N8, the vector-ALU kernel of the narrow heads (conv_n8.h)
         return "conv_n8_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
+    if kind == 22:            # conv.h: CONV_7x7_S4_B3, FaceBoxes' stem as split-bf16 products (conv_stem_b3.h)
+        return "conv_stem_s4_b3_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
     if kind in (19, 20):      # conv.h: CONV_7x7_S4_U8 / _K168, the stride-4 stem of FaceBoxes (conv_stem_s4.h)
         return "conv_stem_s4_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
     if kind == 18:            # conv.h: CONV_7x7_S2_U8, the stem conv on the raw uint8 frame (conv_stem_u8.h)

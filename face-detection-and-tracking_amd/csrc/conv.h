@@ -32,6 +32,7 @@ enum ConvKind {
   CONV_7x7_S4_K168,    // CONV_7x7_S4 for Cin = 3 (f32 NCHW input) as 3 x 7 x 8 k-columns instead of 4 x 49, three workgroups per CU (conv_stem_s4.h)
   CONV_1x1_S1_B3,      // CONV_1x1_S1 with split-bf16 products on v_mfma_f32_32x32x16_bf16 (three bf16 planes per operand, six plane
                        // products, f32 accumulate: conv_b3.h).  Same tolerance as the f32 classes, not the same bits.
+  CONV_7x7_S4_B3,      // CONV_7x7_S4 for Cin = 3 with split-bf16 products (conv_stem_b3.h): FaceBoxes' conv1 on the bf16 matrix pipe
   CONV_KIND_COUNT
 };
 

@@ -188,6 +188,7 @@ struct Table {
     conv_fill_stem_u8(e[CONV_7x7_S2_U8]);
     conv_fill_stem_s4(e[CONV_7x7_S4_K168], e[CONV_7x7_S4_U8]);
     conv_fill_1x1_b3(e[CONV_1x1_S1_B3]);
+    conv_fill_stem_b3(e[CONV_7x7_S4_B3]);
   }
 };
 
@@ -202,7 +203,7 @@ const ConvGeom kGeoms[CONV_KIND_COUNT] = {
     {3, 3, 1, 1, 1, 8, 1},  {3, 3, 1, 2, 2, 8, 1},  {1, 1, 1, 1, 0, 32, 0},  {1, 1, 1, 1, 0, 64, 0},
     {7, 7, 2, 1, 1, 2, 0},  {3, 3, 1, 1, 1, 1, 0},  {3, 3, 1, 1, 1, 2, 2},  {3, 3, 1, 2, 2, 2, 2},
     {1, 1, 1, 1, 0, 16, 0}, {1, 1, 1, 1, 0, 32, 0}, {7, 7, 2, 1, 3, 4, 0},  {7, 7, 4, 1, 3, 3, 0},
-    {7, 7, 4, 1, 3, 3, 0},  {1, 1, 1, 1, 0, 16, 0},
+    {7, 7, 4, 1, 3, 3, 0},  {1, 1, 1, 1, 0, 16, 0}, {7, 7, 4, 1, 3, 3, 0},
 };
 const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum ConvTile)
     {128, 128, 8, 16}, {128, 64, 8, 16}, {128, 32, 8, 16}, {64, 64, 8, 8},   {64, 128, 8, 8},
@@ -243,7 +244,8 @@ ConvKind conv_base_kind(ConvKind k) {
     case CONV_1x1_S1_B3: return CONV_1x1_S1;
     case CONV_7x7_S2_U8: return CONV_7x7_S2;
     case CONV_7x7_S4_U8:
-    case CONV_7x7_S4_K168: return CONV_7x7_S4;
+    case CONV_7x7_S4_K168:
+    case CONV_7x7_S4_B3: return CONV_7x7_S4;
     default: return k;
   }
 }
@@ -286,6 +288,38 @@ void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKin
         for (int t = 0; t < 49; ++t)
           out[(((size_t)(co / 32) * 3 + ci) * 7 + t / 7) * 256 + (size_t)(t % 7 + 1) * 32 + co % 32] =
               w[((size_t)co * 3 + ci) * 49 + t] * (scale ? scale[co] : 1.0f);
+    return;
+  }
+  if (kind == CONV_7x7_S4_B3) {
+    // conv_stem_b3.h: per channel tile [plane][k-step s][k-half h][32 couts][8 columns = taps -1 .. 6] bf16, pair q = 2 s + h =
+    // (channel q / 7, tap row q % 7); pair 21 and the first column are zero (StemB3::WSZ = 8448 floats per tile)
+    out.assign((size_t)n_tiles * 8448, 0.0f);
+    if (Cin != 3 || BN != 32) return;
+    unsigned short* o16 = reinterpret_cast<unsigned short*>(out.data());
+    auto bf16_rne = [](float x) -> unsigned short {
+      unsigned u;
+      memcpy(&u, &x, 4);
+      u += 0x7fffu + ((u >> 16) & 1u);
+      return (unsigned short)(u >> 16);
+    };
+    auto bf16_f32 = [](unsigned short h) -> float {
+      const unsigned u = (unsigned)h << 16;
+      float f;
+      memcpy(&f, &u, 4);
+      return f;
+    };
+    for (int co = 0; co < Cout; ++co)
+      for (int q = 0; q < 21; ++q)
+        for (int kx = 0; kx < 7; ++kx) {
+          const float wv = w[((size_t)co * 3 + q / 7) * 49 + (q % 7) * 7 + kx] * (scale ? scale[co] : 1.0f);
+          const unsigned short p0 = bf16_rne(wv);
+          const float r1 = wv - bf16_f32(p0);
+          const unsigned short p1 = bf16_rne(r1);
+          const unsigned short p2 = bf16_rne(r1 - bf16_f32(p1));
+          const unsigned short pl[3] = {p0, p1, p2};
+          for (int pp = 0; pp < 3; ++pp)
+            o16[(size_t)(co / 32) * 16896 + ((((size_t)pp * 11 + q / 2) * 2 + q % 2) * 32 + co % 32) * 8 + kx + 1] = pl[pp];
+        }
     return;
   }
   if (kind == CONV_1x1_S1_B3) {
@@ -430,6 +464,9 @@ bool conv_shape_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
     return a.in_u8 != nullptr && a.Cin == 3 && a.ksplit <= 1 && !a.ws && !a.res && !a.up && !a.sk_count &&
            (long long)(a.Cout + 64) * a.Hout * a.Wout * 4 < (1ll << 31);
   if (a.in_u8) return false;   // every other class reads f32 NCHW
+  if (kind == CONV_7x7_S4_B3)      // f32 NCHW frames, 16-byte pieces only
+    return a.Cin == 3 && (a.Win & 3) == 0 && a.ksplit <= 1 && !a.ws && !a.res && !a.up && !a.sk_count && !a.out2 && !a.in_bstride &&
+           (long long)3 * a.Hin * a.Win * 4 < (1ll << 31) && (long long)(a.Cout + 64) * a.Hout * a.Wout * 4 < (1ll << 31);
   if (kind == CONV_7x7_S4_K168)
     return a.Cin == 3 && a.ksplit <= 1 && !a.ws && !a.res && !a.up && !a.sk_count && (long long)3 * a.Hin * a.Win * 4 < (1ll << 31) &&
            (long long)(a.Cout + 64) * a.Hout * a.Wout * 4 < (1ll << 31);
@@ -530,11 +567,12 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
     FDT_LAUNCH_CHECK();
     return FDT_OK;
   }
-  if (kind == CONV_7x7_S4_K168 || kind == CONV_7x7_S4_U8) {
-    // conv_stem_s4.h: persistent over the (image, spatial tile) pairs, three workgroups per CU; grid.y = channel tile
+  if (kind == CONV_7x7_S4_K168 || kind == CONV_7x7_S4_U8 || kind == CONV_7x7_S4_B3) {
+    // conv_stem_s4.h / conv_stem_b3.h: persistent over the (image, spatial tile) pairs, three (split-bf16: two) workgroups per
+    // CU; grid.y = channel tile
     const long long total = (long long)a.B * tiles;
     FDT_REQUIRE(total <= 0x7fffffffll && n_ct <= 65535, FDT_ERR_ARG, "launch_conv: grid too large");
-    const int k = (int)ceil_div_ll(total, (long long)device_cus(dev) * 3);
+    const int k = (int)ceil_div_ll(total, (long long)device_cus(dev) * (kind == CONV_7x7_S4_B3 ? 2 : 3));
     a.tiles_per_wg = k;
     hipLaunchKernelGGL(ke.fn, dim3((unsigned)ceil_div_ll(total, k), (unsigned)n_ct), dim3(ke.threads), ke.lds, st, a);
     FDT_LAUNCH_CHECK();

@@ -58,6 +58,28 @@ __device__ __forceinline__ void split3_bf16(float x, __bf16& p0, __bf16& p1, __b
   p2 = (__bf16)r2;
 }
 
+// The same split on a PAIR of values, with the packed instructions (v_cvt_pk_bf16_f32, v_pk_add_f32): nine vector-ALU operations
+// per pair where the compiler's own code for two scalar splits takes thirteen.  P0 / P1 / P2: the pair's three planes as packed
+// bf16 pairs (low half = x.x).
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(f32x2v x) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2v));
+}
+__device__ __forceinline__ f32x2v unpack_bf16_pair(unsigned p) {
+  f32x2v f;
+  f.x = __builtin_bit_cast(float, p << 16);
+  f.y = __builtin_bit_cast(float, p & 0xffff0000u);
+  return f;
+}
+__device__ __forceinline__ void split3_bf16_pair(f32x2v x, unsigned& P0, unsigned& P1, unsigned& P2) {
+  P0 = cvt_pk_bf16(x);
+  const f32x2v r1 = x - unpack_bf16_pair(P0);
+  P1 = cvt_pk_bf16(r1);
+  const f32x2v r2 = r1 - unpack_bf16_pair(P1);
+  P2 = cvt_pk_bf16(r2);
+}
+
 template <int OFF>
 __device__ __forceinline__ void lds_read_b128(bf16x8& v, unsigned addr) {
   static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
@@ -169,19 +191,23 @@ __global__ __launch_bounds__(256, (T::MI * T::NI >= 4) ? 2 : 3) void conv_b3_ker
 #pragma unroll
     for (int j = 0; j < T::NI; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.A[j][0]), "+v"(o.A[j][1]), "+v"(o.A[j][2]));
   };
-  auto split_one = [&](Ops& o, int i, int q) {
-    __bf16 p0, p1, p2;
-    split3_bf16(o.xv[i][q], p0, p1, p2);
-    o.Bp[i][0][q] = p0;
-    o.Bp[i][1][q] = p1;
-    o.Bp[i][2][q] = p2;
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+  auto split_pair = [&](Ops& o, int i, int qp) {       // channels 2 qp, 2 qp + 1 of pixel tile i
+    unsigned P0, P1, P2;
+    split3_bf16_pair((f32x2v){o.xv[i][2 * qp], o.xv[i][2 * qp + 1]}, P0, P1, P2);
+    u32x4v b0 = __builtin_bit_cast(u32x4v, o.Bp[i][0]), b1 = __builtin_bit_cast(u32x4v, o.Bp[i][1]),
+           b2 = __builtin_bit_cast(u32x4v, o.Bp[i][2]);
+    b0[qp] = P0; b1[qp] = P1; b2[qp] = P2;
+    o.Bp[i][0] = __builtin_bit_cast(bf16x8, b0);
+    o.Bp[i][1] = __builtin_bit_cast(bf16x8, b1);
+    o.Bp[i][2] = __builtin_bit_cast(bf16x8, b2);
   };
   // The six plane products of every (cout tile, pixel tile) of stage `c`, smallest first (a-plane, b-plane): 11 20 02 10 01 00;
   // the reads of stage `n` were issued in front of this call: they are waited for after the first third of the MFMAs and the
   // f32 -> 3 x bf16 split of `n` is spread over the rest -- vector-ALU work in the shadow of this wave's own bf16 MFMAs.
   auto mfmas = [&](Ops& c, Ops& n, bool have_next) {
     constexpr int pa[6] = {1, 2, 0, 1, 0, 0}, pb[6] = {1, 0, 2, 0, 1, 0};
-    constexpr int NM = T::NI * T::MI * 6, NS = T::MI * 8;
+    constexpr int NM = T::NI * T::MI * 6, NS = T::MI * 4;      // NS: channel PAIRS to split
     constexpr int FIRST = NM / 3;                          // MFMAs in front of the wait
     constexpr int PER = (NS + (NM - FIRST) - 1) / (NM - FIRST);   // values split per MFMA behind it
     static_for<0, NM>([&](auto mc) {
@@ -193,7 +219,7 @@ __global__ __launch_bounds__(256, (T::MI * T::NI >= 4) ? 2 : 3) void conv_b3_ker
           if constexpr (m + 1 == FIRST) wait_reads(n);
           static_for<0, PER>([&](auto ec) {
             constexpr int idx = (m + 1 - FIRST) * PER + decltype(ec)::value;      // compile-time: no dynamic register indexing
-            if constexpr (idx < NS) split_one(n, idx / 8, idx % 8);
+            if constexpr (idx < NS) split_pair(n, idx / 4, idx % 4);
           });
         }
       }
@@ -218,7 +244,7 @@ __global__ __launch_bounds__(256, (T::MI * T::NI >= 4) ? 2 : 3) void conv_b3_ker
 #pragma unroll
     for (int i = 0; i < T::MI; ++i)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) split_one(O[0], i, q);
+      for (int q = 0; q < 4; ++q) split_pair(O[0], i, q);
   }
   // steady state, two stages per trip (the operand sets swap roles): at the top of step `it` the operands of stage `it` sit in
   // registers; stage it + 1 is waited for (stage it + 2 stays in flight), the barrier also says every wave has finished READING

@@ -1,5 +1,6 @@
 // Split-bf16 1x1 / stride-1 kernels (conv_b3.h): three bf16 planes per operand on v_mfma_f32_32x32x16_bf16.
 #include "conv_b3.h"
+#include "conv_stem_b3.h"
 
 namespace fdt {
 void conv_fill_1x1_b3(void* row) {
@@ -8,5 +9,9 @@ void conv_fill_1x1_b3(void* row) {
   r[TILE_128x64R3] = entry_b3<TB3_128x64>();
   r[TILE_128x128WR3] = entry_b3<TB3_128x128W>();
   r[TILE_128x64WR3] = entry_b3<TB3_128x64W>();
+}
+void conv_fill_stem_b3(void* row) {
+  KernelEntry* r = (KernelEntry*)row;
+  r[TILE_128x32W] = entry_stem_s4_b3();
 }
 }  // namespace fdt

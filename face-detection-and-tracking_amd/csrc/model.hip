@@ -174,6 +174,7 @@ struct fdt_model {
   unsigned long long graph_clock = 0;
   int plan_runs = 0;          // eager forwards since the plan was (re)built; capture starts at the second
   bool use_graph = true;
+  bool stem_b3 = true;        // FaceBoxes' stem as split-bf16 products (conv_stem_b3.h); FDT_STEM_B3=0 at create time: the f32 form
   bool stream_ir = true;      // try3 / try4 / try5: the streaming vector-ALU kernels of stream_ir.hip (FDT_STREAM_IR=0 at create time: off)
   int fb_fuse = 2;            // FaceBoxes' Inception: 0 eight launches per block, 1 the three 1x1 branches on x as one, 2 also conv4 | conv6 (Builder::inception)
   struct Hint { int kind, tile, split, map, combine; };   // combine: in-kernel split-K combine (conv.h) instead of the reduce pass
@@ -497,8 +498,11 @@ struct Builder {
       while (wgs * ksplit < 512 && ksplit * 2 <= std::min(32, in.C / 8)) ksplit *= 2;
     } else if (kind == CONV_7x7_S4 && in.C == 3 && o.groups == 1 && o.res_t < 0 && o.up_t < 0 &&
                conv_supported(CONV_7x7_S4_K168, TILE_128x32W) && stem_s4_enabled()) {
-      // FaceBoxes' stem: K = 3 x 7 x 8 instead of 4 x 49, three workgroups per CU (conv_stem_s4.h)
-      kind = CONV_7x7_S4_K168;
+      // FaceBoxes' stem: K = 3 x 7 x 8 instead of 4 x 49, three workgroups per CU (conv_stem_s4.h); with 16-byte rows the
+      // split-bf16 form of the same k layout on the bf16 matrix pipe (conv_stem_b3.h; FDT_STEM_B3=0: the f32 form)
+      const bool b3_ok = m->stem_b3;
+      kind = (b3_ok && (in.W & 3) == 0 && special == false && conv_supported(CONV_7x7_S4_B3, TILE_128x32W)) ? CONV_7x7_S4_B3
+                                                                                                               : CONV_7x7_S4_K168;
       op.kind = kind;
       op.tile = TILE_128x32W;
     } else {
@@ -2112,6 +2116,7 @@ extern "C" fdt_model* fdt_model_create(int arch, int device) {
   if (const char* g = getenv("FDT_GRAPH")) m->use_graph = atoi(g) != 0;
   if (const char* g = getenv("FDT_FB_FUSE")) m->fb_fuse = atoi(g);
   if (const char* g = getenv("FDT_STREAM_IR")) m->stream_ir = atoi(g) != 0;
+  if (const char* g = getenv("FDT_STEM_B3")) m->stem_b3 = atoi(g) != 0;
   if (const char* g = getenv("FDT_FUSE_INGEST")) m->fuse_stem = atoi(g);   // A/B: 0 = ingest kernel + planar stem conv, 2 = also FaceBoxes
   if (arch == FDT_ARCH_TRY3 || arch == FDT_ARCH_TRY4 || arch == FDT_ARCH_TRY5) {   // pyramid_mb2_try3.py:216
     m->conf_t = 0.2f;
@@ -2184,6 +2189,7 @@ extern "C" fdt_model* fdt_model_clone(fdt_model* src) {
   m->fuse_stem = src->fuse_stem;
   m->fb_fuse = src->fb_fuse;
   m->stream_ir = src->stream_ir;
+  m->stem_b3 = src->stem_b3;
   return m.release();
 }
 

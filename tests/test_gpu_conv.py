@@ -477,3 +477,31 @@ def test_facebox_stem_k168(shape):
     x5 = rng.standard_normal((1, 5, 32, 32)).astype(np.float32)                    # not the three-channel stem: refused
     rc, _ = run_conv(x5, rng.standard_normal((8, 5, 7, 7)).astype(np.float32), None, 7, 4, 3, 1, tile=36)
     assert rc != 0 and b"not instantiated" in lib().lib().fdt_last_error()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 128, 24), (1, 1024, 1024, 24), (3, 45, 76, 24), (2, 130, 252, 45), (1, 7, 12, 5)])
+def test_facebox_stem_b3(shape):
+    """conv_stem_b3.h (CONV_7x7_S4_B3, class 22): FaceBoxes' 7x7 / stride 4 / pad 3 stem as split-bf16 products -- 11 k-steps of
+    two (channel, tap row) pairs x 8 columns, three bf16 planes per operand, six plane products per k-step -- against torch at the
+    f32 classes' tolerance, incl. odd heights, images smaller than a tile, two channel tiles, every activation; and an error
+    against f64 no larger than the f32 kernel's (x1.5)."""
+    B, H, W, Cout = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    x = rng.uniform(0, 1, (B, 3, H, W)).astype(np.float32)                 # what FaceBoxes feeds: BGR / 255
+    w = (rng.standard_normal((Cout, 3, 7, 7)) / np.sqrt(147)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    for act, bias in ((1, b), (0, None), (2, b)):
+        rc, got = run_conv(x, w, bias, 7, 4, 3, 1, act=act, tile=22 * 100 + 36)
+        assert rc == 0, lib().lib().fdt_last_error()
+        exp = reference(x, w, bias, 7, 4, 3, 1, act=act)
+        assert rel_err(got, exp) < 1e-5, (shape, act, rel_err(got, exp))
+    ref64 = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, 4, 3).numpy()
+    rc, got = run_conv(x, w, None, 7, 4, 3, 1, tile=22 * 100 + 36)
+    rc2, f32 = run_conv(x, w, None, 7, 4, 3, 1, tile=36)
+    assert rc == 0 and rc2 == 0
+    e_b3 = float(np.sqrt(((got - ref64) ** 2).mean()) / np.sqrt((ref64 ** 2).mean()))
+    e_f32 = float(np.sqrt(((f32 - ref64) ** 2).mean()) / np.sqrt((ref64 ** 2).mean()))
+    print("stem: split-bf16 vs f64 %.3e, f32 MFMA vs f64 %.3e (%s)" % (e_b3, e_f32, shape))
+    assert e_b3 <= 1.5 * e_f32 + 1e-7
+    rc, _ = run_conv(x[:, :, :, :W - 2].copy(), w, None, 7, 4, 3, 1, tile=22 * 100 + 36)     # Win % 4 != 0: not this class
+    assert rc != 0

@@ -216,9 +216,11 @@ def test_three_batches_in_flight_on_cloned_handles(net):
         c_.close()
 
 
-def test_fused_ingest_facebox_bits(fb_sd):
+def test_fused_ingest_facebox_bits(fb_sd, monkeypatch):
     """FaceBoxes: conv1 (7x7 / 4, 3 -> 24) on the raw uint8 frame with the /255 in its staging (conv_stem_u8.h, class 19) == the
-    ingest kernel + planar conv1, bit for bit, also behind the 4K resize."""
+    ingest kernel + planar f32-MFMA conv1 (class 20; FDT_STEM_B3=0: the default planar stem is the split-bf16 class 22, which has
+    another summation order), bit for bit, also behind the 4K resize."""
+    monkeypatch.setenv("FDT_STEM_B3", "0")
     L = M("_lib")
     d, _ = load_npz("facebox_r2")
     frames = np.stack([d["img%d_frame" % i] for i in (0, 1)])
