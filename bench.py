@@ -849,6 +849,8 @@ def main():
         # the LFPN.  [launches, ms, algorithmic flops, executed flops], same serial profile pass as conv_stack.
         bb = [0, 0.0, 0.0, 0.0]
         b3 = [0, 0.0, 0.0]                    # split-bf16 1x1 layers: launches, ms, algorithmic flops
+        bb_f32 = [0.0]
+        exe_f32 = 0.0
         bb_pool_ms = 0.0
         is_backbone = lambda layer: args.arch == "res50" and (layer == "conv1" or layer.split(".")[0] in (
             "layer1", "layer2", "layer3", "layer4", "layer5", "layer6"))
@@ -878,19 +880,21 @@ def main():
             # against the peak of the pipe it runs on: `ex` is kept in f32-pipe equivalents (executed FLOPs x f32 peak / that
             # pipe's peak), so that ex / time / 157.3 stays what it was -- the fraction of the time the matrix pipe is busy at
             # its paper rate -- whatever mix of the two pipes a set of kernels uses
+            ex_f32 = ex                      # the same launch priced as if it had run on the f32 pipe (what rounds 1-4 ran)
             if kind == B3_KIND:
                 b3[0] += 1; b3[1] += ms; b3[2] += fl
                 ex = 6.0 * fl * PEAK_F32_MFMA_TFLOPS / PEAK_BF16_MFMA_TFLOPS
             g = groups.setdefault((kind, tile), [0, 0.0, 0.0, 0.0])
             g[0] += 1; g[1] += ms; g[2] += fl; g[3] += ex
             conv_ms += ms; alg += fl; exe += ex; n_conv += 1
+            exe_f32 += ex_f32
             if is_backbone(layer):
-                bb[0] += 1; bb[1] += ms; bb[2] += fl; bb[3] += ex
+                bb[0] += 1; bb[1] += ms; bb[2] += fl; bb[3] += ex; bb_f32[0] += ex_f32
         (dk, dt_), dg = max(groups.items(), key=lambda kv: kv[1][1])
         # HBM bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (PMC
         # cannot be read from inside the process); the committed summary of the current round is quoted here.
         traffic = traffic_src = traffic_cal = traffic_classes = traffic_ratio = traffic_alg = None
-        for rnd in ("r04", "r03", "r02", "r01"):
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             tj = os.path.join(ROOT, "profiles", rnd, "conv_hbm_traffic%s.json" % ("" if B == 1 else "_b%d" % B))
             if args.arch == "res50" and H == 1024 and W == 1024 and os.path.exists(tj):
                 tdata = json.load(open(tj))
@@ -961,6 +965,10 @@ def main():
                           "executed_gflop_per_frame": round(bb[3] / B / 1e9, 3),
                           "achieved_executed": round(tf(bb[3], seg_ms["backbone"][0]), 2),
                           "frac": round(tf(bb[3], seg_ms["backbone"][0]) / PEAK_F32_MFMA_TFLOPS, 4),
+                          # the same launches with the split-bf16 layers counted as the f32 work they replace (one FLOP per
+                          # algorithmic FLOP against the f32 peak): comparable with the rounds in which every layer ran on the
+                          # f32 pipe; `frac` above prices those layers' SIX bf16 FLOPs per FLOP against the 16x higher bf16 peak
+                          "frac_f32_equivalent": round(tf(bb_f32[0], seg_ms["backbone"][0]) / PEAK_F32_MFMA_TFLOPS, 4),
                           "achieved_algorithmic": round(tf(bb[2], seg_ms["backbone"][0]), 2),
                           "frac_algorithmic": round(tf(bb[2], seg_ms["backbone"][0]) / PEAK_F32_MFMA_TFLOPS, 4),
                           # rounds 1-3 quoted the SUM of per-launch event intervals (one event record per launch inside):
@@ -976,6 +984,7 @@ def main():
             # the timed region itself (frames overlap on several streams): FLOPs of a step / ms_per_step
             # (a profiled forward covers G frames when launches are grouped; a step is one frame)
             "timed_step": {"ms_per_step": round(step_ms, 4),
+                           "frac_f32_equivalent": round(tf(exe_f32 / max(G, 1), step_ms) / PEAK_F32_MFMA_TFLOPS, 4),
                            "achieved_executed": round(tf(exe / max(G, 1), step_ms), 2),
                            "frac_executed": round(tf(exe / max(G, 1), step_ms) / PEAK_F32_MFMA_TFLOPS, 4),
                            "achieved_algorithmic": round(tf(alg / max(G, 1), step_ms), 2),

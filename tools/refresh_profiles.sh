@@ -3,10 +3,12 @@
 # passes (FETCH_SIZE, WRITE_SIZE) summarised per kernel, MFMA-busy PMC of the dominant Winograd kernel and of the three
 # 1x1 instantiations that take the most time, the per-layer HIP-event table and the bench lines of the other
 # configurations.  Run through gpurun from the repo root:
-#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r04'
+#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r05 a'      (rocprofv3 stats, traffic and PMC passes)
+#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r05 b'      (per-layer tables and the bench lines of every configuration)
 # Outputs land in gpurun_out/profiles_<round>/ (copy them into profiles/<round>/ afterwards).
 set -e -o pipefail
-R=${1:-r04}
+R=${1:-r05}
+PART=${2:-all}
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT /tmp/raw
 export TMPDIR=/tmp
@@ -20,7 +22,8 @@ K_B=$(plan_of layer1.0.conv3)
 K_C=$(plan_of layer2.1.conv3)
 case "$K_WINO" in "14 32 "*|"14 33 "*) ;; *) echo "refresh_profiles: conv2_SSH.conv1 is no longer a Winograd F(4x4,3x3) kernel ($K_WINO)" >&2; exit 1;; esac
 K_WD2=$(plan_of conv2_SSH.conv2)       # the dilated SSH context conv: quarter-split F(2x2,3x3)
-B="python bench.py --steps 48 --warmup 8 --cpu-frames 0 --host-frames 0 --ungrouped-steps 0"
+B="python bench.py --steps 48 --warmup 8 --cpu-frames 0 --host-frames 0 --ungrouped-steps 0 --latency-frames 0"
+if [ "$PART" != "b" ]; then
 timeout -k 10 400 python bench.py --steps 64 --warmup 8 > $OUT/bench_line_res50_1024.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt --output-format csv -- $B > $OUT/bench_under_rocprof.log 2>&1
 cp /tmp/raw/kt_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_res50_1024.csv
@@ -34,7 +37,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt1 --output-f
 cp /tmp/raw/kt1_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_res50_1024_inflight1.csv
 python tools/rocprof_conv_summary.py $OUT/rocprofv3_kernel_stats_bench_res50_1024_inflight1.csv 60 $OUT/bench_line_res50_1024.json > $OUT/rocprof_vs_bench_inflight1.txt
 # HBM traffic by request size class, per dispatch (tools/experiments/traffic_r4.sh has the calibration passes)
-P="python bench.py --steps 32 --warmup 8 --cpu-frames 0 --host-frames 0 --inflight 1 --profile-frames 1 --graph 0 --ungrouped-steps 0"
+P="python bench.py --steps 32 --warmup 8 --cpu-frames 0 --host-frames 0 --inflight 1 --profile-frames 1 --graph 0 --ungrouped-steps 0 --latency-frames 0"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d /tmp/raw -o fwd_rd --output-format csv -- $P > /tmp/raw/fwd_rd.log 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -d /tmp/raw -o fwd_wr --output-format csv -- $P > /tmp/raw/fwd_wr.log 2>&1
 python tools/dump_ops.py --batch 4 > $OUT/ops_1024_b4.json 2> /tmp/raw/dump_ops.err
@@ -49,7 +52,7 @@ python tools/traffic_by_class.py /tmp/raw/fwd1_rd_counter_collection.csv /tmp/ra
 # matrix-pipe occupancy of the production kernels (one kernel per process; SQ counters + GRBM in one pass)
 #        name                       kind tile split cin  h   w  cout res
 pmc_one() {
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_COEXEC_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
     -d /tmp/raw -o mfma_$1 --output-format csv -- python tools/one_conv.py $2 $3 $4 $5 $6 $7 $8 $9 8 > $OUT/pmc_mfma_$1_times.txt 2>&1 || \
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
     -d /tmp/raw -o mfma_$1 --output-format csv -- python tools/one_conv.py $2 $3 $4 $5 $6 $7 $8 $9 8 > $OUT/pmc_mfma_$1_times.txt 2>&1
@@ -67,12 +70,14 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VA
   -d /tmp/raw -o valu_head --output-format csv -- python tools/one_conv.py $K_HEAD 512 256 256 8 0 8 > $OUT/pmc_valu_head_512to8_256x256_times.txt 2>&1 && \
   python tools/summarize_pmc.py /tmp/raw/valu_head_counter_collection.csv $OUT/pmc_valu_head_512to8_256x256.csv || echo "head PMC pass failed (counters unavailable)" > $OUT/pmc_valu_head_512to8_256x256.csv
 echo "face_loc.0 $K_HEAD" >> $OUT/pmc_mfma_kernels.txt
+fi
+if [ "$PART" != "a" ]; then
 timeout -k 10 300 python tools/profile_layers.py > $OUT/per_layer_hip_events_res50_1024.txt
 timeout -k 10 300 python tools/profile_layers.py --batch 4 > $OUT/per_layer_hip_events_res50_1024_b4.txt
 timeout -k 10 300 python bench.py --steps 256 --warmup 32 --group 1 --cpu-frames 0 --host-frames 0 > $OUT/bench_line_res50_1024_group1.json
 timeout -k 10 300 python bench.py --steps 256 --warmup 32 --height 480 --width 640 > $OUT/bench_line_res50_640x480.json
 timeout -k 10 300 python bench.py --steps 256 --warmup 32 --height 480 --width 640 --group 1 --cpu-frames 0 --host-frames 0 > $OUT/bench_line_res50_640x480_group1.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt480 --output-format csv -- python bench.py --steps 64 --warmup 8 --height 480 --width 640 --cpu-frames 0 --host-frames 0 --ungrouped-steps 0 > $OUT/bench_640x480_under_rocprof.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kt480 --output-format csv -- python bench.py --steps 64 --warmup 8 --height 480 --width 640 --cpu-frames 0 --host-frames 0 --ungrouped-steps 0 --latency-frames 0 > $OUT/bench_640x480_under_rocprof.log 2>&1
 cp /tmp/raw/kt480_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_res50_640x480.csv
 timeout -k 10 200 python tools/profile_layers.py --height 480 --width 640 > $OUT/per_layer_hip_events_res50_640x480.txt
 timeout -k 10 300 python bench.py --steps 128 --warmup 16 --source 1080x1920 --height 480 --width 640 --host-frames 256 > $OUT/bench_line_res50_640x480_from_1080p.json
@@ -86,6 +91,7 @@ timeout -k 10 300 python bench.py --steps 256 --warmup 32 --height 480 --width 6
 timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line_res50_1024_driver_style.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o ktfb --output-format csv -- python bench.py --arch facebox --batch 16 --steps 50 --warmup 5 --cpu-frames 0 > $OUT/bench_facebox_under_rocprof.log 2>&1
 cp /tmp/raw/ktfb_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_facebox_4k_b16.csv
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kttry3 --output-format csv -- python bench.py --steps 32 --warmup 4 --arch try3 --batch 8 --cpu-frames 0 --host-frames 0 > $OUT/bench_try3_b8_under_rocprof.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/raw -o kttry3 --output-format csv -- python bench.py --steps 32 --warmup 4 --arch try3 --batch 8 --cpu-frames 0 --host-frames 0 --latency-frames 0 > $OUT/bench_try3_b8_under_rocprof.log 2>&1
 cp /tmp/raw/kttry3_kernel_stats.csv $OUT/rocprofv3_kernel_stats_bench_try3_1024_b8.csv
-tail -c 600 $OUT/bench_line_res50_1024.json
+fi
+ls $OUT | wc -l

@@ -16,7 +16,7 @@ line = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1]) if len(sys.
 # (the command is run with --ungrouped-steps 0)
 G = (line["config"].get("frames_grouped_per_launch") or line["config"].get("batch_per_gpu") or 1) if line else 1
 frames = forwards * G
-conv = [r for r in rows if any(k in r["Name"] for k in ("conv_kernel", "conv_wino", "conv1x1p_kernel", "conv_stem_u8_kernel", "conv_stem_s4_kernel", "conv_n8_kernel"))]
+conv = [r for r in rows if any(k in r["Name"] for k in ("conv_kernel", "conv_wino", "conv1x1p_kernel", "conv_stem_u8_kernel", "conv_stem_s4_kernel", "conv_n8_kernel", "conv_b3_kernel", "conv_stem_s4_b3_kernel"))]
 red = [r for r in rows if "splitk_reduce" in r["Name"]]
 tot = lambda rs: sum(float(r["TotalDurationNs"]) for r in rs)
 calls = lambda rs: sum(int(r["Calls"]) for r in rs)
@@ -32,7 +32,7 @@ if line:
     r = d["roofline"]
     cs = r["conv_stack"]
     print("bench.py (HIP events, same ops)        : %.3f ms per frame over %d launches; %.2f TFLOP/s executed, %.2f algorithmic" %
-          (cs["ms_per_frame"], cs["launches_per_frame"], cs["achieved_executed"], cs["achieved_algorithmic"]))
+          (cs["ms_per_frame"], cs.get("launches_per_forward", cs.get("launches_per_frame")), cs["achieved_executed"], cs["achieved_algorithmic"]))
     ms = (tot(conv) + tot(red)) / frames / 1e6
     print("from the rocprof durations             : %.2f TFLOP/s executed (%.3f GFLOP/frame), %.2f algorithmic (%.3f GFLOP/frame)" %
           (cs["executed_gflop_per_frame"] / ms, cs["executed_gflop_per_frame"], cs["algorithmic_gflop_per_frame"] / ms,
@@ -41,4 +41,4 @@ if line:
     print("dominant kernel by rocprof time        : %s" % dom["Name"])
     print("   calls/forward %.1f, average %.2f us (bench.py: %s, %d launches/forward, average %.2f us)" %
           (int(dom["Calls"]) / forwards, float(dom["TotalDurationNs"]) / int(dom["Calls"]) / 1e3, r["kernel"],
-           r["launches_per_frame"], r["avg_launch_us"]))
+           r.get("launches_per_forward", r.get("launches_per_frame")), r["avg_launch_us"]))
