@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 (v_mfma_f32_32x32x16_bf16: 1024 FLOP/clk/SIMD at 2.4 GHz)
-B3_KIND = 21                      # conv.h: CONV_1x1_S1_B3 -- split-bf16 products, SIX bf16 MFMA FLOPs per algorithmic f32 FLOP
+B3_KINDS = (21, 23)               # conv.h: CONV_1x1_S1_B3, CONV_1x1_S2_B3 -- split-bf16 products, SIX bf16 MFMA FLOPs per algorithmic f32 FLOP
 
 
 def facebox_main(args, rank=0, local_rank=0, world=1):
@@ -297,7 +297,7 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
 
 
 KIND_NAMES = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2", "3x3s1_wino", "3x3d2_wino", "1x1s1_k32",
-              "1x1s1_k64", "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44", "1x1s1_p16", "1x1s1_p32", "7x7s2_u8", "7x7s4_u8", "7x7s4_k168", "1x1s1_b3", "7x7s4_b3"]
+              "1x1s1_k64", "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44", "1x1s1_p16", "1x1s1_p32", "7x7s2_u8", "7x7s4_u8", "7x7s4_k168", "1x1s1_b3", "7x7s4_b3", "1x1s2_b3"]
 WINO_KINDS = (8, 9, 14, 15)   # conv.h: Winograd kinds execute fewer MACs than the direct form:
 WINO_RATIO = {8: 2.25, 9: 2.25, 14: 4.0, 15: 4.0}   # F(2x2,3x3) 16/36 of them, F(4x4,3x3) (CONV_3x3_{S1,D2}_WINO44) 36/144
 
@@ -334,7 +334,7 @@ def kernel_label(kind, tile):
         return "conv_stem_s4_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
     if kind == 18:            # conv.h: CONV_7x7_S2_U8, the stem conv on the raw uint8 frame (conv_stem_u8.h)
         return "conv_stem_u8_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
-    if kind == 21:            # conv.h: CONV_1x1_S1_B3, split-bf16 products on the bf16 matrix pipe (conv_b3.h)
+    if kind in B3_KINDS:      # conv.h: CONV_1x1_S1_B3 / _S2_B3, split-bf16 products on the bf16 matrix pipe (conv_b3.h)
         return "conv_b3_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
     if kind in (16, 17):      # conv.h: CONV_1x1_S1_P16 / _P32, the persistent-tile 1x1 kernel (conv_1x1p.h)
         return "conv1x1p_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
@@ -881,7 +881,7 @@ def main():
             # pipe's peak), so that ex / time / 157.3 stays what it was -- the fraction of the time the matrix pipe is busy at
             # its paper rate -- whatever mix of the two pipes a set of kernels uses
             ex_f32 = ex                      # the same launch priced as if it had run on the f32 pipe (what rounds 1-4 ran)
-            if kind == B3_KIND:
+            if kind in B3_KINDS:
                 b3[0] += 1; b3[1] += ms; b3[2] += fl
                 ex = 6.0 * fl * PEAK_F32_MFMA_TFLOPS / PEAK_BF16_MFMA_TFLOPS
             g = groups.setdefault((kind, tile), [0, 0.0, 0.0, 0.0])
@@ -990,8 +990,8 @@ def main():
                            "achieved_algorithmic": round(tf(alg / max(G, 1), step_ms), 2),
                            "frac_algorithmic": round(tf(alg / max(G, 1), step_ms) / PEAK_F32_MFMA_TFLOPS, 4)},
             "by_kernel": [{"kernel": kernel_label(k, t), "launches": g[0], "ms": round(g[1], 4),
-                           "executed_tflops": round(tf(g[2] * 6.0 if k == B3_KIND else g[3], g[1]), 1),
-                           "pipe": "bf16" if k == B3_KIND else "f32",
+                           "executed_tflops": round(tf(g[2] * 6.0 if k in B3_KINDS else g[3], g[1]), 1),
+                           "pipe": "bf16" if k in B3_KINDS else "f32",
                            "frac_of_pipe_peak": round(tf(g[3], g[1]) / PEAK_F32_MFMA_TFLOPS, 4),
                            "algorithmic_tflops": round(tf(g[2], g[1]), 1)}
                           for (k, t), g in sorted(groups.items(), key=lambda kv: -kv[1][1])[:6]],
@@ -1007,7 +1007,7 @@ def main():
                                     "the bf16 peak (as f32-pipe equivalents), the others with their f32 FLOPs against the f32 peak"}
                            if b3[0] else None),
         }
-        if dk == B3_KIND:      # the dominant kernel itself runs on the bf16 pipe: quote it against that peak
+        if dk in B3_KINDS:      # the dominant kernel itself runs on the bf16 pipe: quote it against that peak
             roof.update({"achieved": round(tf(6.0 * dg[2], dg[1]), 2), "peak": PEAK_BF16_MFMA_TFLOPS,
                          "frac": round(tf(6.0 * dg[2], dg[1]) / PEAK_BF16_MFMA_TFLOPS, 4),
                          "frac_executed": round(tf(6.0 * dg[2], dg[1]) / PEAK_BF16_MFMA_TFLOPS, 4)})

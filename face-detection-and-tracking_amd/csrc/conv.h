@@ -33,6 +33,7 @@ enum ConvKind {
   CONV_1x1_S1_B3,      // CONV_1x1_S1 with split-bf16 products on v_mfma_f32_32x32x16_bf16 (three bf16 planes per operand, six plane
                        // products, f32 accumulate: conv_b3.h).  Same tolerance as the f32 classes, not the same bits.
   CONV_7x7_S4_B3,      // CONV_7x7_S4 for Cin = 3 with split-bf16 products (conv_stem_b3.h): FaceBoxes' conv1 on the bf16 matrix pipe
+  CONV_1x1_S2_B3,      // CONV_1x1_S2 with split-bf16 products (conv_b3.h, S = 2): the bottleneck's downsample branch
   CONV_KIND_COUNT
 };
 

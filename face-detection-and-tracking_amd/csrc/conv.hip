@@ -189,6 +189,7 @@ struct Table {
     conv_fill_stem_s4(e[CONV_7x7_S4_K168], e[CONV_7x7_S4_U8]);
     conv_fill_1x1_b3(e[CONV_1x1_S1_B3]);
     conv_fill_stem_b3(e[CONV_7x7_S4_B3]);
+    conv_fill_1x1_s2_b3(e[CONV_1x1_S2_B3]);
   }
 };
 
@@ -203,7 +204,7 @@ const ConvGeom kGeoms[CONV_KIND_COUNT] = {
     {3, 3, 1, 1, 1, 8, 1},  {3, 3, 1, 2, 2, 8, 1},  {1, 1, 1, 1, 0, 32, 0},  {1, 1, 1, 1, 0, 64, 0},
     {7, 7, 2, 1, 1, 2, 0},  {3, 3, 1, 1, 1, 1, 0},  {3, 3, 1, 1, 1, 2, 2},  {3, 3, 1, 2, 2, 2, 2},
     {1, 1, 1, 1, 0, 16, 0}, {1, 1, 1, 1, 0, 32, 0}, {7, 7, 2, 1, 3, 4, 0},  {7, 7, 4, 1, 3, 3, 0},
-    {7, 7, 4, 1, 3, 3, 0},  {1, 1, 1, 1, 0, 16, 0}, {7, 7, 4, 1, 3, 3, 0},
+    {7, 7, 4, 1, 3, 3, 0},  {1, 1, 1, 1, 0, 16, 0}, {7, 7, 4, 1, 3, 3, 0},  {1, 1, 2, 1, 0, 16, 0},
 };
 const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum ConvTile)
     {128, 128, 8, 16}, {128, 64, 8, 16}, {128, 32, 8, 16}, {64, 64, 8, 8},   {64, 128, 8, 8},
@@ -242,6 +243,7 @@ ConvKind conv_base_kind(ConvKind k) {
     case CONV_1x1_S1_P16:
     case CONV_1x1_S1_P32:
     case CONV_1x1_S1_B3: return CONV_1x1_S1;
+    case CONV_1x1_S2_B3: return CONV_1x1_S2;
     case CONV_7x7_S2_U8: return CONV_7x7_S2;
     case CONV_7x7_S4_U8:
     case CONV_7x7_S4_K168:
@@ -322,7 +324,7 @@ void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKin
         }
     return;
   }
-  if (kind == CONV_1x1_S1_B3) {
+  if (kind == CONV_1x1_S1_B3 || kind == CONV_1x1_S2_B3) {
     // conv_b3.h: per (channel tile, stage of 16 input channels) [plane][k-half][BN couts][8 k] bf16 -- the three bf16 planes of
     // every BN-folded f32 weight, w = p0 + p1 + p2 exactly (each the round-to-nearest-even bf16 of the remainder) -- padded to
     // whole dwordx4 LDS-DMA rounds (LayoutB3::WSZP floats); couts past Cout and channels past Cin stay zero
@@ -452,7 +454,7 @@ bool conv_combine_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
 static bool kind_is_direct(ConvKind k) {
   return k == CONV_1x1_S1 || k == CONV_1x1_S2 || k == CONV_3x3_S1 || k == CONV_3x3_S1_D2 || k == CONV_3x3_S2 || k == CONV_7x7_S2 ||
          k == CONV_7x7_S4 || k == CONV_5x5_S2 || k == CONV_1x1_S1_K32 || k == CONV_1x1_S1_K64 || k == CONV_7x7_S2_P1 ||
-         k == CONV_1x1_S1_B3;       // conv_b3.h carries the same epilogue
+         k == CONV_1x1_S1_B3 || k == CONV_1x1_S2_B3;       // conv_b3.h carries the same epilogue
 }
 
 bool conv_shape_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
@@ -472,6 +474,8 @@ bool conv_shape_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
            (long long)(a.Cout + 64) * a.Hout * a.Wout * 4 < (1ll << 31);
   if (kind == CONV_1x1_S1_B3)      // 16-byte activation staging and the vector epilogue only
     return (a.Win & 3) == 0 && (long long)(a.Cout + 128) * a.Hout * a.Wout * 4 < (1ll << 40);
+  if (kind == CONV_1x1_S2_B3)      // the vector epilogue only
+    return (a.Wout & 3) == 0 && (long long)(a.Cout + 128) * a.Hout * a.Wout * 4 < (1ll << 40);
   if (kind_is_persistent(kind)) {
     const int nstages = ceil_div(a.Cin, conv_geom(kind).kc);
     const long long hw = (long long)a.Hin * a.Win;

@@ -22,6 +22,7 @@
 //   * per (cout tile, pixel tile): six MFMAs, smallest plane products first;
 //   * epilogue: the f32 class's (bias, fused bilinear x2 upsample-add, residual, ReLU / ReLU6, second destination, split-K slabs).
 // Needs Win % 4 == 0 (16-byte activation staging).  Channels past Cin read as zeros (buffer bounds), weights are zero there.
+// S = 2 (class CONV_1x1_S2_B3): the same kernel with a dword gather of every second pixel in the staging (Wout % 4 == 0).
 #pragma once
 #include "conv_kernel.h"
 
@@ -31,11 +32,11 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <class T>
+template <class T, int S = 1>
 struct LayoutB3 {
   static constexpr int KC = 16;
   static constexpr int XSZ = KC * T::BM;                       // floats: [16][BM]
-  static constexpr int NXV = XSZ / 1024;                       // dwordx4 LDS-DMA instructions per wave and stage
+  static constexpr int NXV = S == 1 ? XSZ / 1024 : XSZ / 256;  // LDS-DMA instructions per wave and stage: dwordx4 (stride 1), dword
   static constexpr int WSZ = 24 * T::BN;                       // floats holding [3][2][BN][8] bf16
   static constexpr int WSZP = (WSZ + 1023) / 1024 * 1024;
   static constexpr int NW = WSZP / 1024;
@@ -46,7 +47,7 @@ struct LayoutB3 {
   static constexpr int RING = T::NBUF * STAGE;
   static constexpr size_t LDS_BYTES = (size_t)(RING > EPI ? RING : EPI) * sizeof(float);
   static_assert(XSZ % 1024 == 0, "whole dwordx4 LDS-DMA rounds");
-  static_assert(T::NBUF == 3, "ring of three stages");
+  static_assert(T::NBUF == 3 || T::NBUF == 4, "ring of three or four stages");
 };
 
 // x = p0 + p1 + p2 exactly (each conversion rounds to nearest even; the remainders are exact in f32)
@@ -86,10 +87,9 @@ __device__ __forceinline__ void lds_read_b128(bf16x8& v, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
 }
 
-template <class T>
+template <class T, int S = 1>
 __global__ __launch_bounds__(256, (T::MI * T::NI >= 4) ? 2 : 3) void conv_b3_kernel(const ConvArgs a) {
-  using L = LayoutB3<T>;
-  using G = Geom<1, 1, 1, 1, 0, 16>;
+  using L = LayoutB3<T, S>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
@@ -113,24 +113,38 @@ __global__ __launch_bounds__(256, (T::MI * T::NI >= 4) ? 2 : 3) void conv_b3_ker
   const int s_begin = (int)((long long)nstages * ks / a.ksplit);
   const int s_end = (int)((long long)nstages * (ks + 1) / a.ksplit);
 
-  // staging plan: float4 v = 256 * k + tid covers 4 consecutive pixels of one tile row of one channel of the stage
+  // staging plan.  Stride 1: float4 v = 256 * k + tid covers 4 consecutive pixels of one tile row of one channel of the stage;
+  // stride 2 (the bottleneck's downsample branch): dword v = 256 * k + tid is ONE pixel, every second one of every second row
   const __amdgpu_buffer_rsrc_t xrs = buf_rsrc(in_b, (long long)a.Cin * HWin * 4);
   const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(w_t, 0x7fffffffll);
   unsigned xoff[L::NXV];
 #pragma unroll
   for (int k = 0; k < L::NXV; ++k) {
     const int v = tid + 256 * k;
-    const int c = v / (T::BM / 4);
-    const int p = (v - c * (T::BM / 4)) * 4;
-    const int gy = oy0 + p / T::TW, gx = ox0 + p % T::TW;
-    const bool ok = gy < a.Hin && gx < a.Win;
-    xoff[k] = ok ? (unsigned)(c * HWin + gy * a.Win + gx) * 4u : kOob;
+    if constexpr (S == 1) {
+      const int c = v / (T::BM / 4);
+      const int p = (v - c * (T::BM / 4)) * 4;
+      const int gy = oy0 + p / T::TW, gx = ox0 + p % T::TW;
+      const bool ok = gy < a.Hin && gx < a.Win;
+      xoff[k] = ok ? (unsigned)(c * HWin + gy * a.Win + gx) * 4u : kOob;
+    } else {
+      const int c = v / T::BM;
+      const int p = v - c * T::BM;
+      const int oy = oy0 + p / T::TW, ox = ox0 + p % T::TW;
+      const bool ok = oy < a.Hout && ox < a.Wout;
+      xoff[k] = ok ? (unsigned)(c * HWin + oy * S * a.Win + ox * S) * 4u : kOob;
+    }
   }
 #define FDT_B3_STAGE(s_, buf_)                                                                            \
   {                                                                                                       \
     const unsigned xso_ = (unsigned)((s_) * L::KC) * (unsigned)HWin * 4u;                                 \
-    float* X_ = smem + (buf_) * L::STAGE + wave * 256;                                                    \
-    _Pragma("unroll") for (int k = 0; k < L::NXV; ++k) bglds16(xrs, X_ + 1024 * k, xoff[k], xso_);        \
+    if constexpr (S == 1) {                                                                               \
+      float* X_ = smem + (buf_) * L::STAGE + wave * 256;                                                  \
+      _Pragma("unroll") for (int k = 0; k < L::NXV; ++k) bglds16(xrs, X_ + 1024 * k, xoff[k], xso_);      \
+    } else {                                                                                              \
+      float* X_ = smem + (buf_) * L::STAGE + wave * 64;                                                   \
+      _Pragma("unroll") for (int k = 0; k < L::NXV; ++k) bglds4(xrs, X_ + 256 * k, xoff[k], xso_);        \
+    }                                                                                                     \
     const unsigned wso_ = (unsigned)((s_) * L::WSZP) * 4u;                                                \
     float* W_ = smem + (buf_) * L::STAGE + L::XSZ + wave * 256;                                           \
     _Pragma("unroll") for (int k = 0; k < L::NW; ++k) bglds16(wrs, W_ + 1024 * k, (unsigned)tid * 16u, wso_ + 4096u * k); \
@@ -226,19 +240,26 @@ __global__ __launch_bounds__(256, (T::MI * T::NI >= 4) ? 2 : 3) void conv_b3_ker
     });
   };
 
-  // ring: buffer of stage s = s % 3.  Prologue: stages 0 and 1 requested, stage 0 waited for, read and split.
-#pragma unroll
-  for (int p = 0; p < T::NBUF - 1; ++p)
-    if (p < nst) FDT_B3_STAGE(s_begin + p, p);
-  Ops O[2];
-  if (nst > 0) {
-    if (nst > 1)
+  // ring of D = NBUF stages: buffer of stage s = s % D.  Prologue: stages 0 .. D-2 requested, stage 0 waited for (the younger ones
+  // stay in flight: exact vmcnt), read and split.
+  constexpr int D = T::NBUF;
+  auto wait_leaving = [&](int stages) {        // every LDS-DMA group but the `stages` youngest has landed
+    if (stages >= 2 && D >= 4)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L::LOADS) : "memory");
+    else if (stages >= 1)
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::LOADS) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+#pragma unroll
+  for (int p = 0; p < D - 1; ++p)
+    if (p < nst) FDT_B3_STAGE(s_begin + p, p);
+  Ops O[2];
+  if (nst > 0) {
+    wait_leaving(min(nst, D - 1) - 1);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (2 < nst) FDT_B3_STAGE(s_begin + 2, 2);
+    if (D - 1 < nst) FDT_B3_STAGE(s_begin + D - 1, D - 1);
     issue_reads(O[0], 0);
     wait_reads(O[0]);
 #pragma unroll
@@ -247,23 +268,21 @@ __global__ __launch_bounds__(256, (T::MI * T::NI >= 4) ? 2 : 3) void conv_b3_ker
       for (int q = 0; q < 4; ++q) split_pair(O[0], i, q);
   }
   // steady state, two stages per trip (the operand sets swap roles): at the top of step `it` the operands of stage `it` sit in
-  // registers; stage it + 1 is waited for (stage it + 2 stays in flight), the barrier also says every wave has finished READING
-  // stage it -- so stage it + 3 may be requested into its buffer --, stage it + 1 is read, and the MFMAs of stage `it` run.
+  // registers; stage it + 1 is waited for (stages it + 2 .. it + D - 1 stay in flight), the barrier also says every wave has
+  // finished READING stage it -- so stage it + D may be requested into its buffer --, stage it + 1 is read, and the MFMAs of
+  // stage `it` run.
   int buf_next = 1;                                        // buffer of stage it + 1
   auto step = [&](int it, Ops& c, Ops& n) {
     const bool have_next = it + 1 < nst;
     if (have_next) {
-      if (it + 2 < nst)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::LOADS) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_leaving(min(nst - it - 2, D - 2));
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (it + 3 < nst) FDT_B3_STAGE(s_begin + it + 3, (buf_next + 2) % 3);
+      if (it + D < nst) FDT_B3_STAGE(s_begin + it + D, (buf_next + D - 1) % D);
       issue_reads(n, buf_next);
     }
     mfmas(c, n, have_next);
-    buf_next = buf_next == 2 ? 0 : buf_next + 1;
+    buf_next = buf_next == D - 1 ? 0 : buf_next + 1;
   };
   for (int it = 0; it < nst; it += 2) {
     step(it, O[0], O[1]);
@@ -342,10 +361,16 @@ using TB3_128x128 = Tile<8, 16, 128, 2, 2, 3>;
 using TB3_128x64 = Tile<8, 16, 64, 2, 2, 3>;
 using TB3_128x128W = Tile<4, 32, 128, 2, 2, 3>;
 using TB3_128x64W = Tile<4, 32, 64, 2, 2, 3>;
+// waves 4 x 1: every wave owns 32 of the tile's pixels and ALL its couts, so each activation is split by exactly one wave
+// (36 vector-ALU operations per stage and wave in place of 72, R5-11) at the price of every wave reading the whole weight stage
+using TB3_128x128W4 = Tile<4, 32, 128, 4, 1, 3>;
+using TB3_128x64W4 = Tile<4, 32, 64, 4, 1, 3>;
+// (a ring of FOUR stages -- Tile<8, 16, BN, 4, 1, 4>, the kernel takes NBUF = 4 -- measured 3-20 % slower than these on every
+// backbone shape, docs/EXPERIMENTS.md R5-11: the class is not bound by LDS-DMA latency; not instantiated)
 
-template <class T>
+template <class T, int S = 1>
 KernelEntry entry_b3() {
-  return KernelEntry{conv_b3_kernel<T>, LayoutB3<T>::LDS_BYTES, 256};
+  return KernelEntry{conv_b3_kernel<T, S>, LayoutB3<T, S>::LDS_BYTES, 256};
 }
 
 }  // namespace

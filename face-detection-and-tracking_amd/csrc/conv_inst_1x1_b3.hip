@@ -9,6 +9,13 @@ void conv_fill_1x1_b3(void* row) {
   r[TILE_128x64R3] = entry_b3<TB3_128x64>();
   r[TILE_128x128WR3] = entry_b3<TB3_128x128W>();
   r[TILE_128x64WR3] = entry_b3<TB3_128x64W>();
+  r[TILE_128x128W] = entry_b3<TB3_128x128W4>();
+  r[TILE_128x64W] = entry_b3<TB3_128x64W4>();
+}
+void conv_fill_1x1_s2_b3(void* row) {
+  KernelEntry* r = (KernelEntry*)row;
+  r[TILE_128x128W] = entry_b3<TB3_128x128W4, 2>();
+  r[TILE_128x64W] = entry_b3<TB3_128x64W4, 2>();
 }
 void conv_fill_stem_b3(void* row) {
   KernelEntry* r = (KernelEntry*)row;

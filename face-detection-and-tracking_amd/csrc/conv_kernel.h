@@ -491,6 +491,7 @@ void conv_fill_3x3_s2(void* row);
 void conv_fill_n8(void* row);   // conv_n8.h
 void conv_fill_stems(void* row_7x7_s2, void* row_7x7_s4, void* row_5x5_s2, void* row_7x7_s2_p1);
 void conv_fill_1x1_b3(void* row);   // conv_b3.h
+void conv_fill_1x1_s2_b3(void* row);
 void conv_fill_stem_b3(void* row);  // conv_stem_b3.h
 
 }  // namespace fdt

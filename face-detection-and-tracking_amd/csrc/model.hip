@@ -2619,6 +2619,7 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   int rc = FDT_OK;
   // FDT_TUNE_ONLY=<substring>: re-measure only the layers whose name contains it (the others keep their plan entry)
   const char* only = getenv("FDT_TUNE_ONLY");
+  const char* only_base = getenv("FDT_TUNE_BASE");
   const float split_penalty = getenv("FDT_TUNE_SPLIT_PENALTY") ? (float)atof(getenv("FDT_TUNE_SPLIT_PENALTY")) : 0.0f;
   // The in-kernel split-K combine (conv.h) is a candidate only on request (FDT_TUNE_COMBINE=1): measured, it wins a tenth of
   // the split layers in isolation and nothing in the multi-stream step (docs/EXPERIMENTS.md R3-4)
@@ -2626,6 +2627,17 @@ extern "C" int fdt_model_autotune(fdt_model* m, int iters) {
   for (auto& op : m->ops) {
     if (op.type != OP_CONV) continue;
     if (only && *only && op.name.find(only) == std::string::npos) continue;
+    if (only_base && *only_base) {     // FDT_TUNE_BASE=0,1: only the layers of these base classes (conv.h: enum ConvKind)
+      bool hit = false;
+      for (const char* q = only_base; *q;) {
+        char* e = nullptr;
+        const long v = strtol(q, &e, 10);
+        if (e == q) break;
+        hit = hit || v == (long)conv_base_kind(op.kind);
+        q = *e ? e + 1 : e;
+      }
+      if (!hit) continue;
+    }
     struct Cand { int kind, tile, split, combine; float ms; };
     std::vector<Cand> cands;
     long long ws_need = 0, cnt_need = 0;

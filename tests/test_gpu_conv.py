@@ -411,7 +411,7 @@ def test_persistent_1x1_walks_tiles(variant, shape):
     assert rc == 0 and rel_err(got, reference(x, w, None, 1, 1, 0, 1)) < 1e-5
 
 
-@pytest.mark.parametrize("tile", [7, 8, 11, 12])          # the ring-of-three tiles of class 21 (conv.h: CONV_1x1_S1_B3, conv_b3.h)
+@pytest.mark.parametrize("tile", [7, 8, 11, 12, 5, 6])    # class 21 (conv.h: CONV_1x1_S1_B3, conv_b3.h); 5, 6: waves 4 x 1
 @pytest.mark.parametrize("shape", [(1, 64, 64, 64, 256), (2, 40, 36, 48, 72), (1, 19, 27, 36, 45), (1, 1024, 32, 32, 256)])
 def test_split_bf16_1x1(tile, shape):
     """conv_b3.h: 1x1 convolution as split-bf16 products on v_mfma_f32_32x32x16_bf16 (three bf16 planes per operand, six plane
@@ -444,6 +444,33 @@ def test_split_bf16_1x1(tile, shape):
     print("split-bf16 vs f64: %.3e   f32 MFMA vs f64: %.3e   (tile %d, %s)" % (e_b3, e_f32, tile, shape))
     assert e_b3 <= 1.5 * e_f32 + 1e-7, (e_b3, e_f32)
     rc, _ = run_conv(x[:, :, :, :W - 1].copy(), w, b, 1, 1, 0, 1, tile=v)     # Win % 4 != 0: not this class
+    assert rc != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile", [5, 6])
+@pytest.mark.parametrize("shape", [(1, 64, 64, 64, 256), (2, 40, 35, 47, 72), (1, 19, 27, 39, 45), (1, 512, 32, 32, 128)])
+def test_split_bf16_1x1_stride2(tile, shape):
+    """Class 23 (conv.h: CONV_1x1_S2_B3): conv_b3.h with a dword gather of every second pixel in its staging -- the bottleneck's
+    downsample branch (pyramid.py:87-91) as split-bf16 products.  Same tolerance as the f32 class of the same layer; odd input
+    sizes, channels past Cin, couts past Cout, residual / activation, split-K; Wout % 4 != 0 is refused."""
+    B, Cin, H, W, Cout = shape
+    rng = np.random.default_rng(tile * 1000 + Cin + 7)
+    x = np.maximum(rng.standard_normal((B, Cin, H, W)), 0).astype(np.float32) * np.exp(rng.standard_normal((B, Cin, 1, 1))).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    res = rng.standard_normal((B, Cout, Ho, Wo)).astype(np.float32)
+    v = 23 * 100 + tile
+    for kw in (dict(act=0), dict(res=res, act=1)):
+        exp = reference(x, w, b, 1, 2, 0, 1, **kw)
+        for split in (1, 2):
+            if split > (Cin + 15) // 16 // 2:
+                continue
+            rc, got = run_conv(x, w, b, 1, 2, 0, 1, tile=v, split=split, **kw)
+            assert rc == 0, lib().lib().fdt_last_error()
+            assert got.shape == exp.shape and rel_err(got, exp) < 1e-5, (tile, shape, list(kw), split, rel_err(got, exp))
+    rc, _ = run_conv(x[:, :, :, :W - 2].copy(), w, b, 1, 2, 0, 1, tile=v)      # Wout % 4 != 0: not this class
     assert rc != 0
 
 

@@ -2,7 +2,8 @@
 """Re-measure SOME layers of every committed plan (the others keep their entry): after a new kernel variant is added for
 one layer class, e.g. the vector-ALU kernel of the loc/conf heads.
     python tools/retune_layers.py face_loc            # all plans under tuned/
-    python tools/retune_layers.py face_loc res50_1024x1024_b1.plan ..."""
+    python tools/retune_layers.py face_loc res50_1024x1024_b1.plan ...
+    python tools/retune_layers.py base:0,1            # the layers of base classes 0 and 1 (conv.h: the 1x1 convolutions)"""
 import importlib
 import os
 import re
@@ -14,13 +15,18 @@ sys.path.insert(0, ROOT)
 
 def main():
     only = sys.argv[1]
-    os.environ["FDT_TUNE_ONLY"] = only
+    if only.startswith("base:"):
+        os.environ["FDT_TUNE_BASE"] = only[5:]
+    else:
+        os.environ["FDT_TUNE_ONLY"] = only
     tuned = os.path.join(ROOT, "face-detection-and-tracking_amd", "tuned")
     names = sys.argv[2:] or sorted(f for f in os.listdir(tuned) if f.endswith(".plan"))
     synth = importlib.import_module("face-detection-and-tracking_amd.synth")
     layers = importlib.import_module("face-detection-and-tracking_amd.layers")
     for name in names:
         m = re.fullmatch(r"(res50|try3)_(\d+)x(\d+)_b(\d+)\.plan", name)
+        if not m:          # FaceBoxes' plan: tools/profile_facebox.py / bench.py --arch facebox --autotune
+            continue
         arch, W, H, B = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))
         if arch == "res50":
             net = importlib.import_module("face-detection-and-tracking_amd.pyramid").SFD()
@@ -34,7 +40,7 @@ def main():
         old = open(path).read()
         net.import_plan(old)
         net(frames)
-        net.autotune(5)
+        net.autotune(int(os.environ.get("FDT_RETUNE_ITERS", "5")))
         net(frames)
         new = net.export_plan()
         changed = [(a, b) for a, b in zip(old.splitlines(), new.splitlines()) if a != b]
