@@ -32,6 +32,9 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 (v_mfma_f32_32x32x16_bf16: 1024 FLOP/clk/SIMD at 2.4 GHz)
 B3_KINDS = (21, 23)               # conv.h: CONV_1x1_S1_B3, CONV_1x1_S2_B3 -- split-bf16 products, SIX bf16 MFMA FLOPs per algorithmic f32 FLOP
+# kernels on the bf16 matrix pipe: executed bf16 MFMA FLOPs per algorithmic f32 FLOP.  24 = CONV_7x7_S2_U8B (conv_stem_u8b.h): the
+# pixels are exact in ONE bf16 plane, the weights carry three -> 3 plane products, K = 147 padded to 176
+BF16_MULT = {21: 6.0, 23: 6.0, 24: 3.0 * 176.0 / 147.0, 25: 3.0 * 176.0 / 147.0 * 32.0 / 24.0}
 
 
 def facebox_main(args, rank=0, local_rank=0, world=1):
@@ -169,12 +172,16 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
     act_b, w_b, per_op = net.traffic()
     # ingest: 4 bilinear taps per output pixel and channel (u8) when the source is larger than 2x the output, else the
     # whole source frame once; + the f32 NCHW output
-    ingest_b = B * (min(SH * SW * 3, 1024 * 1024 * 3 * 4) + 1024 * 1024 * 3 * 4)
+    # with the raw-frame stem (conv_stem_u8b.h, class 25) the resized frame stays uint8: 1 byte per element written and read
+    u8_stem = any(nm.startswith("conv1#k25t") or nm.startswith("conv1#k19t") for nm, _, _ in acc.values())
+    ingest_b = B * (min(SH * SW * 3, 1024 * 1024 * 3 * 4) + 1024 * 1024 * 3 * (1 if u8_stem else 4))
     rows = []
     for j, (nm, ms, fl) in acc.items():
         by = float(per_op[j]) if j < len(per_op) else 0.0
         if nm == "ingest":
             by = float(ingest_b)
+        elif u8_stem and nm.split("#")[0] == "conv1":
+            by -= float(B * 1024 * 1024 * 3 * 3)
         rows.append((nm, ms, by, fl))
     tot_ms = sum(r[1] for r in rows)
     tot_b = sum(r[2] for r in rows)
@@ -186,21 +193,36 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
         176 (class 22: split-bf16, six bf16 MFMA FLOPs per padded f32 FLOP, against the bf16 peak) and N = 24 to 32; conv2 pads nothing."""
         op = r[0].split("#")[0]
         b3 = "#k22t" in r[0] or "#k21t" in r[0]
+        u8b = "#k25t" in r[0]         # conv_stem_u8b.h: bytes exact in one bf16 plane x three weight planes
         pad = 1.0
         if op == "conv1":
-            pad = (196.0 if "#k6t" in r[0] else 176.0 if "#k22t" in r[0] else 168.0) / 147.0 * 32.0 / 24.0
+            pad = (196.0 if "#k6t" in r[0] else 176.0 if (b3 or u8b) else 168.0) / 147.0 * 32.0 / 24.0
         alg = r[3] / (r[1] * 1e-3) / 1e12
-        ex = alg * pad * (6.0 if b3 else 1.0)
-        peak = PEAK_BF16_MFMA_TFLOPS if b3 else PEAK_F32_MFMA_TFLOPS
+        ex = alg * pad * (6.0 if b3 else 3.0 if u8b else 1.0)
+        peak = PEAK_BF16_MFMA_TFLOPS if (b3 or u8b) else PEAK_F32_MFMA_TFLOPS
         return {"op": op, "ms": round(r[1], 4), "algorithmic_tflops": round(alg, 1), "executed_tflops": round(ex, 1),
-                "pipe": "bf16 (split-bf16 products: 6 plane products per f32 product)" if b3 else "f32", "peak": peak,
-                "frac": round(ex / peak, 4)}
+                "pipe": ("bf16 (split-bf16 products: 6 plane products per f32 product)" if b3 else
+                         "bf16 (uint8 pixels exact in one plane x three weight planes: 3 plane products)" if u8b else "f32"),
+                "peak": peak, "frac": round(ex / peak, 4)}
 
-    roof = {"bound": "hbm", "kernel": dom[0] + (" (resize_preprocess_kernel: cv2.resize + /255 fused)" if dom[0] == "ingest" else ""),
-            "achieved": round(gbs(dom[2], dom[1]), 1), "peak": 8000.0, "unit": "GB/s",
-            "frac": round(gbs(dom[2], dom[1]) / 8000.0, 4), "traffic": None,
+    # the longest kernel is priced against the roofline that bounds IT: conv1 / conv2 are matrix work (mfma_row), everything else
+    # streams; the longest STREAMING kernel is kept beside it (`hbm_dominant`)
+    hdom = max((r for r in rows if r[0].split("#")[0] not in ("conv1", "conv2", "detect")), key=lambda r: r[1])
+    ingest_note = lambda n: n + (" (resize kernel: cv2.resize to uint8, the /255 is conv1's)" if n == "ingest" else "")
+    if dom[0].split("#")[0] in ("conv1", "conv2"):
+        mr = mfma_row(dom)
+        head = {"bound": "mfma", "kernel": dom[0], "achieved": mr["executed_tflops"], "peak": mr["peak"], "unit": "TFLOP/s",
+                "frac": mr["frac"], "pipe": mr["pipe"], "traffic": None}
+    else:
+        head = {"bound": "hbm", "kernel": ingest_note(dom[0]), "achieved": round(gbs(dom[2], dom[1]), 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(gbs(dom[2], dom[1]) / 8000.0, 4), "traffic": None}
+    roof = dict(head)
+    roof.update({
             "algorithmic_bytes_per_launch": round(dom[2]), "avg_launch_us": round(dom[1] * 1e3, 2),
             "time_share": round(dom[1] / tot_ms, 4),
+            "hbm_dominant": {"bound": "hbm", "kernel": ingest_note(hdom[0]), "achieved": round(gbs(hdom[2], hdom[1]), 1), "peak": 8000.0,
+                             "unit": "GB/s", "frac": round(gbs(hdom[2], hdom[1]) / 8000.0, 4), "avg_launch_us": round(hdom[1] * 1e3, 2),
+                             "algorithmic_bytes_per_launch": round(hdom[2])},
             "forward": {"launches": len(rows), "ms_per_batch": round(tot_ms, 4),
                         "algorithmic_bytes_per_frame": round(tot_b / B),
                         "achieved": round(gbs(tot_b, tot_ms), 1), "frac": round(gbs(tot_b, tot_ms) / 8000.0, 4),
@@ -223,7 +245,7 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
             "note": "bytes = un-fused algorithmic lower bound (each op reads its inputs and writes its output once, f32; "
                     "weights once).  The whole net is 1.87 GFLOP and 77 MB per frame over 40 launches: launch-latency bound, "
                     "which is why several batches are kept in flight; conv1 (3 -> 24 channels, K = 147 padded to 168, N = 24 "
-                    "padded to 32) and conv2 are the two layers with real matrix work (algorithmic_tflops)"}
+                    "padded to 32) and conv2 are the two layers with real matrix work (algorithmic_tflops)"})
 
     cpu, parity = None, None
     if world > 1:
@@ -297,7 +319,7 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
 
 
 KIND_NAMES = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2", "3x3s1_wino", "3x3d2_wino", "1x1s1_k32",
-              "1x1s1_k64", "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44", "1x1s1_p16", "1x1s1_p32", "7x7s2_u8", "7x7s4_u8", "7x7s4_k168", "1x1s1_b3", "7x7s4_b3", "1x1s2_b3"]
+              "1x1s1_k64", "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44", "1x1s1_p16", "1x1s1_p32", "7x7s2_u8", "7x7s4_u8", "7x7s4_k168", "1x1s1_b3", "7x7s4_b3", "1x1s2_b3", "7x7s2_u8b", "7x7s4_u8b"]
 WINO_KINDS = (8, 9, 14, 15)   # conv.h: Winograd kinds execute fewer MACs than the direct form:
 WINO_RATIO = {8: 2.25, 9: 2.25, 14: 4.0, 15: 4.0}   # F(2x2,3x3) 16/36 of them, F(4x4,3x3) (CONV_3x3_{S1,D2}_WINO44) 36/144
 
@@ -332,6 +354,8 @@ def kernel_label(kind, tile):
         return "conv_stem_s4_b3_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
     if kind in (19, 20):      # conv.h: CONV_7x7_S4_U8 / _K168, the stride-4 stem of FaceBoxes (conv_stem_s4.h)
         return "conv_stem_s4_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
+    if kind in (24, 25):      # conv.h: CONV_7x7_S2_U8B / _S4_U8B, the raw-frame stems on the bf16 matrix pipe (conv_stem_u8b.h)
+        return "conv_stem_u8b_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
     if kind == 18:            # conv.h: CONV_7x7_S2_U8, the stem conv on the raw uint8 frame (conv_stem_u8.h)
         return "conv_stem_u8_kernel<%s, tile %d>" % (KIND_NAMES[kind], tile)
     if kind in B3_KINDS:      # conv.h: CONV_1x1_S1_B3 / _S2_B3, split-bf16 products on the bf16 matrix pipe (conv_b3.h)
@@ -848,7 +872,7 @@ def main():
         # incl. the downsample convs) and the extra stages layer5 / layer6 (pyramid.py:120-131) -- everything in front of
         # the LFPN.  [launches, ms, algorithmic flops, executed flops], same serial profile pass as conv_stack.
         bb = [0, 0.0, 0.0, 0.0]
-        b3 = [0, 0.0, 0.0]                    # split-bf16 1x1 layers: launches, ms, algorithmic flops
+        b3 = [0, 0.0, 0.0, 0.0]               # layers on the bf16 pipe: launches, ms, algorithmic flops, executed bf16 flops
         bb_f32 = [0.0]
         exe_f32 = 0.0
         bb_pool_ms = 0.0
@@ -881,9 +905,9 @@ def main():
             # pipe's peak), so that ex / time / 157.3 stays what it was -- the fraction of the time the matrix pipe is busy at
             # its paper rate -- whatever mix of the two pipes a set of kernels uses
             ex_f32 = ex                      # the same launch priced as if it had run on the f32 pipe (what rounds 1-4 ran)
-            if kind in B3_KINDS:
-                b3[0] += 1; b3[1] += ms; b3[2] += fl
-                ex = 6.0 * fl * PEAK_F32_MFMA_TFLOPS / PEAK_BF16_MFMA_TFLOPS
+            if kind in BF16_MULT:
+                b3[0] += 1; b3[1] += ms; b3[2] += fl; b3[3] += BF16_MULT[kind] * fl
+                ex = BF16_MULT[kind] * fl * PEAK_F32_MFMA_TFLOPS / PEAK_BF16_MFMA_TFLOPS
             g = groups.setdefault((kind, tile), [0, 0.0, 0.0, 0.0])
             g[0] += 1; g[1] += ms; g[2] += fl; g[3] += ex
             conv_ms += ms; alg += fl; exe += ex; n_conv += 1
@@ -990,8 +1014,8 @@ def main():
                            "achieved_algorithmic": round(tf(alg / max(G, 1), step_ms), 2),
                            "frac_algorithmic": round(tf(alg / max(G, 1), step_ms) / PEAK_F32_MFMA_TFLOPS, 4)},
             "by_kernel": [{"kernel": kernel_label(k, t), "launches": g[0], "ms": round(g[1], 4),
-                           "executed_tflops": round(tf(g[2] * 6.0 if k in B3_KINDS else g[3], g[1]), 1),
-                           "pipe": "bf16" if k in B3_KINDS else "f32",
+                           "executed_tflops": round(tf(g[2] * BF16_MULT[k] if k in BF16_MULT else g[3], g[1]), 1),
+                           "pipe": "bf16" if k in BF16_MULT else "f32",
                            "frac_of_pipe_peak": round(tf(g[3], g[1]) / PEAK_F32_MFMA_TFLOPS, 4),
                            "algorithmic_tflops": round(tf(g[2], g[1]), 1)}
                           for (k, t), g in sorted(groups.items(), key=lambda kv: -kv[1][1])[:6]],
@@ -1000,17 +1024,17 @@ def main():
             # (tests/test_gpu_conv.py::test_split_bf16_1x1), priced against the bf16 peak
             "split_bf16": ({"launches_per_forward": b3[0], "ms_per_forward": round(b3[1], 4),
                             "f32_equivalent_tflops": round(tf(b3[2], b3[1]), 1),
-                            "bf16_tflops_executed": round(tf(6.0 * b3[2], b3[1]), 1), "peak": PEAK_BF16_MFMA_TFLOPS,
-                            "frac_of_bf16_peak": round(tf(6.0 * b3[2], b3[1]) / PEAK_BF16_MFMA_TFLOPS, 4),
+                            "bf16_tflops_executed": round(tf(b3[3], b3[1]), 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+                            "frac_of_bf16_peak": round(tf(b3[3], b3[1]) / PEAK_BF16_MFMA_TFLOPS, 4),
                             "share_of_algorithmic_flops": round(b3[2] / alg, 4) if alg else None,
                             "note": "in the aggregate `frac*_executed` fields these launches count with their bf16 FLOPs against "
                                     "the bf16 peak (as f32-pipe equivalents), the others with their f32 FLOPs against the f32 peak"}
                            if b3[0] else None),
         }
-        if dk in B3_KINDS:      # the dominant kernel itself runs on the bf16 pipe: quote it against that peak
-            roof.update({"achieved": round(tf(6.0 * dg[2], dg[1]), 2), "peak": PEAK_BF16_MFMA_TFLOPS,
-                         "frac": round(tf(6.0 * dg[2], dg[1]) / PEAK_BF16_MFMA_TFLOPS, 4),
-                         "frac_executed": round(tf(6.0 * dg[2], dg[1]) / PEAK_BF16_MFMA_TFLOPS, 4)})
+        if dk in BF16_MULT:     # the dominant kernel itself runs on the bf16 pipe: quote it against that peak
+            roof.update({"achieved": round(tf(BF16_MULT[dk] * dg[2], dg[1]), 2), "peak": PEAK_BF16_MFMA_TFLOPS,
+                         "frac": round(tf(BF16_MULT[dk] * dg[2], dg[1]) / PEAK_BF16_MFMA_TFLOPS, 4),
+                         "frac_executed": round(tf(BF16_MULT[dk] * dg[2], dg[1]) / PEAK_BF16_MFMA_TFLOPS, 4)})
         if dwm > 0:      # config 3: state the HBM side too
             roof["hbm_side"] = {"bound": "hbm", "kernel": " + ".join(sorted(dw_kernels)),
                                 "achieved": round(dwb / (dwm * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",

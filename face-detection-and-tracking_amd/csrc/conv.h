@@ -34,6 +34,8 @@ enum ConvKind {
                        // products, f32 accumulate: conv_b3.h).  Same tolerance as the f32 classes, not the same bits.
   CONV_7x7_S4_B3,      // CONV_7x7_S4 for Cin = 3 with split-bf16 products (conv_stem_b3.h): FaceBoxes' conv1 on the bf16 matrix pipe
   CONV_1x1_S2_B3,      // CONV_1x1_S2 with split-bf16 products (conv_b3.h, S = 2): the bottleneck's downsample branch
+  CONV_7x7_S2_U8B,     // the raw-uint8 stems on the bf16 matrix pipe (conv_stem_u8b.h): a pixel minus an integer mean is exact in ONE
+  CONV_7x7_S4_U8B,     // bf16, the weights carry three planes: three exact plane products per k-step, f32 accumulate.  ConvArgs.in_u8.
   CONV_KIND_COUNT
 };
 

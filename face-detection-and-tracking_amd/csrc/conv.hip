@@ -190,6 +190,7 @@ struct Table {
     conv_fill_1x1_b3(e[CONV_1x1_S1_B3]);
     conv_fill_stem_b3(e[CONV_7x7_S4_B3]);
     conv_fill_1x1_s2_b3(e[CONV_1x1_S2_B3]);
+    conv_fill_stem_u8b(e[CONV_7x7_S2_U8B], e[CONV_7x7_S4_U8B]);
   }
 };
 
@@ -205,6 +206,7 @@ const ConvGeom kGeoms[CONV_KIND_COUNT] = {
     {7, 7, 2, 1, 1, 2, 0},  {3, 3, 1, 1, 1, 1, 0},  {3, 3, 1, 1, 1, 2, 2},  {3, 3, 1, 2, 2, 2, 2},
     {1, 1, 1, 1, 0, 16, 0}, {1, 1, 1, 1, 0, 32, 0}, {7, 7, 2, 1, 3, 4, 0},  {7, 7, 4, 1, 3, 3, 0},
     {7, 7, 4, 1, 3, 3, 0},  {1, 1, 1, 1, 0, 16, 0}, {7, 7, 4, 1, 3, 3, 0},  {1, 1, 2, 1, 0, 16, 0},
+    {7, 7, 2, 1, 3, 3, 0},  {7, 7, 4, 1, 3, 3, 0},
 };
 const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum ConvTile)
     {128, 128, 8, 16}, {128, 64, 8, 16}, {128, 32, 8, 16}, {64, 64, 8, 8},   {64, 128, 8, 8},
@@ -244,10 +246,12 @@ ConvKind conv_base_kind(ConvKind k) {
     case CONV_1x1_S1_P32:
     case CONV_1x1_S1_B3: return CONV_1x1_S1;
     case CONV_1x1_S2_B3: return CONV_1x1_S2;
-    case CONV_7x7_S2_U8: return CONV_7x7_S2;
+    case CONV_7x7_S2_U8:
+    case CONV_7x7_S2_U8B: return CONV_7x7_S2;
     case CONV_7x7_S4_U8:
     case CONV_7x7_S4_K168:
-    case CONV_7x7_S4_B3: return CONV_7x7_S4;
+    case CONV_7x7_S4_B3:
+    case CONV_7x7_S4_U8B: return CONV_7x7_S4;
     default: return k;
   }
 }
@@ -255,8 +259,9 @@ bool tile_is_wino(ConvTile t) {
   return (t >= TILE_WINO_64x64 && t <= TILE_WINO8_64x64W) || t == TILE_WINO4_64x64R3 || t == TILE_WINO4_64x64W;
 }
 bool tile_is_wino44(ConvTile t) { return t == TILE_WINO44_32x64 || t == TILE_WINO44B_32x64; }
+bool kind_is_u8b_stem(ConvKind k) { return k == CONV_7x7_S2_U8B || k == CONV_7x7_S4_U8B; }
 bool kind_is_persistent(ConvKind k) { return k == CONV_1x1_S1_P16 || k == CONV_1x1_S1_P32; }
-bool kind_is_u8_stem(ConvKind k) { return k == CONV_7x7_S2_U8 || k == CONV_7x7_S4_U8; }
+bool kind_is_u8_stem(ConvKind k) { return k == CONV_7x7_S2_U8 || k == CONV_7x7_S4_U8 || kind_is_u8b_stem(k); }
 static int device_cus(int dev) {
   static std::atomic<int> cus[16];
   int v = cus[dev].load(std::memory_order_relaxed);
@@ -290,6 +295,40 @@ void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKin
         for (int t = 0; t < 49; ++t)
           out[(((size_t)(co / 32) * 3 + ci) * 7 + t / 7) * 256 + (size_t)(t % 7 + 1) * 32 + co % 32] =
               w[((size_t)co * 3 + ci) * 49 + t] * (scale ? scale[co] : 1.0f);
+    return;
+  }
+  if (kind_is_u8b_stem(kind)) {
+    // conv_stem_u8b.h: per group of 32 couts [k-step s][plane][lane = 32 h + cout % 32][8 columns = taps -1 .. 6] bf16 -- a lane's
+    // A operand of (step, plane) is the 16 bytes it loads into its registers; pair q = 2 s + h = (channel q / 7, tap row q % 7),
+    // pair 21 and the first column are zero; a channel tile of BN couts is BN / 32 consecutive groups (StemU8B::WSZ = 8448 floats each)
+    const int groups = n_tiles * (BN / 32);
+    out.assign((size_t)groups * 8448, 0.0f);
+    if (Cin != 3 || BN % 32) return;
+    unsigned short* o16 = reinterpret_cast<unsigned short*>(out.data());
+    auto bf16_rne = [](float x) -> unsigned short {
+      unsigned u;
+      memcpy(&u, &x, 4);
+      u += 0x7fffu + ((u >> 16) & 1u);
+      return (unsigned short)(u >> 16);
+    };
+    auto bf16_f32 = [](unsigned short h) -> float {
+      const unsigned u = (unsigned)h << 16;
+      float f;
+      memcpy(&f, &u, 4);
+      return f;
+    };
+    for (int co = 0; co < Cout; ++co)
+      for (int q = 0; q < 21; ++q)
+        for (int kx = 0; kx < 7; ++kx) {
+          const float wv = w[((size_t)co * 3 + q / 7) * 49 + (q % 7) * 7 + kx] * (scale ? scale[co] : 1.0f);
+          const unsigned short p0 = bf16_rne(wv);
+          const float r1 = wv - bf16_f32(p0);
+          const unsigned short p1 = bf16_rne(r1);
+          const unsigned short p2 = bf16_rne(r1 - bf16_f32(p1));
+          const unsigned short pl[3] = {p0, p1, p2};
+          for (int pp = 0; pp < 3; ++pp)
+            o16[(size_t)(co / 32) * 16896 + ((((size_t)(q / 2) * 3 + pp) * 2 + q % 2) * 32 + co % 32) * 8 + kx + 1] = pl[pp];
+        }
     return;
   }
   if (kind == CONV_7x7_S4_B3) {
@@ -462,6 +501,11 @@ bool conv_shape_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
   if (a.out2 && (!kind_is_direct(kind) || a.ksplit > 1 || a.ws || a.res || a.up || a.sk_count)) return false;
   if (a.in_bstride && (kind_is_u8_stem(kind) || kind == CONV_7x7_S4_K168)) return false;
   if (kind == CONV_3x3_D2_WINO44 && (a.Win & 3)) return false;
+  if (kind_is_u8b_stem(kind)) {   // one bf16 plane holds a pixel minus an INTEGER mean exactly; 12-byte groups of four pixels
+    for (int c = 0; c < 3; ++c)
+      if (a.u8_mean[c] != (float)(int)a.u8_mean[c] || a.u8_mean[c] < 0.0f || a.u8_mean[c] > 255.0f) return false;
+    if ((a.Win & 3) || !(a.u8_scale > 0.0f) || (long long)a.Hin * a.Win * 3 >= (1ll << 31)) return false;
+  }
   if (kind_is_u8_stem(kind))   // the raw-frame stem: three input channels, one stage, plain epilogue, one channel tile per 32 / 64 couts
     return a.in_u8 != nullptr && a.Cin == 3 && a.ksplit <= 1 && !a.ws && !a.res && !a.up && !a.sk_count &&
            (long long)(a.Cout + 64) * a.Hout * a.Wout * 4 < (1ll << 31);
@@ -571,12 +615,12 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
     FDT_LAUNCH_CHECK();
     return FDT_OK;
   }
-  if (kind == CONV_7x7_S4_K168 || kind == CONV_7x7_S4_U8 || kind == CONV_7x7_S4_B3) {
+  if (kind == CONV_7x7_S4_K168 || kind == CONV_7x7_S4_U8 || kind == CONV_7x7_S4_B3 || kind_is_u8b_stem(kind)) {
     // conv_stem_s4.h / conv_stem_b3.h: persistent over the (image, spatial tile) pairs, three (split-bf16: two) workgroups per
     // CU; grid.y = channel tile
     const long long total = (long long)a.B * tiles;
     FDT_REQUIRE(total <= 0x7fffffffll && n_ct <= 65535, FDT_ERR_ARG, "launch_conv: grid too large");
-    const int k = (int)ceil_div_ll(total, (long long)device_cus(dev) * (kind == CONV_7x7_S4_B3 ? 2 : 3));
+    const int k = (int)ceil_div_ll(total, (long long)device_cus(dev) * (kind == CONV_7x7_S4_B3 || kind_is_u8b_stem(kind) ? 2 : 3));
     a.tiles_per_wg = k;
     hipLaunchKernelGGL(ke.fn, dim3((unsigned)ceil_div_ll(total, k), (unsigned)n_ct), dim3(ke.threads), ke.lds, st, a);
     FDT_LAUNCH_CHECK();

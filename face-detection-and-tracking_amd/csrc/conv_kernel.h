@@ -493,5 +493,6 @@ void conv_fill_stems(void* row_7x7_s2, void* row_7x7_s4, void* row_5x5_s2, void*
 void conv_fill_1x1_b3(void* row);   // conv_b3.h
 void conv_fill_1x1_s2_b3(void* row);
 void conv_fill_stem_b3(void* row);  // conv_stem_b3.h
+void conv_fill_stem_u8b(void* row_s2, void* row_s4);  // conv_stem_u8b.h
 
 }  // namespace fdt

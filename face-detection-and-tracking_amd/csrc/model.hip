@@ -643,6 +643,9 @@ struct Builder {
           (conv_base_kind(kind) == CONV_7x7_S2 || conv_base_kind(kind) == CONV_7x7_S4)) {
         op.u8_kind = conv_base_kind(kind) == CONV_7x7_S2 ? CONV_7x7_S2_U8 : CONV_7x7_S4_U8;
         op.u8_tile = conv_base_kind(kind) == CONV_7x7_S2 ? TILE_128x64W : TILE_128x32W;
+        // ... on the bf16 matrix pipe where the frame width allows its 12-byte groups (conv_stem_u8b.h; FDT_STEM_B3=0: the f32 form)
+        const ConvKind u8b = conv_base_kind(kind) == CONV_7x7_S2 ? CONV_7x7_S2_U8B : CONV_7x7_S4_U8B;
+        if (m->stem_b3 && (in.W & 3) == 0 && conv_supported(u8b, op.u8_tile)) op.u8_kind = u8b;
         if (conv_supported(op.u8_kind, op.u8_tile)) {
           DevW du;
           r = device_weights(m, name, op.u8_kind, op.u8_tile, du);
@@ -1974,7 +1977,8 @@ int forward_impl(fdt_model* m, const void* frames, bool frames_on_device, int fo
   // iouTracke_cal.py:40-46 / My_test_facebox.py:14-15 happens in the stem conv's staging -- the f32 NCHW frame is never
   // written.  The stem then reads the caller's device frames in place, the H2D landing buffer, or the resized uint8 image.
   const bool fused = m->fuse_stem && format == FDT_FRAME_U8_HWC_BGR && !m->ops.empty() && m->ops[0].u8_stem &&
-                     (m->fuse_stem >= 2 || m->ops[0].u8_stream || m->ops[0].u8_kind == CONV_7x7_S2_U8);
+                     (m->fuse_stem >= 2 || m->ops[0].u8_stream || m->ops[0].u8_kind == CONV_7x7_S2_U8 ||
+                      m->ops[0].u8_kind == CONV_7x7_S2_U8B || m->ops[0].u8_kind == CONV_7x7_S4_U8B);
   m->u8_src = nullptr;
   if (fused) {
     const bool fb = m->arch == FDT_ARCH_FACEBOX;

@@ -69,9 +69,11 @@ def test_forward_stages_vs_oracle(net, fb_sd, synth):
         g = net.get_tensor(st)
         assert g.shape == o[st].shape and rel_rms(g, o[st]) < 2e-5, (st, rel_rms(g, o[st]))
     assert rel_rms(loc.numpy(), o["loc"]) < 2e-5 and rel_rms(conf.numpy(), o["conf"]) < 2e-5
-    # u8 frame in == f32 tensor in (the /255 happens on the GPU)
+    # u8 frame in (the raw-frame stem on the bf16 pipe, conv_stem_u8b.h: bytes x three weight planes, / 255 behind the sum) against
+    # the oracle too, and against the f32 tensor in to f32 rounding
     loc2, conf2 = net(fr[None])
-    assert np.array_equal(loc2.numpy(), loc.numpy()) and np.array_equal(conf2.numpy(), conf.numpy())
+    assert rel_rms(loc2.numpy(), o["loc"]) < 2e-5 and rel_rms(conf2.numpy(), o["conf"]) < 2e-5
+    assert rel_rms(loc2.numpy(), loc.numpy()) < 2e-6 and rel_rms(conf2.numpy(), conf.numpy()) < 2e-6
 
 
 @pytest.mark.parametrize("i", [0, 1, 2])
@@ -239,6 +241,46 @@ def test_fused_ingest_facebox_bits(fb_sd, monkeypatch):
     for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and len(a[1]) >= 3
     assert np.array_equal(res[0][2], res[1][2])
+
+
+def test_raw_frame_stem_on_the_bf16_pipe_facebox(fb_sd):
+    """conv_stem_u8b.h, class 25 (the default on uint8 frames): conv1 reads the bytes -- exact in one bf16 --, multiplies them with
+    the three bf16 planes of the weights and divides the SUM by 255 (My_test_facebox.py:14-15 divides the pixels: a scalar that
+    commutes with the convolution up to f32 rounding).  Against the ingest kernel + planar f32 conv1 (FDT_STEM_B3=0 handle,
+    class 20): conv1's output to 2e-6 of its maximum, the same faces (boxes to 1e-3 px, scores to 1e-5), also behind the resize."""
+    import os
+    L = M("_lib")
+    d, _ = load_npz("facebox_r2")
+    frames = np.stack([d["img%d_frame" % i] for i in (0, 1)])
+    res = []
+    for b3 in ("1", "0"):
+        os.environ["FDT_STEM_B3"] = b3
+        try:
+            n = M("FACEBOX.networks").FaceBox()
+        finally:
+            del os.environ["FDT_STEM_B3"]
+        n.load_state_dict(fb_sd)
+        if b3 == "0":
+            L.check(L.lib().fdt_model_fuse_ingest(n._h, 0))
+        r = n.detect_frames(frames)
+        c1 = n.get_tensor("conv1").copy()
+        n.profile(True)
+        n.detect_frames(frames)
+        first = n.profile_read()
+        n.profile(False)
+        SH, SW = 1080, 1920
+        yi = (np.arange(SH) * 1024) // SH
+        xi = (np.arange(SW) * 1024) // SW
+        r2 = n.detect_frames(np.ascontiguousarray(frames[:, yi][:, :, xi]))
+        res.append((r, r2, c1, [x[0] for x in first]))
+        n.close()
+    assert any(x.startswith("conv1#k25t") for x in res[0][3]), res[0][3][:3]
+    assert any(x.startswith("conv1#k20t") for x in res[1][3]), res[1][3][:3]
+    a, b = res[0][2], res[1][2]
+    assert a.shape == b.shape and float(np.abs(a.astype(np.float64) - b).max()) <= 2e-6 * float(np.abs(b).max())
+    for x, y in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+        assert len(x[1]) == len(y[1]) and len(x[1]) >= 3
+        assert np.abs(x[0] - y[0]).max() <= 1e-3 and np.abs(x[1] - y[1]).max() <= 1e-5
 
 
 @pytest.mark.parametrize("B", [1, 16])

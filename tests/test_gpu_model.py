@@ -582,13 +582,65 @@ def test_try3_with_fused_inverted_residual_heads(try3_sd, synth, monkeypatch):
     assert n > 5 and d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
 
 
+@pytest.mark.parametrize("H,W,B", [(136, 200, 1), (256, 256, 2), (480, 640, 1), (100, 202, 1)])
+def test_raw_frame_stem_on_the_bf16_pipe(res50_sd, synth, H, W, B):
+    """conv_stem_u8b.h (class 24 = CONV_7x7_S2_U8B, the default raw-frame stem where W % 4 == 0): (float)u8 - mean is an integer of
+    magnitude <= 255, exact in ONE bf16; the weights are split into three bf16 planes; three exact plane products per k-step, f32
+    accumulate.  Against the ingest kernel + planar f32-MFMA stem (class 5): the stem tensor to f32 rounding (1e-6 of its
+    maximum; every product is exact in both forms, only the order of the f32 additions differs), the same detections; the
+    "input" tensor formed lazily is the oracle's; image borders (zero padding of the NORMALISED image), tiles hanging over the
+    map, two images, device frames, the resize in front.  W % 4 != 0: the f32 raw-frame class 18 runs instead."""
+    L = M("_lib")
+    nets = []
+    for fuse in (1, 0):
+        n = M("pyramid").build_sfd('test', 640, 2)
+        n.load_state_dict(res50_sd)
+        n.priorbox = M("layers").PriorBoxLayer(W, H)
+        n.detect = M("layers").Detect(2, 0, 750, 0.05, 0.35)
+        L.check(L.lib().fdt_model_fuse_ingest(n._h, fuse))
+        nets.append(n)
+    frames = synth.make_frames(B, H, W, seed=3 * H + B)
+    frames[0, :3, :5] = 255                                   # extremes at an image corner
+    frames[0, -2:, -7:] = 0
+    outs = []
+    for n in nets:
+        y = n(frames if B > 1 else frames[0]).numpy()
+        outs.append((y, n.get_tensor("stem"), n.get_tensor("input")))
+    want = "#k24t" if W % 4 == 0 else "#k18t"
+    for n, k in zip(nets, (want, "#k5t")):
+        n.profile(True)
+        n(frames if B > 1 else frames[0])
+        assert n.profile_read()[0][0].startswith("conv1" + k), n.profile_read()[0][0]
+        n.profile(False)
+    a, b = outs[0][1], outs[1][1]
+    assert a.shape == b.shape and np.isfinite(a).all()
+    assert float(np.abs(a.astype(np.float64) - b).max()) <= 1e-6 * float(np.abs(b).max()), float(np.abs(a - b).max() / np.abs(b).max())
+    assert np.array_equal(outs[0][2], np.concatenate([opb.preprocess(f) for f in frames]))
+    for bi in range(B):
+        nn = int((outs[1][0][bi, 1, :, 0] > 0).sum())
+        d_iou, d_sc = match_detections(outs[0][0][bi, 1], outs[1][0][bi, 1], nn)
+        assert d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL, (bi, nn, d_iou, d_sc)
+    fd = torch.from_numpy(frames).cuda()
+    ydev = nets[0](fd if B > 1 else fd[0]).numpy()
+    assert np.array_equal(ydev, outs[0][0])                  # device frames: the same kernel on the caller's buffer
+    big = synth.make_frames(B, 2 * H + 6, 2 * W + 10, seed=5)
+    yr = [n.forward_resized(big, (W, H)).numpy() for n in nets]
+    sr = [n.get_tensor("stem") for n in nets]
+    assert float(np.abs(sr[0].astype(np.float64) - sr[1]).max()) <= 1e-6 * float(np.abs(sr[1]).max())
+    assert np.array_equal(nets[0].get_tensor("input"), nets[1].get_tensor("input"))
+    for n in nets:
+        n.close()
+
+
 @pytest.mark.parametrize("H,W,B", [(136, 200, 1), (256, 256, 2), (480, 640, 1)])
-def test_fused_ingest_gives_the_bits_of_the_two_launch_form(res50_sd, synth, H, W, B):
+def test_fused_ingest_gives_the_bits_of_the_two_launch_form(res50_sd, synth, H, W, B, monkeypatch):
     """conv_stem_u8.h: the 7x7 stem reading the raw uint8 frame (mean subtraction in its staging) against preprocess_kernel +
     the planar stem conv: same accumulation order -> the stem tensor, the Detect record and the (lazily formed) "input" tensor
     are bit-identical; host frames, device frames, and the device-side resize in front (tiles hanging over the map, the
-    zero padding of the converted domain at every image border, two images)."""
+    zero padding of the converted domain at every image border, two images).  FDT_STEM_B3=0: the f32-MFMA raw-frame class (the
+    default where the width allows is the bf16-pipe class 24, another summation order: test_raw_frame_stem_on_the_bf16_pipe)."""
     import ctypes
+    monkeypatch.setenv("FDT_STEM_B3", "0")
     L = M("_lib")
     nets = []
     for fuse in (1, 0):
