@@ -1212,9 +1212,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": ("f32" if not (roof and roof.get("split_bf16")) else
-                      "f32 (f32 in / f32 out everywhere; 3x3, stem and head convolutions on the f32 MFMA; %d of the forward's 1x1 "
-                      "launches as split-bf16 products -- three bf16 planes per f32 operand, six plane products, f32 accumulate: "
-                      "the f32 MFMA's error against f64)" % roof["split_bf16"]["launches_per_forward"]),
+                      "f32 (f32 in / f32 out everywhere; 3x3 and head convolutions on the f32 MFMA; %d launches per forward on the "
+                      "bf16 matrix pipe with f32 accumulate: the 1x1 convolutions as split-bf16 products -- three bf16 planes per f32 "
+                      "operand, six plane products, the f32 MFMA's error against f64 -- and (Res50) the 7x7 stem on the raw uint8 frame, "
+                      "whose pixels minus the integer means are exact in one bf16 plane)" % roof["split_bf16"]["launches_per_forward"]),
             "data": "synthetic",
             "config": {"workload": "PyramidBox-%s %dx%d synthetic u8 frames%s, %s, decode+NMS+IoU-tracker "
                                    "on device" % ("Res50" if args.arch == "res50" else "MobileNetV2-try3", W, H,
