@@ -623,6 +623,13 @@ def test_raw_frame_stem_on_the_bf16_pipe(res50_sd, synth, H, W, B):
     fd = torch.from_numpy(frames).cuda()
     ydev = nets[0](fd if B > 1 else fd[0]).numpy()
     assert np.array_equal(ydev, outs[0][0])                  # device frames: the same kernel on the caller's buffer
+    # ... also when the caller's device buffer starts at an odd address (the kernel loads 12-byte groups with dword instructions)
+    raw = torch.zeros(frames.size + 8, dtype=torch.uint8, device="cuda")
+    odd = raw[1:1 + frames.size].view(frames.shape)
+    odd.copy_(fd)
+    assert odd.data_ptr() % 4 == 1
+    yodd = nets[0](odd if B > 1 else odd[0]).numpy()
+    assert np.array_equal(yodd, outs[0][0])
     big = synth.make_frames(B, 2 * H + 6, 2 * W + 10, seed=5)
     yr = [n.forward_resized(big, (W, H)).numpy() for n in nets]
     sr = [n.get_tensor("stem") for n in nets]
