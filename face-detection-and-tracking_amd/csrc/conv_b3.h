@@ -299,6 +299,44 @@ __global__ __launch_bounds__(256, (T::MI * T::NI >= 4) ? 2 : 3) void conv_b3_ker
   else
     dst_b = a.out + ((long long)b * a.out_ctot + a.out_coff) * HWout;
   const float* res_b = (!raw && a.res) ? a.res + ((long long)b * a.res_ctot + a.res_coff) * HWout : nullptr;
+  // Waves 4 x 1 on a 4 x 32 tile: a wave's accumulator register is 32 consecutive pixels of ONE output row and one cout (lanes 32-63:
+  // four couts further) -- two whole 128-byte segments per store.  The plain epilogue then runs from the registers like conv_1x1p.h's:
+  // no LDS transpose, no barriers (the short-reduction layers spend as long in the LDS epilogue as in their four to eight stages),
+  // the residual of cout tile j + 1 in flight under the stores of tile j.  Same arithmetic: acc + bias, + residual, activation.
+  if constexpr (T::WM == 4 && T::WN == 1 && T::TH == 4 && T::TW == 32) {
+    if (!raw && !a.up && !a.out2 && (long long)(a.Cout + 8) * HWout * 4 < (1ll << 32)) {
+      const unsigned hw4 = (unsigned)HWout * 4u;
+      const int gy = oy0 + wm, gx = ox0 + l31;
+      const unsigned voff = (gy < a.Hout && gx < a.Wout) ? (unsigned)(gy * a.Wout + gx) * 4u + (unsigned)(4 * half) * hw4 : kOob;
+      const __amdgpu_buffer_rsrc_t ors = buf_rsrc(dst_b, (long long)a.Cout * HWout * 4);          // couts past Cout fall off the end
+      const __amdgpu_buffer_rsrc_t rrs = buf_rsrc(res_b, res_b ? (long long)a.Cout * HWout * 4 : 0);
+      const __amdgpu_buffer_rsrc_t brs = buf_rsrc(a.bias, a.bias ? (long long)a.Cout * 4 : 0);
+      const int co0 = n_tile * T::BN;
+      float rv[2][16];
+      auto load_res = [&](int j, float* d) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          d[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, voff, (unsigned)(co0 + j * 32 + (r & 3) + 8 * (r >> 2)) * hw4, 0));
+      };
+      if (res_b) load_res(0, rv[0]);
+      static_for<0, T::NI>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const float bvj = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (unsigned)(co0 + j * 32 + l31) * 4u, 0, 0));
+        if constexpr (j + 1 < T::NI)
+          if (res_b) load_res(j + 1, rv[(j + 1) & 1]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2);
+          float v = acc[j][0][r] + (a.bias ? __shfl(bvj, rr + 4 * half, 64) : 0.0f);
+          if (res_b) v += rv[j & 1][r];
+          if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
+          else if (a.act == ACT_RELU6) v = fminf(fmaxf(v, 0.0f), 6.0f);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ors, voff, (unsigned)(co0 + j * 32 + rr) * hw4, 0);
+        }
+      });
+      return;
+    }
+  }
   constexpr int ROWS = T::WN * 32;
   constexpr int C4 = T::BM / 4;
   constexpr int PER = (ROWS * C4 + 255) / 256;
