@@ -749,6 +749,14 @@ extern "C" int fdt_conv2d(const float* x, int B, int Cin, int H, int W, const fl
   return FDT_OK;
 }
 
+// Host-only query (not part of include/fdt.h; no GPU needed): is (kernel class, tile) instantiated, and which base class (the layer
+// geometry it serves) does the class belong to?  tests/test_gpu_timed_plans.py checks every row of every committed plan with it.
+extern "C" int fdt_debug_conv_class(int kind, int tile, int* base_kind) {
+  if (kind < 0 || kind >= fdt::CONV_KIND_COUNT || tile < 0 || tile >= fdt::CONV_TILE_COUNT) return 0;
+  if (base_kind) *base_kind = (int)fdt::conv_base_kind((fdt::ConvKind)kind);
+  return fdt::conv_supported((fdt::ConvKind)kind, (fdt::ConvTile)tile) ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Tuning hook (not part of include/fdt.h): time one conv configuration on random data with HIP events.
 // Used by tools/conv_bench.py and tools/autotune.py.

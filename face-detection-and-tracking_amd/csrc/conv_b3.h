@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, (T::MI * T::NI >= 4) ? 2 : 3) void conv_b3_ker
   // no LDS transpose, no barriers (the short-reduction layers spend as long in the LDS epilogue as in their four to eight stages),
   // the residual of cout tile j + 1 in flight under the stores of tile j.  Same arithmetic: acc + bias, + residual, activation.
   if constexpr (T::WM == 4 && T::WN == 1 && T::TH == 4 && T::TW == 32) {
-    if (!raw && !a.up && !a.out2 && (long long)(a.Cout + 8) * HWout * 4 < (1ll << 32)) {
+    if (!raw && !a.up && !a.out2 && (long long)(a.Cout + 8) * HWout * 4 < (1ll << 31)) {      // kOob = 2^31 must stay out of range
       const unsigned hw4 = (unsigned)HWout * 4u;
       const int gy = oy0 + wm, gx = ox0 + l31;
       const unsigned voff = (gy < a.Hout && gx < a.Wout) ? (unsigned)(gy * a.Wout + gx) * 4u + (unsigned)(4 * half) * hw4 : kOob;

@@ -70,6 +70,33 @@ def test_every_committed_plan_is_pinned():
         assert "tuned_plan_text" in body or stem in body, "%s does not import %s" % (where, f)
 
 
+def test_every_row_of_every_committed_plan_names_an_instantiated_kernel():
+    """CPU-checkable: a plan row `layer kind tile split map [combine]` must name a (kernel class, tile) the library instantiates --
+    a stale row would be ignored silently (model.hip: a hint that does not fit the layer falls back to the analytic choice) and the
+    timed handle would no longer run the committed plan -- and, within one file, a layer appears once."""
+    import ctypes
+    L = importlib.import_module("face-detection-and-tracking_amd._lib").lib()
+    L.fdt_debug_conv_class.restype = ctypes.c_int
+    L.fdt_debug_conv_class.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    files = sorted(f for f in os.listdir(TUNED) if f.endswith(".plan"))
+    assert files
+    for f in files:
+        seen = set()
+        rows = [l.split() for l in open(os.path.join(TUNED, f)).read().splitlines() if l.strip()]
+        assert rows[0][0] == "shape" and len(rows[0]) == 4, (f, rows[0])
+        for r in rows[1:]:
+            assert len(r) in (5, 6), (f, r)
+            name, kind, tile, split, mp = r[0], int(r[1]), int(r[2]), int(r[3]), int(r[4])
+            assert name not in seen, (f, name)
+            seen.add(name)
+            base = ctypes.c_int(-1)
+            assert L.fdt_debug_conv_class(kind, tile, ctypes.byref(base)) == 1, "%s: %s names class %d tile %d, not instantiated" % (f, name, kind, tile)
+            assert split >= 1 and 0 <= mp < 8, (f, r)
+            if "downsample" in name and "layer1" not in name:
+                assert base.value == 1, (f, r)          # the stride-2 1x1 of pyramid.py:87-91
+        assert len(seen) >= 20, (f, len(seen))
+
+
 @pytest.fixture(scope="module")
 def oracle_threads():
     n = torch.get_num_threads()
