@@ -36,6 +36,7 @@ enum ConvKind {
   CONV_1x1_S2_B3,      // CONV_1x1_S2 with split-bf16 products (conv_b3.h, S = 2): the bottleneck's downsample branch
   CONV_7x7_S2_U8B,     // the raw-uint8 stems on the bf16 matrix pipe (conv_stem_u8b.h): a pixel minus an integer mean is exact in ONE
   CONV_7x7_S4_U8B,     // bf16, the weights carry three planes: three exact plane products per k-step, f32 accumulate.  ConvArgs.in_u8.
+  CONV_1x1_S1_PB3,     // CONV_1x1_S1_B3 as a persistent-tile kernel (conv_1x1p_b3.h): conv_1x1p.h's schedule, conv_b3.h's arithmetic and bits
   CONV_KIND_COUNT
 };
 
@@ -86,6 +87,8 @@ enum ConvTile {
   TILE_P_128x64,
   TILE_P_128x128,
   TILE_128x32W,        // 4x32 px, 32 ch (the u8 stem of FaceBoxes: 24 output channels)
+  // long-row tiles of the split-bf16 1x1 class (conv_b3.h, waves 4 x 1): 2x64 / 1x128 px -- 256 / 512 contiguous bytes per channel row
+  TILE_R2_128x128, TILE_R2_128x64, TILE_R1_128x128, TILE_R1_128x64,
   CONV_TILE_COUNT
 };
 

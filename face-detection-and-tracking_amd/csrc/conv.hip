@@ -191,6 +191,7 @@ struct Table {
     conv_fill_stem_b3(e[CONV_7x7_S4_B3]);
     conv_fill_1x1_s2_b3(e[CONV_1x1_S2_B3]);
     conv_fill_stem_u8b(e[CONV_7x7_S2_U8B], e[CONV_7x7_S4_U8B]);
+    conv_fill_1x1_pb3(e[CONV_1x1_S1_PB3]);
   }
 };
 
@@ -206,7 +207,7 @@ const ConvGeom kGeoms[CONV_KIND_COUNT] = {
     {7, 7, 2, 1, 1, 2, 0},  {3, 3, 1, 1, 1, 1, 0},  {3, 3, 1, 1, 1, 2, 2},  {3, 3, 1, 2, 2, 2, 2},
     {1, 1, 1, 1, 0, 16, 0}, {1, 1, 1, 1, 0, 32, 0}, {7, 7, 2, 1, 3, 4, 0},  {7, 7, 4, 1, 3, 3, 0},
     {7, 7, 4, 1, 3, 3, 0},  {1, 1, 1, 1, 0, 16, 0}, {7, 7, 4, 1, 3, 3, 0},  {1, 1, 2, 1, 0, 16, 0},
-    {7, 7, 2, 1, 3, 3, 0},  {7, 7, 4, 1, 3, 3, 0},
+    {7, 7, 2, 1, 3, 3, 0},  {7, 7, 4, 1, 3, 3, 0},  {1, 1, 1, 1, 0, 16, 0},
 };
 const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum ConvTile)
     {128, 128, 8, 16}, {128, 64, 8, 16}, {128, 32, 8, 16}, {64, 64, 8, 8},   {64, 128, 8, 8},
@@ -228,7 +229,9 @@ const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum 
     // persistent-tile 1x1
     {128, 64, 4, 32}, {128, 128, 4, 32},
     // 4x32 px, 32 ch
-    {128, 32, 4, 32}};
+    {128, 32, 4, 32},
+    // long-row tiles: 2x64, 1x128 px
+    {128, 128, 2, 64}, {128, 64, 2, 64}, {128, 128, 1, 128}, {128, 64, 1, 128}};
 
 }  // namespace
 
@@ -244,7 +247,8 @@ ConvKind conv_base_kind(ConvKind k) {
     case CONV_1x1_S1_K64:
     case CONV_1x1_S1_P16:
     case CONV_1x1_S1_P32:
-    case CONV_1x1_S1_B3: return CONV_1x1_S1;
+    case CONV_1x1_S1_B3:
+    case CONV_1x1_S1_PB3: return CONV_1x1_S1;
     case CONV_1x1_S2_B3: return CONV_1x1_S2;
     case CONV_7x7_S2_U8:
     case CONV_7x7_S2_U8B: return CONV_7x7_S2;
@@ -260,7 +264,7 @@ bool tile_is_wino(ConvTile t) {
 }
 bool tile_is_wino44(ConvTile t) { return t == TILE_WINO44_32x64 || t == TILE_WINO44B_32x64; }
 bool kind_is_u8b_stem(ConvKind k) { return k == CONV_7x7_S2_U8B || k == CONV_7x7_S4_U8B; }
-bool kind_is_persistent(ConvKind k) { return k == CONV_1x1_S1_P16 || k == CONV_1x1_S1_P32; }
+bool kind_is_persistent(ConvKind k) { return k == CONV_1x1_S1_P16 || k == CONV_1x1_S1_P32 || k == CONV_1x1_S1_PB3; }
 bool kind_is_u8_stem(ConvKind k) { return k == CONV_7x7_S2_U8 || k == CONV_7x7_S4_U8 || kind_is_u8b_stem(k); }
 static int device_cus(int dev) {
   static std::atomic<int> cus[16];
@@ -363,7 +367,7 @@ void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKin
         }
     return;
   }
-  if (kind == CONV_1x1_S1_B3 || kind == CONV_1x1_S2_B3) {
+  if (kind == CONV_1x1_S1_B3 || kind == CONV_1x1_S2_B3 || kind == CONV_1x1_S1_PB3) {
     // conv_b3.h: per (channel tile, stage of 16 input channels) [plane][k-half][BN couts][8 k] bf16 -- the three bf16 planes of
     // every BN-folded f32 weight, w = p0 + p1 + p2 exactly (each the round-to-nearest-even bf16 of the remainder) -- padded to
     // whole dwordx4 LDS-DMA rounds (LayoutB3::WSZP floats); couts past Cout and channels past Cin stay zero
@@ -523,7 +527,8 @@ bool conv_shape_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
   if (kind_is_persistent(kind)) {
     const int nstages = ceil_div(a.Cin, conv_geom(kind).kc);
     const long long hw = (long long)a.Hin * a.Win;
-    return (a.Win & 3) == 0 && a.ksplit <= 1 && !a.up && !a.sk_count && !a.ws && nstages >= 2 &&
+    // (the split-bf16 form runs its ring one stage further ahead -- operands of stage g + 1 are read under the MFMAs of stage g --: three stages)
+    return (a.Win & 3) == 0 && a.ksplit <= 1 && !a.up && !a.sk_count && !a.ws && nstages >= (kind == CONV_1x1_S1_PB3 ? 3 : 2) &&
            ((long long)a.Cout + 128) * hw * 4 < (1ll << 31) && (long long)a.Cin * hw * 4 < (1ll << 31);
   }
   return true;
@@ -607,7 +612,7 @@ int launch_conv(ConvKind kind, ConvTile tile, const ConvArgs& a_in, hipStream_t 
 #else
     const int env_r = 0;
 #endif
-    const int resident = env_r > 0 ? env_r : conv_1x1p_resident(tile);
+    const int resident = env_r > 0 ? env_r : kind == CONV_1x1_S1_PB3 ? conv_1x1pb3_resident(tile) : conv_1x1p_resident(tile);
     const long long slots = (long long)device_cus(dev) * resident;
     const int k = (int)ceil_div_ll(total, slots);
     a.tiles_per_wg = k;

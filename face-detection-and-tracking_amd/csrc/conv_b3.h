@@ -303,10 +303,10 @@ __global__ __launch_bounds__(256, (T::MI * T::NI >= 4) ? 2 : 3) void conv_b3_ker
   // four couts further) -- two whole 128-byte segments per store.  The plain epilogue then runs from the registers like conv_1x1p.h's:
   // no LDS transpose, no barriers (the short-reduction layers spend as long in the LDS epilogue as in their four to eight stages),
   // the residual of cout tile j + 1 in flight under the stores of tile j.  Same arithmetic: acc + bias, + residual, activation.
-  if constexpr (T::WM == 4 && T::WN == 1 && T::TH == 4 && T::TW == 32) {
+  if constexpr (T::WM == 4 && T::WN == 1 && T::TW % 32 == 0) {
     if (!raw && !a.up && !a.out2 && (long long)(a.Cout + 8) * HWout * 4 < (1ll << 31)) {      // kOob = 2^31 must stay out of range
       const unsigned hw4 = (unsigned)HWout * 4u;
-      const int gy = oy0 + wm, gx = ox0 + l31;
+      const int gy = oy0 + (wm * 32) / T::TW, gx = ox0 + (wm * 32) % T::TW + l31;      // the wave's 32 pixels: one row segment
       const unsigned voff = (gy < a.Hout && gx < a.Wout) ? (unsigned)(gy * a.Wout + gx) * 4u + (unsigned)(4 * half) * hw4 : kOob;
       const __amdgpu_buffer_rsrc_t ors = buf_rsrc(dst_b, (long long)a.Cout * HWout * 4);          // couts past Cout fall off the end
       const __amdgpu_buffer_rsrc_t rrs = buf_rsrc(res_b, res_b ? (long long)a.Cout * HWout * 4 : 0);
@@ -403,6 +403,11 @@ using TB3_128x64W = Tile<4, 32, 64, 2, 2, 3>;
 // (36 vector-ALU operations per stage and wave in place of 72, R5-11) at the price of every wave reading the whole weight stage
 using TB3_128x128W4 = Tile<4, 32, 128, 4, 1, 3>;
 using TB3_128x64W4 = Tile<4, 32, 64, 4, 1, 3>;
+// long rows: 2 x 64 and 1 x 128 pixels (256 / 512 contiguous bytes per channel row in the staging and in the stores)
+using TB3_R2_128 = Tile<2, 64, 128, 4, 1, 3>;
+using TB3_R2_64 = Tile<2, 64, 64, 4, 1, 3>;
+using TB3_R1_128 = Tile<1, 128, 128, 4, 1, 3>;
+using TB3_R1_64 = Tile<1, 128, 64, 4, 1, 3>;
 // (a ring of FOUR stages -- Tile<8, 16, BN, 4, 1, 4>, the kernel takes NBUF = 4 -- measured 3-20 % slower than these on every
 // backbone shape, docs/EXPERIMENTS.md R5-11: the class is not bound by LDS-DMA latency; not instantiated)
 

@@ -11,6 +11,10 @@ void conv_fill_1x1_b3(void* row) {
   r[TILE_128x64WR3] = entry_b3<TB3_128x64W>();
   r[TILE_128x128W] = entry_b3<TB3_128x128W4>();
   r[TILE_128x64W] = entry_b3<TB3_128x64W4>();
+  r[TILE_R2_128x128] = entry_b3<TB3_R2_128>();
+  r[TILE_R2_128x64] = entry_b3<TB3_R2_64>();
+  r[TILE_R1_128x128] = entry_b3<TB3_R1_128>();
+  r[TILE_R1_128x64] = entry_b3<TB3_R1_64>();
 }
 void conv_fill_1x1_s2_b3(void* row) {
   KernelEntry* r = (KernelEntry*)row;

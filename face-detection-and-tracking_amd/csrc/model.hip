@@ -479,9 +479,10 @@ struct Builder {
         conv_supported((ConvKind)hint->second.kind, (ConvTile)hint->second.tile) &&
         // the persistent 1x1 class has shape limits of its own (conv.hip: conv_shape_supported); a plan entry that does not
         // fit this layer is ignored like one for another shape
-        !(((ConvKind)hint->second.kind == CONV_1x1_S1_P16 || (ConvKind)hint->second.kind == CONV_1x1_S1_P32) &&
-          ((in.W & 3) || o.up_t >= 0 || hint->second.split != 1 ||
-           ceil_div(in.C, conv_geom((ConvKind)hint->second.kind).kc) < 2))) {
+        !(((ConvKind)hint->second.kind == CONV_1x1_S1_P16 || (ConvKind)hint->second.kind == CONV_1x1_S1_P32 ||
+           (ConvKind)hint->second.kind == CONV_1x1_S1_PB3) &&
+          ((in.W & 3) || o.up_t >= 0 || hint->second.split != 1 || (o.out2_t >= 0 && (ConvKind)hint->second.kind == CONV_1x1_S1_PB3) ||
+           ceil_div(in.C, conv_geom((ConvKind)hint->second.kind).kc) < ((ConvKind)hint->second.kind == CONV_1x1_S1_PB3 ? 3 : 2)))) {
       kind = (ConvKind)hint->second.kind;     // e.g. the Winograd implementation of a 3x3/s1 layer
       op.kind = kind;
       op.tile = (ConvTile)hint->second.tile;

@@ -411,7 +411,7 @@ def test_persistent_1x1_walks_tiles(variant, shape):
     assert rc == 0 and rel_err(got, reference(x, w, None, 1, 1, 0, 1)) < 1e-5
 
 
-@pytest.mark.parametrize("tile", [7, 8, 11, 12, 5, 6])    # class 21 (conv.h: CONV_1x1_S1_B3, conv_b3.h); 5, 6: waves 4 x 1
+@pytest.mark.parametrize("tile", [7, 8, 11, 12, 5, 6, 37, 38, 39, 40])    # class 21 (conv.h: CONV_1x1_S1_B3, conv_b3.h); 5, 6: waves 4 x 1; 37-40: long-row tiles
 @pytest.mark.parametrize("shape", [(1, 64, 64, 64, 256), (2, 40, 36, 48, 72), (1, 19, 27, 36, 45), (1, 1024, 32, 32, 256)])
 def test_split_bf16_1x1(tile, shape):
     """conv_b3.h: 1x1 convolution as split-bf16 products on v_mfma_f32_32x32x16_bf16 (three bf16 planes per operand, six plane
@@ -472,6 +472,37 @@ def test_split_bf16_1x1_stride2(tile, shape):
             assert got.shape == exp.shape and rel_err(got, exp) < 1e-5, (tile, shape, list(kw), split, rel_err(got, exp))
     rc, _ = run_conv(x[:, :, :, :W - 2].copy(), w, b, 1, 2, 0, 1, tile=v)      # Wout % 4 != 0: not this class
     assert rc != 0
+
+
+@pytest.mark.parametrize("tile", [34, 35])
+@pytest.mark.parametrize("shape", [(1, 64, 64, 64, 256), (2, 56, 36, 48, 72), (3, 147, 27, 36, 200), (1, 1024, 32, 32, 256), (4, 64, 128, 128, 64)])
+def test_persistent_split_bf16_1x1(tile, shape):
+    """Class 26 (conv.h: CONV_1x1_S1_PB3, conv_1x1p_b3.h): the split-bf16 1x1 convolution as a persistent-tile kernel -- a workgroup
+    walks consecutive output tiles, the LDS ring and the operand pipeline run across tile boundaries, register epilogue.  The same
+    products in the same order as class 21 (tiles 5 / 6, waves 4 x 1): BIT-identical outputs, with bias / residual / activations,
+    ragged tiles, channels past Cin, couts past Cout, several images (a workgroup's tile range crosses image boundaries); torch
+    tolerance 1e-5.  Refused: fewer than three stages, split-K, the fused upsample-add, W % 4 != 0."""
+    B, Cin, H, W, Cout = shape
+    rng = np.random.default_rng(tile * 1000 + Cin + B)
+    x = np.maximum(rng.standard_normal((B, Cin, H, W)), 0).astype(np.float32) * np.exp(rng.standard_normal((B, Cin, 1, 1))).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((B, Cout, H, W)).astype(np.float32)
+    v, v21 = 26 * 100 + tile, 21 * 100 + (6 if tile == 34 else 5)
+    for kw in (dict(res=res, act=1), dict(act=0), dict(act=2), dict(res=res, act=0)):
+        exp = reference(x, w, b, 1, 1, 0, 1, **kw)
+        rc, got = run_conv(x, w, b, 1, 1, 0, 1, tile=v, **kw)
+        assert rc == 0, lib().lib().fdt_last_error()
+        assert rel_err(got, exp) < 1e-5, (tile, shape, list(kw), rel_err(got, exp))
+        rc, same = run_conv(x, w, b, 1, 1, 0, 1, tile=v21, **kw)
+        assert rc == 0 and np.array_equal(got, same), (tile, shape, list(kw), float(np.abs(got - same).max()))
+    rc, got = run_conv(x, w, None, 1, 1, 0, 1, tile=v)                        # no bias
+    assert rc == 0 and rel_err(got, reference(x, w, None, 1, 1, 0, 1)) < 1e-5
+    up = rng.standard_normal((B, Cout, (H + 1) // 2, (W + 1) // 2)).astype(np.float32)
+    assert run_conv(x, w, b, 1, 1, 0, 1, tile=v, up=up)[0] != 0
+    assert run_conv(x, w, b, 1, 1, 0, 1, tile=v, split=2)[0] != 0
+    assert run_conv(x[:, :32].copy(), w[:, :32].copy(), b, 1, 1, 0, 1, tile=v)[0] != 0     # two stages
+    assert run_conv(x[:, :, :, :W - 1].copy(), w, b, 1, 1, 0, 1, tile=v)[0] != 0
 
 
 def test_persistent_1x1_refuses_what_it_is_not_built_for():

@@ -16,7 +16,7 @@ line = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1]) if len(sys.
 # (the command is run with --ungrouped-steps 0)
 G = (line["config"].get("frames_grouped_per_launch") or line["config"].get("batch_per_gpu") or 1) if line else 1
 frames = forwards * G
-conv = [r for r in rows if any(k in r["Name"] for k in ("conv_kernel", "conv_wino", "conv1x1p_kernel", "conv_stem_u8_kernel", "conv_stem_s4_kernel", "conv_n8_kernel", "conv_b3_kernel", "conv_stem_s4_b3_kernel", "conv_stem_u8b_kernel"))]
+conv = [r for r in rows if any(k in r["Name"] for k in ("conv_kernel", "conv_wino", "conv1x1p_kernel", "conv_stem_u8_kernel", "conv_stem_s4_kernel", "conv_n8_kernel", "conv_b3_kernel", "conv_stem_s4_b3_kernel", "conv_stem_u8b_kernel", "conv1x1p_b3_kernel"))]
 red = [r for r in rows if "splitk_reduce" in r["Name"]]
 tot = lambda rs: sum(float(r["TotalDurationNs"]) for r in rs)
 calls = lambda rs: sum(int(r["Calls"]) for r in rs)
