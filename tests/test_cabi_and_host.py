@@ -186,7 +186,9 @@ def test_bench_host_helpers_and_committed_plans():
     assert plan["conv2_SSH.conv1"][0] == 14 and plan["conv2_SSH.conv1"][1] in (32, 33)    # Winograd F(4x4,3x3)
     assert plan["conv2_SSH.conv2"][0] == 15 and plan["conv2_SSH.conv2"][1] == 32          # dilated F(4x4,3x3) on parity sub-lattices
     assert bench.kernel_label(14, 32).startswith("conv_wino44_kernel<3x3s1_wino44") and bench.WINO_RATIO[14] == 4.0
-    assert plan["layer1.1.conv3"][0] == 16 and plan["layer1.1.conv3"][2] == 1             # persistent-tile 1x1 on the 256^2 expand layers
+    # the HBM-heavy 256^2 expand layers: a 1x1 class without split-K (persistent f32 16, split-bf16 21, persistent split-bf16 26)
+    assert plan["layer1.1.conv3"][0] in (16, 21, 26) and plan["layer1.1.conv3"][2] == 1
+    assert bench.kernel_label(26, 35) == "conv1x1p_b3_kernel<1x1s1_pb3, tile 35>" and bench.kernel_label(24, 6).startswith("conv_stem_u8b_kernel<7x7s2_u8b")
     assert len(plan) == 105                                                               # every conv layer of Res50
     sh = open(os.path.join(ROOT, "tools", "refresh_profiles.sh")).read()
     assert all(("plan_of " + layer) in sh for layer in ("conv2_SSH.conv1", "conv2_SSH.conv2", "layer3.1.conv1", "layer1.0.conv3"))
