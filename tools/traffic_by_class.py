@@ -19,7 +19,7 @@ KIND = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2", 
 TILE = ["128x128", "128x64", "128x32", "64x64", "64x128", "128x128W", "128x64W", "128x128R3", "128x64R3", "64x64R3", "64x128R3",
         "128x128WR3", "128x64WR3", "128x32R3", "w64x64", "w64x64R3", "w128x32", "w128x32R3", "w32x128", "w32x128R3", "w64x64W",
         "w8_64x64", "w8_64x64R3", "w8_128x32R3", "w8_64x64W", "128x128R4", "128x64R4", "64x64R4", "64x128R4", "w4_64x64R3",
-        "w4_64x64W", "n8_32x64", "w44_32x64", "w44b_32x64", "p128x64", "p128x128", "128x32W"]
+        "w4_64x64W", "n8_32x64", "w44_32x64", "w44b_32x64", "p128x64", "p128x128", "128x32W", "r2_128x128", "r2_128x64", "r1_128x128", "r1_128x64"]
 
 
 def is_conv(n):
