@@ -582,7 +582,7 @@ def test_try3_with_fused_inverted_residual_heads(try3_sd, synth, monkeypatch):
     assert n > 5 and d_iou <= BOX_IOU_TOL and d_sc <= SCORE_ATOL
 
 
-@pytest.mark.parametrize("H,W,B", [(136, 200, 1), (256, 256, 2), (480, 640, 1), (100, 202, 1)])
+@pytest.mark.parametrize("H,W,B", [(136, 200, 1), (256, 256, 2), (480, 640, 1), (100, 202, 1), (101, 36, 3), (67, 132, 1)])
 def test_raw_frame_stem_on_the_bf16_pipe(res50_sd, synth, H, W, B):
     """conv_stem_u8b.h (class 24 = CONV_7x7_S2_U8B, the default raw-frame stem where W % 4 == 0): (float)u8 - mean is an integer of
     magnitude <= 255, exact in ONE bf16; the weights are split into three bf16 planes; three exact plane products per k-step, f32
