@@ -31,10 +31,10 @@ if ROOT not in sys.path:
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 (v_mfma_f32_32x32x16_bf16: 1024 FLOP/clk/SIMD at 2.4 GHz)
-B3_KINDS = (21, 23, 26)             # conv.h: CONV_1x1_S1_B3, CONV_1x1_S2_B3 -- split-bf16 products, SIX bf16 MFMA FLOPs per algorithmic f32 FLOP
+B3_KINDS = (21, 23, 26, 27)           # conv.h: CONV_1x1_S1_B3, CONV_1x1_S2_B3 -- split-bf16 products, SIX bf16 MFMA FLOPs per algorithmic f32 FLOP
 # kernels on the bf16 matrix pipe: executed bf16 MFMA FLOPs per algorithmic f32 FLOP.  24 = CONV_7x7_S2_U8B (conv_stem_u8b.h): the
 # pixels are exact in ONE bf16 plane, the weights carry three -> 3 plane products, K = 147 padded to 176
-BF16_MULT = {21: 6.0, 23: 6.0, 26: 6.0, 24: 3.0 * 176.0 / 147.0, 25: 3.0 * 176.0 / 147.0 * 32.0 / 24.0}
+BF16_MULT = {21: 6.0, 23: 6.0, 26: 6.0, 27: 6.0, 24: 3.0 * 176.0 / 147.0, 25: 3.0 * 176.0 / 147.0 * 32.0 / 24.0}
 
 
 def facebox_main(args, rank=0, local_rank=0, world=1):
@@ -319,7 +319,7 @@ def facebox_main(args, rank=0, local_rank=0, world=1):
 
 
 KIND_NAMES = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2", "3x3s1_wino", "3x3d2_wino", "1x1s1_k32",
-              "1x1s1_k64", "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44", "1x1s1_p16", "1x1s1_p32", "7x7s2_u8", "7x7s4_u8", "7x7s4_k168", "1x1s1_b3", "7x7s4_b3", "1x1s2_b3", "7x7s2_u8b", "7x7s4_u8b", "1x1s1_pb3"]
+              "1x1s1_k64", "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44", "1x1s1_p16", "1x1s1_p32", "7x7s2_u8", "7x7s4_u8", "7x7s4_k168", "1x1s1_b3", "7x7s4_b3", "1x1s2_b3", "7x7s2_u8b", "7x7s4_u8b", "1x1s1_pb3", "3x3s2_b3"]
 WINO_KINDS = (8, 9, 14, 15)   # conv.h: Winograd kinds execute fewer MACs than the direct form:
 WINO_RATIO = {8: 2.25, 9: 2.25, 14: 4.0, 15: 4.0}   # F(2x2,3x3) 16/36 of them, F(4x4,3x3) (CONV_3x3_{S1,D2}_WINO44) 36/144
 

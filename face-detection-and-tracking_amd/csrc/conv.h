@@ -37,6 +37,7 @@ enum ConvKind {
   CONV_7x7_S2_U8B,     // the raw-uint8 stems on the bf16 matrix pipe (conv_stem_u8b.h): a pixel minus an integer mean is exact in ONE
   CONV_7x7_S4_U8B,     // bf16, the weights carry three planes: three exact plane products per k-step, f32 accumulate.  ConvArgs.in_u8.
   CONV_1x1_S1_PB3,     // CONV_1x1_S1_B3 as a persistent-tile kernel (conv_1x1p_b3.h): conv_1x1p.h's schedule, conv_b3.h's arithmetic and bits
+  CONV_3x3_S2_B3,      // CONV_3x3_S2 (padding 1) with split-bf16 products (conv_b3.h, KS = 3): nine tap stages per 16-channel group
   CONV_KIND_COUNT
 };
 

@@ -192,6 +192,7 @@ struct Table {
     conv_fill_1x1_s2_b3(e[CONV_1x1_S2_B3]);
     conv_fill_stem_u8b(e[CONV_7x7_S2_U8B], e[CONV_7x7_S4_U8B]);
     conv_fill_1x1_pb3(e[CONV_1x1_S1_PB3]);
+    conv_fill_3x3_s2_b3(e[CONV_3x3_S2_B3]);
   }
 };
 
@@ -207,7 +208,7 @@ const ConvGeom kGeoms[CONV_KIND_COUNT] = {
     {7, 7, 2, 1, 1, 2, 0},  {3, 3, 1, 1, 1, 1, 0},  {3, 3, 1, 1, 1, 2, 2},  {3, 3, 1, 2, 2, 2, 2},
     {1, 1, 1, 1, 0, 16, 0}, {1, 1, 1, 1, 0, 32, 0}, {7, 7, 2, 1, 3, 4, 0},  {7, 7, 4, 1, 3, 3, 0},
     {7, 7, 4, 1, 3, 3, 0},  {1, 1, 1, 1, 0, 16, 0}, {7, 7, 4, 1, 3, 3, 0},  {1, 1, 2, 1, 0, 16, 0},
-    {7, 7, 2, 1, 3, 3, 0},  {7, 7, 4, 1, 3, 3, 0},  {1, 1, 1, 1, 0, 16, 0},
+    {7, 7, 2, 1, 3, 3, 0},  {7, 7, 4, 1, 3, 3, 0},  {1, 1, 1, 1, 0, 16, 0},  {3, 3, 2, 1, 1, 16, 0},
 };
 const int kTileDims[CONV_TILE_COUNT][4] = {  // BM, BN, TH, TW   (order of enum ConvTile)
     {128, 128, 8, 16}, {128, 64, 8, 16}, {128, 32, 8, 16}, {64, 64, 8, 8},   {64, 128, 8, 8},
@@ -250,6 +251,7 @@ ConvKind conv_base_kind(ConvKind k) {
     case CONV_1x1_S1_B3:
     case CONV_1x1_S1_PB3: return CONV_1x1_S1;
     case CONV_1x1_S2_B3: return CONV_1x1_S2;
+    case CONV_3x3_S2_B3: return CONV_3x3_S2;
     case CONV_7x7_S2_U8:
     case CONV_7x7_S2_U8B: return CONV_7x7_S2;
     case CONV_7x7_S4_U8:
@@ -365,6 +367,42 @@ void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKin
           for (int pp = 0; pp < 3; ++pp)
             o16[(size_t)(co / 32) * 16896 + ((((size_t)pp * 11 + q / 2) * 2 + q % 2) * 32 + co % 32) * 8 + kx + 1] = pl[pp];
         }
+    return;
+  }
+  if (kind == CONV_3x3_S2_B3) {
+    // conv_b3.h, KS = 3: per (channel tile, 16-channel group, tap) [plane][k-half][BN couts][8 k] bf16 -- the 1x1 class's stage with the
+    // group's weights of ONE tap; couts past Cout and channels past Cin stay zero
+    const size_t wszp_b3 = ((size_t)24 * BN + 1023) / 1024 * 1024;
+    out.assign((size_t)n_tiles * nstages * 9 * wszp_b3, 0.0f);
+    unsigned short* o16 = reinterpret_cast<unsigned short*>(out.data());
+    auto bf16_rne = [](float x) -> unsigned short {
+      unsigned u;
+      memcpy(&u, &x, 4);
+      u += 0x7fffu + ((u >> 16) & 1u);
+      return (unsigned short)(u >> 16);
+    };
+    auto bf16_f32 = [](unsigned short h) -> float {
+      const unsigned u = (unsigned)h << 16;
+      float f;
+      memcpy(&f, &u, 4);
+      return f;
+    };
+    for (int co = 0; co < Cout; ++co) {
+      const float sc = scale ? scale[co] : 1.0f;
+      for (int ci = 0; ci < Cin; ++ci)
+        for (int t = 0; t < 9; ++t) {
+          const float wv = w[((size_t)co * Cin + ci) * 9 + t] * sc;
+          const unsigned short p0 = bf16_rne(wv);
+          const float r1 = wv - bf16_f32(p0);
+          const unsigned short p1 = bf16_rne(r1);
+          const unsigned short p2 = bf16_rne(r1 - bf16_f32(p1));
+          const unsigned short pl[3] = {p0, p1, p2};
+          const size_t st = ((size_t)(co / BN) * nstages + ci / 16) * 9 + t;
+          const int kk = ci % 16, h = kk / 8, q = kk % 8;
+          for (int pp = 0; pp < 3; ++pp)
+            o16[st * wszp_b3 * 2 + (((size_t)pp * 2 + h) * BN + co % BN) * 8 + q] = pl[pp];
+        }
+    }
     return;
   }
   if (kind == CONV_1x1_S1_B3 || kind == CONV_1x1_S2_B3 || kind == CONV_1x1_S1_PB3) {
@@ -497,7 +535,7 @@ bool conv_combine_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
 static bool kind_is_direct(ConvKind k) {
   return k == CONV_1x1_S1 || k == CONV_1x1_S2 || k == CONV_3x3_S1 || k == CONV_3x3_S1_D2 || k == CONV_3x3_S2 || k == CONV_7x7_S2 ||
          k == CONV_7x7_S4 || k == CONV_5x5_S2 || k == CONV_1x1_S1_K32 || k == CONV_1x1_S1_K64 || k == CONV_7x7_S2_P1 ||
-         k == CONV_1x1_S1_B3 || k == CONV_1x1_S2_B3;       // conv_b3.h carries the same epilogue
+         k == CONV_1x1_S1_B3 || k == CONV_1x1_S2_B3 || k == CONV_3x3_S2_B3;       // conv_b3.h carries the same epilogue
 }
 
 bool conv_shape_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
@@ -522,7 +560,7 @@ bool conv_shape_supported(ConvKind kind, ConvTile tile, const ConvArgs& a) {
            (long long)(a.Cout + 64) * a.Hout * a.Wout * 4 < (1ll << 31);
   if (kind == CONV_1x1_S1_B3)      // 16-byte activation staging and the vector epilogue only
     return (a.Win & 3) == 0 && (long long)(a.Cout + 128) * a.Hout * a.Wout * 4 < (1ll << 40);
-  if (kind == CONV_1x1_S2_B3)      // the vector epilogue only
+  if (kind == CONV_1x1_S2_B3 || kind == CONV_3x3_S2_B3)      // the vector epilogue only
     return (a.Wout & 3) == 0 && (long long)(a.Cout + 128) * a.Hout * a.Wout * 4 < (1ll << 40);
   if (kind_is_persistent(kind)) {
     const int nstages = ceil_div(a.Cin, conv_geom(kind).kc);

@@ -23,6 +23,9 @@
 //   * epilogue: the f32 class's (bias, fused bilinear x2 upsample-add, residual, ReLU / ReLU6, second destination, split-K slabs).
 // Needs Win % 4 == 0 (16-byte activation staging).  Channels past Cin read as zeros (buffer bounds), weights are zero there.
 // S = 2 (class CONV_1x1_S2_B3): the same kernel with a dword gather of every second pixel in the staging (Wout % 4 == 0).
+// KS = 3 (class CONV_3x3_S2_B3: 3x3 / stride 2 / padding 1, pyramid.py:99 in the first block of layer2-4): nine stages per 16-channel
+// group, one per tap -- the gather of tap (ky, kx) is the centre tap's plus a constant, pixels in the padding carry the out-of-range
+// offset (LDS-DMA writes zeros); split-K cuts between channel groups.
 #pragma once
 #include "conv_kernel.h"
 
@@ -87,9 +90,11 @@ __device__ __forceinline__ void lds_read_b128(bf16x8& v, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
 }
 
-template <class T, int S = 1>
+template <class T, int S = 1, int KS = 1>
 __global__ __launch_bounds__(256, (T::MI * T::NI >= 4) ? 2 : 3) void conv_b3_kernel(const ConvArgs a) {
   using L = LayoutB3<T, S>;
+  constexpr int KK = KS * KS;                  // LDS stages per 16-channel group: one per tap (3x3 / stride 2: class CONV_3x3_S2_B3)
+  static_assert(KS == 1 || (KS == 3 && S == 2), "1x1 (stride 1, 2) and 3x3 / stride 2 / padding 1");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
@@ -109,15 +114,16 @@ __global__ __launch_bounds__(256, (T::MI * T::NI >= 4) ? 2 : 3) void conv_b3_ker
   const int HWout = a.Hout * a.Wout;
   const float* in_b = a.in + (long long)b * conv_in_bstride(a);
   const int nstages = (a.Cin + L::KC - 1) / L::KC;
-  const float* w_t = a.w + (long long)n_tile * nstages * L::WSZP;
-  const int s_begin = (int)((long long)nstages * ks / a.ksplit);
-  const int s_end = (int)((long long)nstages * (ks + 1) / a.ksplit);
+  const float* w_t = a.w + (long long)n_tile * nstages * KK * L::WSZP;
+  const int s_begin = (int)((long long)nstages * ks / a.ksplit) * KK;       // split-K cuts between channel groups
+  const int s_end = (int)((long long)nstages * (ks + 1) / a.ksplit) * KK;
 
   // staging plan.  Stride 1: float4 v = 256 * k + tid covers 4 consecutive pixels of one tile row of one channel of the stage;
   // stride 2 (the bottleneck's downsample branch): dword v = 256 * k + tid is ONE pixel, every second one of every second row
   const __amdgpu_buffer_rsrc_t xrs = buf_rsrc(in_b, (long long)a.Cin * HWin * 4);
   const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(w_t, 0x7fffffffll);
   unsigned xoff[L::NXV];
+  unsigned xfl[KS == 3 ? L::NXV : 1];          // 3x3: which taps of this pixel fall into the padding (bits: 1 top, 2 bottom, 4 left, 8 right, 16 no pixel)
 #pragma unroll
   for (int k = 0; k < L::NXV; ++k) {
     const int v = tid + 256 * k;
@@ -132,18 +138,31 @@ __global__ __launch_bounds__(256, (T::MI * T::NI >= 4) ? 2 : 3) void conv_b3_ker
       const int p = v - c * T::BM;
       const int oy = oy0 + p / T::TW, ox = ox0 + p % T::TW;
       const bool ok = oy < a.Hout && ox < a.Wout;
-      xoff[k] = ok ? (unsigned)(c * HWin + oy * S * a.Win + ox * S) * 4u : kOob;
+      if constexpr (KS == 1) {
+        xoff[k] = ok ? (unsigned)(c * HWin + oy * S * a.Win + ox * S) * 4u : kOob;
+      } else {      // the CENTRE tap's pixel (2 oy, 2 ox): always inside the image for a valid output pixel (padding 1)
+        xoff[k] = (unsigned)(c * HWin + oy * S * a.Win + ox * S) * 4u;
+        xfl[k] = (oy == 0 ? 1u : 0u) | (oy * S + 1 >= a.Hin ? 2u : 0u) | (ox == 0 ? 4u : 0u) | (ox * S + 1 >= a.Win ? 8u : 0u) | (ok ? 0u : 16u);
+      }
     }
   }
 #define FDT_B3_STAGE(s_, buf_)                                                                            \
   {                                                                                                       \
-    const unsigned xso_ = (unsigned)((s_) * L::KC) * (unsigned)HWin * 4u;                                 \
+    const int cg_ = (s_) / KK, tap_ = (s_) - cg_ * KK;         /* 16-channel group, tap (1x1: the stage itself, 0) */ \
+    const unsigned xso_ = (unsigned)(cg_ * L::KC) * (unsigned)HWin * 4u;                                  \
     if constexpr (S == 1) {                                                                               \
       float* X_ = smem + (buf_) * L::STAGE + wave * 256;                                                  \
       _Pragma("unroll") for (int k = 0; k < L::NXV; ++k) bglds16(xrs, X_ + 1024 * k, xoff[k], xso_);      \
-    } else {                                                                                              \
+    } else if constexpr (KS == 1) {                                                                       \
       float* X_ = smem + (buf_) * L::STAGE + wave * 64;                                                   \
       _Pragma("unroll") for (int k = 0; k < L::NXV; ++k) bglds4(xrs, X_ + 256 * k, xoff[k], xso_);        \
+    } else {                                                                                              \
+      const int ky_ = tap_ / 3, kx_ = tap_ - 3 * ky_;                                                     \
+      const int dl_ = ((ky_ - 1) * a.Win + (kx_ - 1)) * 4;                                                \
+      const unsigned tm_ = 16u | (ky_ == 0 ? 1u : 0u) | (ky_ == 2 ? 2u : 0u) | (kx_ == 0 ? 4u : 0u) | (kx_ == 2 ? 8u : 0u); \
+      float* X_ = smem + (buf_) * L::STAGE + wave * 64;                                                   \
+      _Pragma("unroll") for (int k = 0; k < L::NXV; ++k)                                                  \
+          bglds4(xrs, X_ + 256 * k, (xfl[k] & tm_) ? kOob : xoff[k] + (unsigned)dl_, xso_);               \
     }                                                                                                     \
     const unsigned wso_ = (unsigned)((s_) * L::WSZP) * 4u;                                                \
     float* W_ = smem + (buf_) * L::STAGE + L::XSZ + wave * 256;                                           \
@@ -411,9 +430,9 @@ using TB3_R1_64 = Tile<1, 128, 64, 4, 1, 3>;
 // (a ring of FOUR stages -- Tile<8, 16, BN, 4, 1, 4>, the kernel takes NBUF = 4 -- measured 3-20 % slower than these on every
 // backbone shape, docs/EXPERIMENTS.md R5-11: the class is not bound by LDS-DMA latency; not instantiated)
 
-template <class T, int S = 1>
+template <class T, int S = 1, int KS = 1>
 KernelEntry entry_b3() {
-  return KernelEntry{conv_b3_kernel<T, S>, LayoutB3<T, S>::LDS_BYTES, 256};
+  return KernelEntry{conv_b3_kernel<T, S, KS>, LayoutB3<T, S>::LDS_BYTES, 256};
 }
 
 }  // namespace

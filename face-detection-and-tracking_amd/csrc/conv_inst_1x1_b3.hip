@@ -21,6 +21,11 @@ void conv_fill_1x1_s2_b3(void* row) {
   r[TILE_128x128W] = entry_b3<TB3_128x128W4, 2>();
   r[TILE_128x64W] = entry_b3<TB3_128x64W4, 2>();
 }
+void conv_fill_3x3_s2_b3(void* row) {
+  KernelEntry* r = (KernelEntry*)row;
+  r[TILE_128x128W] = entry_b3<TB3_128x128W4, 2, 3>();
+  r[TILE_128x64W] = entry_b3<TB3_128x64W4, 2, 3>();
+}
 void conv_fill_stem_b3(void* row) {
   KernelEntry* r = (KernelEntry*)row;
   r[TILE_128x32W] = entry_stem_s4_b3();

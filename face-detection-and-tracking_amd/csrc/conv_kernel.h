@@ -492,6 +492,7 @@ void conv_fill_n8(void* row);   // conv_n8.h
 void conv_fill_stems(void* row_7x7_s2, void* row_7x7_s4, void* row_5x5_s2, void* row_7x7_s2_p1);
 void conv_fill_1x1_b3(void* row);   // conv_b3.h
 void conv_fill_1x1_s2_b3(void* row);
+void conv_fill_3x3_s2_b3(void* row);
 void conv_fill_stem_b3(void* row);  // conv_stem_b3.h
 void conv_fill_stem_u8b(void* row_s2, void* row_s4);  // conv_stem_u8b.h
 void conv_fill_1x1_pb3(void* row);                    // conv_1x1p_b3.h

@@ -505,6 +505,41 @@ def test_persistent_split_bf16_1x1(tile, shape):
     assert run_conv(x[:, :, :, :W - 1].copy(), w, b, 1, 1, 0, 1, tile=v)[0] != 0
 
 
+@pytest.mark.parametrize("tile", [5, 6])
+@pytest.mark.parametrize("shape", [(1, 64, 64, 64, 128), (2, 40, 35, 47, 72), (1, 19, 27, 39, 45), (1, 128, 32, 32, 128), (2, 256, 16, 16, 256)])
+def test_split_bf16_3x3_stride2(tile, shape):
+    """Class 27 (conv.h: CONV_3x3_S2_B3): the 3x3 / stride-2 / padding-1 convolution of the first bottleneck of layer2-4
+    (pyramid.py:99) as split-bf16 products -- conv_b3.h with nine tap stages per 16-channel group, the gather of a tap = the centre
+    tap's offsets plus a constant, padding as out-of-range offsets.  Torch tolerance 1e-5 (the f32 class's), every image border
+    (odd and even input sizes), channels past Cin, couts past Cout, bias / residual / activation, split-K between channel groups;
+    error against an f64 convolution not above the f32 class's; Wout % 4 != 0 is refused."""
+    B, Cin, H, W, Cout = shape
+    rng = np.random.default_rng(tile * 1000 + Cin + 3)
+    x = np.maximum(rng.standard_normal((B, Cin, H, W)), 0).astype(np.float32) * np.exp(rng.standard_normal((B, Cin, 1, 1))).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    res = rng.standard_normal((B, Cout, Ho, Wo)).astype(np.float32)
+    v = 27 * 100 + tile
+    for kw in (dict(act=1), dict(res=res, act=0), dict(act=2)):
+        exp = reference(x, w, b, 3, 2, 1, 1, **kw)
+        for split in (1, 2, 4):
+            if split > (Cin + 15) // 16:
+                continue
+            rc, got = run_conv(x, w, b, 3, 2, 1, 1, tile=v, split=split, **kw)
+            assert rc == 0, lib().lib().fdt_last_error()
+            assert got.shape == exp.shape and rel_err(got, exp) < 1e-5, (tile, shape, list(kw), split, rel_err(got, exp))
+    ref64 = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), 2, 1).numpy()
+    rc, got = run_conv(x, w, b, 3, 2, 1, 1, tile=v)
+    rc2, f32 = run_conv(x, w, b, 3, 2, 1, 1, tile=1)          # the f32-MFMA class of the same layer
+    assert rc == 0 and rc2 == 0
+    e_b3 = float(np.sqrt(((got - ref64) ** 2).mean()) / np.sqrt((ref64 ** 2).mean()))
+    e_f32 = float(np.sqrt(((f32 - ref64) ** 2).mean()) / np.sqrt((ref64 ** 2).mean()))
+    assert e_b3 <= 1.5 * e_f32 + 1e-7, (e_b3, e_f32)
+    rc, _ = run_conv(x[:, :, :, :W - 2].copy(), w, b, 3, 2, 1, 1, tile=v)      # Wout % 4 != 0: not this class
+    assert rc != 0
+
+
 def test_persistent_1x1_refuses_what_it_is_not_built_for():
     rng = np.random.default_rng(5)
     x = rng.standard_normal((1, 40, 20, 30)).astype(np.float32)           # W % 4 != 0

@@ -10,12 +10,12 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lib = importlib.import_module("face-detection-and-tracking_amd._lib")
-KIND = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2", "3x3wino", "3x3d2wino", "1x1k32", "1x1k64", "7x7s2p1", "3x3n8", "3x3wino44", "3x3d2wino44", "1x1p16", "1x1p32", "7x7s2u8", "7x7s4u8", "7x7s4k168", "1x1b3", "7x7s4b3", "1x1s2b3", "7x7s2u8b", "7x7s4u8b", "1x1pb3"]
+KIND = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2", "3x3wino", "3x3d2wino", "1x1k32", "1x1k64", "7x7s2p1", "3x3n8", "3x3wino44", "3x3d2wino44", "1x1p16", "1x1p32", "7x7s2u8", "7x7s4u8", "7x7s4k168", "1x1b3", "7x7s4b3", "1x1s2b3", "7x7s2u8b", "7x7s4u8b", "1x1pb3", "3x3s2b3"]
 TILE = ["128x128", "128x64", "128x32", "64x64", "64x128", "128x128W", "128x64W", "128x128R3", "128x64R3",
         "64x64R3", "64x128R3", "128x128WR3", "128x64WR3", "128x32R3", "w64x64", "w64x64R3", "w128x32", "w128x32R3",
         "w32x128", "w32x128R3", "w64x64W", "w8_64x64", "w8_64x64R3", "w8_128x32R3", "w8_64x64W", "128x128R4", "128x64R4", "64x64R4", "64x128R4", "w4_64x64R3", "w4_64x64W", "n8_32x64", "w44_32x64", "w44b_32x64", "p128x64", "p128x128", "128x32W", "r2_128x128", "r2_128x64", "r1_128x128", "r1_128x64"]
-GEOM = {0: (1, 1), 1: (1, 2), 2: (3, 1), 3: (3, 1), 4: (3, 2), 5: (7, 2), 6: (7, 4), 7: (5, 2), 8: (3, 1), 9: (3, 1), 10: (1, 1), 11: (1, 1), 12: (7, 2), 13: (3, 1), 14: (3, 1), 15: (3, 1), 16: (1, 1), 17: (1, 1), 18: (7, 2), 19: (7, 4), 20: (7, 4), 21: (1, 1), 22: (7, 4), 23: (1, 2), 24: (7, 2), 25: (7, 4), 26: (1, 1)}
-KC = {0: 16, 1: 16, 2: 4, 3: 4, 4: 4, 5: 2, 6: 2, 7: 2, 8: 8, 9: 8, 10: 32, 11: 64, 12: 2, 13: 1, 14: 2, 15: 2, 16: 16, 17: 32, 18: 4, 19: 3, 20: 3, 21: 16, 22: 3, 23: 16, 24: 3, 25: 3, 26: 16}
+GEOM = {0: (1, 1), 1: (1, 2), 2: (3, 1), 3: (3, 1), 4: (3, 2), 5: (7, 2), 6: (7, 4), 7: (5, 2), 8: (3, 1), 9: (3, 1), 10: (1, 1), 11: (1, 1), 12: (7, 2), 13: (3, 1), 14: (3, 1), 15: (3, 1), 16: (1, 1), 17: (1, 1), 18: (7, 2), 19: (7, 4), 20: (7, 4), 21: (1, 1), 22: (7, 4), 23: (1, 2), 24: (7, 2), 25: (7, 4), 26: (1, 1), 27: (3, 2)}
+KC = {0: 16, 1: 16, 2: 4, 3: 4, 4: 4, 5: 2, 6: 2, 7: 2, 8: 8, 9: 8, 10: 32, 11: 64, 12: 2, 13: 1, 14: 2, 15: 2, 16: 16, 17: 32, 18: 4, 19: 3, 20: 3, 21: 16, 22: 3, 23: 16, 24: 3, 25: 3, 26: 16, 27: 16}
 
 
 def bench(kind, tile, split, cin, h, w, cout, res=0, up=0, iters=20, B=1):

@@ -15,7 +15,7 @@ import os
 import sys
 
 KIND = ["1x1s1", "1x1s2", "3x3s1", "3x3d2", "3x3s2", "7x7s2", "7x7s4", "5x5s2", "3x3s1_wino", "3x3d2_wino", "1x1s1_k32", "1x1s1_k64",
-        "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44", "1x1s1_p16", "1x1s1_p32", "7x7s2_u8", "7x7s4_u8", "7x7s4_k168", "1x1s1_b3", "7x7s4_b3", "1x1s2_b3", "7x7s2_u8b", "7x7s4_u8b", "1x1s1_pb3"]
+        "7x7s2p1", "3x3s1_n8", "3x3s1_wino44", "3x3d2_wino44", "1x1s1_p16", "1x1s1_p32", "7x7s2_u8", "7x7s4_u8", "7x7s4_k168", "1x1s1_b3", "7x7s4_b3", "1x1s2_b3", "7x7s2_u8b", "7x7s4_u8b", "1x1s1_pb3", "3x3s2_b3"]
 TILE = ["128x128", "128x64", "128x32", "64x64", "64x128", "128x128W", "128x64W", "128x128R3", "128x64R3", "64x64R3", "64x128R3",
         "128x128WR3", "128x64WR3", "128x32R3", "w64x64", "w64x64R3", "w128x32", "w128x32R3", "w32x128", "w32x128R3", "w64x64W",
         "w8_64x64", "w8_64x64R3", "w8_128x32R3", "w8_64x64W", "128x128R4", "128x64R4", "64x64R4", "64x128R4", "w4_64x64R3",
