@@ -1214,8 +1214,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": ("f32" if not (roof and roof.get("split_bf16")) else
-                      "f32 (f32 in / f32 out everywhere; 3x3 and head convolutions on the f32 MFMA; %d launches per forward on the "
-                      "bf16 matrix pipe with f32 accumulate: the 1x1 convolutions as split-bf16 products -- three bf16 planes per f32 "
+                      "f32 (f32 in / f32 out everywhere; stride-1 3x3 (Winograd) and head convolutions in f32 arithmetic; %d launches per forward on the "
+                      "bf16 matrix pipe with f32 accumulate: the 1x1 and 3x3 / stride-2 convolutions as split-bf16 products -- three bf16 planes per f32 "
                       "operand, six plane products, the f32 MFMA's error against f64 -- and (Res50) the 7x7 stem on the raw uint8 frame, "
                       "whose pixels minus the integer means are exact in one bf16 plane)" % roof["split_bf16"]["launches_per_forward"]),
             "data": "synthetic",
