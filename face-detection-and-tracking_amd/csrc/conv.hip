@@ -284,6 +284,27 @@ int tile_tw(ConvTile t) { return kTileDims[t][3]; }
 bool conv_supported(ConvKind kind, ConvTile tile) { return table().e[kind][tile].fn != nullptr; }
 size_t conv_lds_bytes(ConvKind kind, ConvTile tile) { return table().e[kind][tile].lds; }
 
+// A finite f32 as three bf16 planes, x = p[0] + p[1] + p[2] exactly (each the round-to-nearest-even bf16 of the remainder): the
+// host-side split of the weights of every bf16-pipe class (conv_b3.h: split3_bf16 is the device form)
+static void split3_bf16_host(float x, unsigned short p[3]) {
+  auto rne = [](float v) -> unsigned short {
+    unsigned u;
+    memcpy(&u, &v, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+  };
+  auto widen = [](unsigned short h) -> float {
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+  };
+  p[0] = rne(x);
+  const float r1 = x - widen(p[0]);
+  p[1] = rne(r1);
+  p[2] = rne(r1 - widen(p[1]));
+}
+
 void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKind kind, ConvTile tile,
                   std::vector<float>& out) {
   const ConvGeom g = conv_geom(kind);
@@ -311,27 +332,12 @@ void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKin
     out.assign((size_t)groups * 8448, 0.0f);
     if (Cin != 3 || BN % 32) return;
     unsigned short* o16 = reinterpret_cast<unsigned short*>(out.data());
-    auto bf16_rne = [](float x) -> unsigned short {
-      unsigned u;
-      memcpy(&u, &x, 4);
-      u += 0x7fffu + ((u >> 16) & 1u);
-      return (unsigned short)(u >> 16);
-    };
-    auto bf16_f32 = [](unsigned short h) -> float {
-      const unsigned u = (unsigned)h << 16;
-      float f;
-      memcpy(&f, &u, 4);
-      return f;
-    };
     for (int co = 0; co < Cout; ++co)
       for (int q = 0; q < 21; ++q)
         for (int kx = 0; kx < 7; ++kx) {
           const float wv = w[((size_t)co * 3 + q / 7) * 49 + (q % 7) * 7 + kx] * (scale ? scale[co] : 1.0f);
-          const unsigned short p0 = bf16_rne(wv);
-          const float r1 = wv - bf16_f32(p0);
-          const unsigned short p1 = bf16_rne(r1);
-          const unsigned short p2 = bf16_rne(r1 - bf16_f32(p1));
-          const unsigned short pl[3] = {p0, p1, p2};
+          unsigned short pl[3];
+          split3_bf16_host(wv, pl);
           for (int pp = 0; pp < 3; ++pp)
             o16[(size_t)(co / 32) * 16896 + ((((size_t)(q / 2) * 3 + pp) * 2 + q % 2) * 32 + co % 32) * 8 + kx + 1] = pl[pp];
         }
@@ -343,27 +349,12 @@ void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKin
     out.assign((size_t)n_tiles * 8448, 0.0f);
     if (Cin != 3 || BN != 32) return;
     unsigned short* o16 = reinterpret_cast<unsigned short*>(out.data());
-    auto bf16_rne = [](float x) -> unsigned short {
-      unsigned u;
-      memcpy(&u, &x, 4);
-      u += 0x7fffu + ((u >> 16) & 1u);
-      return (unsigned short)(u >> 16);
-    };
-    auto bf16_f32 = [](unsigned short h) -> float {
-      const unsigned u = (unsigned)h << 16;
-      float f;
-      memcpy(&f, &u, 4);
-      return f;
-    };
     for (int co = 0; co < Cout; ++co)
       for (int q = 0; q < 21; ++q)
         for (int kx = 0; kx < 7; ++kx) {
           const float wv = w[((size_t)co * 3 + q / 7) * 49 + (q % 7) * 7 + kx] * (scale ? scale[co] : 1.0f);
-          const unsigned short p0 = bf16_rne(wv);
-          const float r1 = wv - bf16_f32(p0);
-          const unsigned short p1 = bf16_rne(r1);
-          const unsigned short p2 = bf16_rne(r1 - bf16_f32(p1));
-          const unsigned short pl[3] = {p0, p1, p2};
+          unsigned short pl[3];
+          split3_bf16_host(wv, pl);
           for (int pp = 0; pp < 3; ++pp)
             o16[(size_t)(co / 32) * 16896 + ((((size_t)pp * 11 + q / 2) * 2 + q % 2) * 32 + co % 32) * 8 + kx + 1] = pl[pp];
         }
@@ -375,28 +366,13 @@ void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKin
     const size_t wszp_b3 = ((size_t)24 * BN + 1023) / 1024 * 1024;
     out.assign((size_t)n_tiles * nstages * 9 * wszp_b3, 0.0f);
     unsigned short* o16 = reinterpret_cast<unsigned short*>(out.data());
-    auto bf16_rne = [](float x) -> unsigned short {
-      unsigned u;
-      memcpy(&u, &x, 4);
-      u += 0x7fffu + ((u >> 16) & 1u);
-      return (unsigned short)(u >> 16);
-    };
-    auto bf16_f32 = [](unsigned short h) -> float {
-      const unsigned u = (unsigned)h << 16;
-      float f;
-      memcpy(&f, &u, 4);
-      return f;
-    };
     for (int co = 0; co < Cout; ++co) {
       const float sc = scale ? scale[co] : 1.0f;
       for (int ci = 0; ci < Cin; ++ci)
         for (int t = 0; t < 9; ++t) {
           const float wv = w[((size_t)co * Cin + ci) * 9 + t] * sc;
-          const unsigned short p0 = bf16_rne(wv);
-          const float r1 = wv - bf16_f32(p0);
-          const unsigned short p1 = bf16_rne(r1);
-          const unsigned short p2 = bf16_rne(r1 - bf16_f32(p1));
-          const unsigned short pl[3] = {p0, p1, p2};
+          unsigned short pl[3];
+          split3_bf16_host(wv, pl);
           const size_t st = ((size_t)(co / BN) * nstages + ci / 16) * 9 + t;
           const int kk = ci % 16, h = kk / 8, q = kk % 8;
           for (int pp = 0; pp < 3; ++pp)
@@ -412,30 +388,14 @@ void tile_weights(const float* w, const float* scale, int Cout, int Cin, ConvKin
     const size_t wszp_b3 = ((size_t)24 * BN + 1023) / 1024 * 1024;
     out.assign((size_t)n_tiles * nstages * wszp_b3, 0.0f);
     unsigned short* o16 = reinterpret_cast<unsigned short*>(out.data());
-    auto bf16_rne = [](float x) -> unsigned short {       // finite inputs (weights)
-      unsigned u;
-      memcpy(&u, &x, 4);
-      u += 0x7fffu + ((u >> 16) & 1u);
-      return (unsigned short)(u >> 16);
-    };
-    auto bf16_f32 = [](unsigned short h) -> float {
-      const unsigned u = (unsigned)h << 16;
-      float f;
-      memcpy(&f, &u, 4);
-      return f;
-    };
     for (int co = 0; co < Cout; ++co) {
       const float sc = scale ? scale[co] : 1.0f;
       const int nt = co / BN, n = co % BN;
       for (int ci = 0; ci < Cin; ++ci) {
         const int s_ = ci / 16, k = ci % 16, h = k / 8, i = k % 8;
         const float wv = w[(size_t)co * Cin + ci] * sc;
-        const unsigned short p0 = bf16_rne(wv);
-        const float r1 = wv - bf16_f32(p0);
-        const unsigned short p1 = bf16_rne(r1);
-        const float r2 = r1 - bf16_f32(p1);
-        const unsigned short p2 = bf16_rne(r2);
-        const unsigned short pl[3] = {p0, p1, p2};
+        unsigned short pl[3];
+        split3_bf16_host(wv, pl);
         for (int pp = 0; pp < 3; ++pp)
           o16[(((size_t)nt * nstages + s_) * wszp_b3) * 2 + ((((size_t)pp * 2 + h) * BN + n) * 8 + i)] = pl[pp];
       }
